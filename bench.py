@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- GF(2) n x n x n matrix product on MI355X, BASELINE.json's headline metric.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one full product C = A*B over GF(2) with A and B already resident in HBM
+(n = 65536 by default; it fits one GPU: 3 x 512 MiB + workspace).  With N > 1 ranks
+(launched by torch.distributed.run, one process per GPU, RCCL) the total work is fixed
+(strong scaling): rank r keeps row block r of A resident, B lives on rank 0, and every step
+does  broadcast(B)  ->  local product of the row block  ->  gather(C blocks) on rank 0.
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed on its own
+stream inside the library) and `cpu_baseline` (the oracle's single-thread M4RM+Strassen port on
+a bounded sample, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBS = 8000.0      # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s is the measured copy rate
+HBM_COPY_GBS = 6290.0
+LDS_PEAK_TBS = 150.0       # aggregate ds_read_b128 rate, all CUs (MI355X_MICROARCH.md, LDS)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=65536, help="matrix dimension (BASELINE metric: 65536)")
+    ap.add_argument("--algo", default="auto", choices=["auto", "m4rm", "strassen"])
+    ap.add_argument("--levels", type=int, default=0, help="Strassen levels (0 = automatic)")
+    ap.add_argument("--cpu-n", type=int, default=16384, help="dimension of the CPU-baseline sample product")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--check", action="store_true", help="spot-check rows of C against the oracle after timing")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the multiply path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    import m4ri_rust_amd  # noqa: F401
+    from m4ri_rust_amd import device
+    from m4ri_rust_amd import sharded
+
+    n = args.n
+    assert n % (64 * world) == 0
+    rows = n // world
+    ldw = n // 64
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # resident operands (torch owns the memory; the library sees raw device pointers)
+    A_t = torch.empty((rows, ldw), dtype=torch.int64, device="cuda")
+    B_t = torch.empty((n, ldw), dtype=torch.int64, device="cuda")
+    C_t = torch.empty((rows, ldw), dtype=torch.int64, device="cuda")
+    A = device.DMat.from_torch(A_t, n)
+    B = device.DMat.from_torch(B_t, n)
+    C = device.DMat.from_torch(C_t, n)
+    # synthetic data: seeded splitmix64 bits (same stream as the oracle generator); rank r holds
+    # rows [r*rows, (r+1)*rows) of the global A (seed 1), B has seed 2
+    sharded.fill_row_block(A, seed=1, row0=rank * rows, stream=stream)
+    if rank == 0:
+        B.fill_random(2, stream)
+    Cfull_t = torch.empty((n, ldw), dtype=torch.int64, device="cuda") if (rank == 0 and world > 1) else None
+    torch.cuda.synchronize()
+
+    def step():
+        if world > 1:
+            sharded.step(A_t, B_t, C_t, Cfull_t, A, B, C, algo=args.algo, levels=args.levels, stream=stream)
+        else:
+            device.mul(A, B, C=C, algo=args.algo, param=args.levels, stream=stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    device.prof_enable(True)
+    device.prof_read(reset=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    device.prof_enable(False)
+    launches, kernel_ms = device.prof_read(reset=True)
+
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    bitops = 2.0 * n * n * n * args.steps
+    ms_per_step = dt * 1e3 / args.steps
+
+    # dominant kernel: the (batched) M4RM tile kernel. Algorithmic bytes of ONE launch = what that
+    # launch's products read and write once: batch * (m*l + l*n + m*n)/8 with the leaf dims.
+    levels = sharded.levels_used(rows, n, n, args.algo, args.levels)
+    mi, li, ni, batch = rows >> levels, n >> levels, n >> levels, 7 ** levels
+    alg_bytes_launch = batch * (mi * li + li * ni + mi * ni) / 8.0
+    avg_kernel_ms = kernel_ms / max(launches, 1)
+    achieved = alg_bytes_launch / (avg_kernel_ms * 1e-3) / 1e9 if launches else 0.0
+    # on-chip view: every 8 bits of the inner dimension cost one 16-byte LDS read per 128 columns
+    lds_bytes_launch = batch * (mi * (li / 8.0) * (ni / 128.0) * 16.0)
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tfile):
+        try:
+            with open(tfile) as f:
+                tj = json.load(f)
+            if tj.get("n") == n and tj.get("levels") == levels and tj.get("n_gpus") == world:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "gf2_matmul_bit_ops_per_sec_n%d" % n,
+        "value": bitops / dt,
+        "unit": "bit-ops/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong" if world > 1 else "weak",
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+        "config": {
+            "workload": "GF(2) %dx%dx%d matmul, inputs resident in HBM, %s" % (
+                n, n, n, "Strassen(%d levels)-over-M4RM" % levels if levels else "M4RM only"),
+            "n": n, "algo": args.algo, "strassen_levels": levels,
+            "parallelism": "row-block shard of A over %d GPU(s)%s" % (
+                world, ", RCCL broadcast(B) + gather(C) per step" if world > 1 else ""),
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "gf2_m4rm_kernel (batch of %d leaf products %dx%dx%d)" % (batch, mi, li, ni),
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "frac_of_measured_copy": achieved / HBM_COPY_GBS,
+            "traffic": traffic,
+            "launches": launches, "avg_launch_ms": avg_kernel_ms,
+            "algorithmic_bytes_per_launch": alg_bytes_launch,
+            "note": "this kernel is LDS-bound, not HBM-bound (see onchip); HBM fraction is small by construction",
+            "onchip": {
+                "bound": "lds", "achieved": lds_bytes_launch / (avg_kernel_ms * 1e-3) / 1e12 if launches else 0.0,
+                "peak": LDS_PEAK_TBS, "unit": "TB/s",
+                "frac": (lds_bytes_launch / (avg_kernel_ms * 1e-3) / 1e12 / LDS_PEAK_TBS) if launches else 0.0,
+            },
+        },
+        "hbm_equiv_GBps_whole_step": 3.0 * n * n / 8.0 / (ms_per_step * 1e-3) / 1e9,
+    }
+
+    if world == 1 and not args.no_cpu:
+        import numpy as np
+        import gf2util as g
+        cn = args.cpu_n
+        a, b = g.random_words(cn, cn, 1), g.random_words(cn, cn, 2)
+        g.oracle()
+        t1 = time.perf_counter()
+        c = g.o_mul_fast(a, b, cn, cn, cn)
+        cdt = time.perf_counter() - t1
+        out["cpu_baseline"] = {
+            "value": 2.0 * cn ** 3 / cdt, "unit": "bit-ops/s", "cores": 1, "kind": "port",
+            "sample": "one %dx%dx%d product by oracle_mul_fast (single-thread M4RM k=8 + Strassen-Winograd, "
+                      "gcc -Ofast, no -march), %.2f s; M4RI itself is absent from the reference tree" % (cn, cn, cn, cdt),
+            "host_cpus": os.cpu_count(),
+        }
+        if args.check and cn <= n:
+            # the GPU must reproduce the CPU sample product bit for bit
+            Ad, Bd = device.DMat.random(cn, cn, 1), device.DMat.random(cn, cn, 2)
+            out["cpu_baseline"]["gpu_matches_cpu_sample"] = bool(
+                np.array_equal(device.mul(Ad, Bd, algo=args.algo, param=args.levels).to_words(), c))
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

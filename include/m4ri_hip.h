@@ -1,0 +1,170 @@
+/*
+ * m4ri_hip.h -- C ABI of libm4ri_hip.so: the MI355X (gfx950) replacement for the part of
+ * the M4RI C library that thomwiggers/m4ri-rust reaches on its multiply path.
+ *
+ * Section 1 is the DROP-IN boundary: the struct layout and the symbols that m4ri-sys declares
+ * in `extern "C"` blocks and that the friendly layer (BinMatrix / BinVector) calls.  Every
+ * declaration cites the reference interface it replaces (paths relative to the reference
+ * repository root).  Host code that links m4ri-sys against this library instead of libm4ri.a
+ * needs no source change: see INTEGRATION.md.
+ *
+ * Section 2 is the device-resident API (raw device pointers, explicit HIP stream) used by
+ * bench.py, the multi-GPU host layer and callers that chain products without the PCIe round
+ * trip.  No torch types appear in any signature.
+ *
+ * All products are computed on the GPU by hand-written HIP kernels; there is no CPU fallback.
+ * If no HIP device is usable the multiply entry points print a diagnostic on stderr and return
+ * NULL (the m4ri-rust wrapper turns that into its "Multiplication failed" panic,
+ * m4ri-rust/src/friendly/binary_matrix.rs:467-469).
+ */
+#ifndef M4RI_HIP_H
+#define M4RI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ===================================================================================== */
+/* 1. M4RI-compatible boundary                                                            */
+/* ===================================================================================== */
+
+/* m4ri-sys/src/misc.rs:5-26 */
+typedef int rci_t;     /* Rci  */
+typedef int wi_t;      /* Wi   */
+typedef int BIT;       /* BIT  */
+typedef uint64_t word; /* Word */
+#define m4ri_radix 64
+#define m4ri_one ((word)1)
+#define m4ri_ffff ((word)0xffffffffffffffffULL)
+
+/* m4ri-sys/src/mzd.rs:16-21 (MzdBlock) */
+typedef struct {
+  size_t size; /* bytes in this block */
+  word *begin;
+  word *end;
+} mzd_block_t;
+
+/* m4ri-sys/src/mzd.rs:24-79 (#[repr(C)] Mzd, 64 bytes, size asserted mzd.rs:385).
+ * Rust reads nrows/ncols/rows directly (binary_matrix.rs:138,176,286,294) and the private
+ * fields in mzd_row / mzd_first_row (mzd.rs:277-313): offsets must not move. */
+typedef struct mzd_t {
+  rci_t nrows;           /*  0 */
+  rci_t ncols;           /*  4 */
+  wi_t width;            /*  8  ceil(ncols / 64) */
+  wi_t rowstride;        /* 12  words between rows (even-padded when width >= 3) */
+  wi_t offset_vector;    /* 16  words from blocks[0].begin to row 0 */
+  wi_t row_offset;       /* 20 */
+  uint8_t flags;         /* 24  mzd.rs:82-94 */
+  uint8_t blockrows_log; /* 25 */
+  uint8_t padding[14];   /* 26  (byte 26 holds this library's allocation kind) */
+  word high_bitmask;     /* 40  valid bits of the last word of a row */
+  mzd_block_t *blocks;   /* 48 */
+  word **rows;           /* 56  rows[i] = first word of row i, always a HOST pointer */
+} mzd_t;
+
+/* m4ri-sys/src/mzd.rs:82-94 */
+#define mzd_flag_nonzero_excess 0x2
+#define mzd_flag_windowed_zerooffset 0x4
+#define mzd_flag_windowed_zeroexcess 0x8
+#define mzd_flag_windowed_ownsblocks 0x10
+#define mzd_flag_multiple_blocks 0x20
+
+/* --- container support (host side) --- */
+mzd_t *mzd_init(rci_t rows, rci_t cols);                           /* mzd.rs:98  */
+void mzd_free(mzd_t *A);                                           /* mzd.rs:102 */
+mzd_t *mzd_init_window(mzd_t *M, rci_t lowr, rci_t lowc, rci_t highr, rci_t highc); /* mzd.rs:121-127 */
+mzd_t *mzd_copy(mzd_t *dst, mzd_t const *src);                     /* mzd.rs:192 */
+int mzd_equal(mzd_t const *A, mzd_t const *B);                     /* mzd.rs:187 */
+void mzd_randomize(mzd_t *A);                                      /* mzd.rs:184 */
+void mzd_set_ui(mzd_t *A, unsigned int value);                     /* mzd.rs:198 */
+mzd_t *mzd_transpose(mzd_t *dst, mzd_t const *A);                  /* mzd.rs:148 */
+mzd_t *mzd_add(mzd_t *C, mzd_t const *A, mzd_t const *B);          /* mzd.rs:223 */
+mzd_t *mzd_sub(mzd_t *C, mzd_t const *A, mzd_t const *B);          /* mzd.rs:230 */
+mzd_t *mzd_concat(mzd_t *C, mzd_t const *A, mzd_t const *B);       /* mzd.rs:195 */
+mzd_t *mzd_stack(mzd_t *C, mzd_t const *A, mzd_t const *B);        /* mzd.rs:201 */
+mzd_t *mzd_submatrix(mzd_t *S, mzd_t const *M, rci_t lowr, rci_t lowc, rci_t highr, rci_t highc); /* mzd.rs:205-212 */
+int mzd_is_zero(mzd_t const *A);                                   /* mzd.rs:233 */
+void mzd_row_swap(mzd_t *M, rci_t rowa, rci_t rowb);               /* mzd.rs:130 */
+void mzd_copy_row(mzd_t *B, rci_t i, mzd_t const *A, rci_t j);     /* mzd.rs:141 */
+int m4ri_opt_k(int a, int b, int c);                               /* graycode.rs:56 */
+
+/* --- the hot path: every product below runs on the GPU --- */
+
+/* C = A*B, Method of the Four Russians. C may be NULL (allocated). k is M4RI's table-size
+ * hint (0 = automatic); the device kernel uses 8-bit tables in LDS whatever k says.
+ * brilliantrussian.rs:210-216; caller binary_matrix.rs:59 */
+mzd_t *mzd_mul_m4rm(mzd_t *C, mzd_t const *A, mzd_t const *B, int k);
+/* C ^= A*B. brilliantrussian.rs:218-224 */
+mzd_t *mzd_addmul_m4rm(mzd_t *C, mzd_t const *A, mzd_t const *B, int k);
+/* C = A*B, Strassen recursion over M4RM leaves; cutoff = minimal dimension for recursion,
+ * 0 = library default. strassen.rs:8-18; caller binary_matrix.rs:72 (the default `*`) */
+mzd_t *mzd_mul(mzd_t *C, mzd_t const *A, mzd_t const *B, int cutoff);
+/* C ^= A*B. strassen.rs:20-31 */
+mzd_t *mzd_addmul(mzd_t *C, mzd_t const *A, mzd_t const *B, int cutoff);
+/* C = A*B, "naive" entry. mzd.rs:150-152; callers binary_matrix.rs:82 and :427 (mul_slice) */
+mzd_t *mzd_mul_naive(mzd_t *C, mzd_t const *A, mzd_t const *B);
+/* C ^= A*B. mzd.rs:170-173 */
+mzd_t *mzd_addmul_naive(mzd_t *C, mzd_t const *A, mzd_t const *B);
+/* C (+)= A * Bt^T with Bt pre-transposed (n x l); clear != 0 overwrites. mzd.rs:154-168 */
+mzd_t *_mzd_mul_naive(mzd_t *C, mzd_t const *A, mzd_t const *Bt, int clear);
+/* C (+)= v*A, v a 1 x l row. mzd.rs:175-181 */
+mzd_t *_mzd_mul_va(mzd_t *C, mzd_t const *v, mzd_t const *A, int clear);
+
+/* ===================================================================================== */
+/* 2. Device-resident API                                                                 */
+/* ===================================================================================== */
+
+/* A dense bit matrix in device memory: row-major 64-bit words, LSB-first, `ld` words between
+ * rows (ld even, base 16-byte aligned), excess bits of the last word zero. */
+typedef struct {
+  uint64_t *data; /* device pointer */
+  int64_t ld;     /* words per row stride */
+  int nrows;
+  int ncols;
+} gf2_dmat;
+
+enum { GF2_ALGO_AUTO = 0, GF2_ALGO_M4RM = 1, GF2_ALGO_STRASSEN = 2, GF2_ALGO_NAIVE = 3 };
+
+/* 0 on success, HIP error code (>0) or -1 (bad arguments) otherwise. */
+int gf2_device_count(void);                 /* usable HIP devices (0 if none) */
+const char *gf2_last_error(void);           /* thread-local text of the last failure */
+
+/* allocation helpers (hipMalloc / hipFree on the current device) */
+int gf2_dmat_alloc(gf2_dmat *M, int nrows, int ncols);
+void gf2_dmat_free(gf2_dmat *M);
+int gf2_dmat_upload(gf2_dmat *dst, mzd_t const *src, void *stream);   /* host mzd_t -> device */
+int gf2_dmat_download(mzd_t *dst, gf2_dmat const *src, void *stream); /* device -> host mzd_t */
+int gf2_dmat_fill_random(gf2_dmat *M, uint64_t seed, void *stream);   /* splitmix64 stream, same as the oracle */
+/* same stream, but M holds rows [row0, row0 + M->nrows) of the full matrix (row-block shards) */
+int gf2_dmat_fill_random_rows(gf2_dmat *M, uint64_t seed, int64_t row0, void *stream);
+
+/* C (+)= A*B on `stream` (hipStream_t, NULL = default stream); asynchronous.
+ * algo: GF2_ALGO_*; param: Strassen levels when algo==STRASSEN (0 = automatic), else ignored. */
+int gf2_mul_dev(gf2_dmat *C, gf2_dmat const *A, gf2_dmat const *B, int accumulate, int algo, int param,
+                void *stream);
+/* C (+)= A * Bt^T (row-parity form, mzd.rs:154-168) */
+int gf2_mul_nt_dev(gf2_dmat *C, gf2_dmat const *A, gf2_dmat const *Bt, int accumulate, void *stream);
+/* C = A xor B (mzd.rs:223), D = S^T (mzd.rs:148), equality (mzd.rs:187; *equal = 1/0) */
+int gf2_add_dev(gf2_dmat *C, gf2_dmat const *A, gf2_dmat const *B, void *stream);
+int gf2_transpose_dev(gf2_dmat *D, gf2_dmat const *S, void *stream);
+int gf2_equal_dev(gf2_dmat const *A, gf2_dmat const *B, int *equal, void *stream);
+
+/* Strassen levels the library will use for this shape (0 = plain M4RM) */
+int gf2_strassen_levels(int m, int l, int n, int algo, int param);
+/* bytes of scratch a product of this shape needs (Strassen operands, packed copies);
+ * the library keeps one cached arena per device and grows it on demand. */
+size_t gf2_mul_workspace_bytes(int m, int l, int n, int algo, int param);
+
+/* kernel timing for bench.py's roofline object: HIP events recorded on the launch stream
+ * around every launch of the dominant multiply kernel while enabled. */
+void gf2_prof_enable(int on);
+/* sums since the last reset: *launches, *ms = total event-measured duration of those launches */
+int gf2_prof_read(int *launches, double *ms, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M4RI_HIP_H */

@@ -1,0 +1,38 @@
+// gf2_kernels.h -- internal interface between the kernels (gf2_kernels.hip) and the C-ABI layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// One (batched) product C (+)= A*B on dense device buffers; strides in 64-bit words.
+struct gf2k_mul_args {
+  const uint64_t *A;
+  const uint64_t *B;
+  uint64_t *C;
+  long long lda, ldb, ldc;  // row strides
+  long long sA, sB, sC;     // batch strides
+  int m, l, n;              // bits
+  int tiles_m, tiles_n;     // filled in by the launcher
+  int batch;
+  int accumulate;  // 0: C = A*B, 1: C ^= A*B
+};
+
+extern "C" {
+int gf2k_m4rm_rows_per_tile(int cfg);
+hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream);
+hipError_t gf2k_rowparity(const uint64_t *A, long long lda, const uint64_t *Bt, long long ldbt, uint64_t *C, long long ldc,
+                          int m, int l, int n, int accumulate, hipStream_t stream);
+hipError_t gf2k_va(const uint64_t *A, long long lda, const uint64_t *B, long long ldb, uint64_t *C, long long ldc, int m,
+                   int l, int n, hipStream_t stream);
+hipError_t gf2k_xor2d(uint64_t *C, long long ldc, const uint64_t *A, long long lda, const uint64_t *B, long long ldb,
+                      int rows, int words, hipStream_t stream);
+hipError_t gf2k_fill_random(uint64_t *M, long long ld, int rows, int cols, uint64_t seed, long long row0,
+                            hipStream_t stream);
+hipError_t gf2k_diff(const uint64_t *A, long long lda, const uint64_t *B, long long ldb, int rows, int cols, int *diff,
+                     hipStream_t stream);
+hipError_t gf2k_transpose(uint64_t *D, long long ldd, const uint64_t *S, long long lds_, int rows, int cols,
+                          hipStream_t stream);
+hipError_t gf2k_strassen_split(uint64_t *dst, long long ldd, long long dstStride, const uint64_t *src, long long lds_,
+                               long long srcStride, int h, int w, int side, int batch, hipStream_t stream);
+hipError_t gf2k_strassen_merge(uint64_t *dst, long long ldd, long long dstStride, const uint64_t *src, long long lds_,
+                               long long srcStride, int h, int w, int accumulate, int batch, hipStream_t stream);
+}

@@ -1,0 +1,651 @@
+// gf2_kernels.hip -- hand-written gfx950 (MI355X / CDNA4) kernels for dense GF(2) products.
+//
+// Replaces, on the device, the M4RI routines reached by m4ri-rust's `*`:
+//   mzd_mul_m4rm / mzd_addmul_m4rm   (/root/reference/m4ri-sys/src/brilliantrussian.rs:210-224)
+//   mzd_mul / mzd_addmul             (/root/reference/m4ri-sys/src/strassen.rs:8-31)
+//   mzd_mul_naive / _mzd_mul_naive   (/root/reference/m4ri-sys/src/mzd.rs:150-168)
+//   _mzd_mul_va                      (/root/reference/m4ri-sys/src/mzd.rs:175-181)
+// plus mzd_add / mzd_transpose / mzd_equal / mzd_randomize equivalents on device buffers.
+//
+// Data layout in HBM: row-major 64-bit words, bit j of a row = bit (j%64) of word j/64 (LSB first,
+// mzd.rs:246-269), row stride `ld` words (even), excess bits of the last word zero.
+//
+// Design notes:
+//  * gf2_m4rm_kernel: one workgroup owns an R x 2048-column tile of C held entirely in VGPRs
+//    (R = WAVES*RPW rows).  The inner dimension is consumed 8 bits at a time: the workgroup builds
+//    the 256-entry Four-Russians table of 8 rows of B (256 entries x 256 B = 64 KiB, double buffered
+//    in LDS, Gray-code order per half-wave), then every 16-lane group looks up the table row selected
+//    by a byte of A with one conflict-free ds_read_b128 and XORs it into its accumulators.  The table
+//    row is exactly one LDS bank row (64 banks x 4 B), so any mix of entries is conflict free.
+//    The LDS byte address is formed by ONE v_perm_b32: {0, table-select, A byte, lane offset}.
+//  * everything else is an HBM-streaming kernel with 16-byte accesses.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gf2_kernels.h"
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+// ---------------------------------------------------------------------------------------------
+// M4RM tile kernel
+// ---------------------------------------------------------------------------------------------
+
+static constexpr int kTileWords = 32;          // 2048 columns per tile = one 256-byte LDS bank row
+static constexpr int kTableBytes = 256 * 256;  // 2^8 entries x 256 B
+static constexpr int kStageBytes = 64 * 256;   // 64 rows of B x 256 B
+static constexpr int kLdsBytes = 2 * kTableBytes + kStageBytes;
+
+__device__ __forceinline__ uint4 xor4(uint4 a, uint4 b) {
+  return make_uint4(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w);
+}
+
+template <int N>
+struct Log2 {
+  static constexpr int value = 1 + Log2<N / 2>::value;
+};
+template <>
+struct Log2<1> {
+  static constexpr int value = 0;
+};
+
+template <int WAVES, int RPW>
+__global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel(const gf2k_mul_args p) {
+  constexpr int NT = WAVES * 64;
+  constexpr int R = WAVES * RPW;
+  constexpr int STEPS = RPW / 4;  // 4 rows (one per 16-lane group) per ds_read_b128
+  extern __shared__ __align__(16) unsigned char lds[];
+  unsigned char *const stg = lds + 2 * kTableBytes;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // XCD-aware, bijective remap: blocks b and b+8 share an XCD (L2); give each XCD a contiguous
+  // range of logical tiles so that the row tiles sharing a B column panel sit in one L2.
+  int t;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = t % p.tiles_m;
+  t /= p.tiles_m;
+  const int tn = t % p.tiles_n;
+  const int bt = t / p.tiles_n;
+
+  const u64 *__restrict__ A = p.A + (long long)bt * p.sA;
+  const u64 *__restrict__ B = p.B + (long long)bt * p.sB;
+  u64 *__restrict__ C = p.C + (long long)bt * p.sC;
+
+  const int row0 = tm * R, w0 = tn * kTileWords;
+  const int widthA = (p.l + 63) >> 6, widthB = (p.n + 63) >> 6;
+  const u64 maskA = (p.l & 63) ? ((1ull << (p.l & 63)) - 1) : ~0ull;
+  const u64 maskC = (p.n & 63) ? ((1ull << (p.n & 63)) - 1) : ~0ull;
+
+  const int g = lane >> 4, qd = lane & 15;
+  const u32 laneoff0 = (u32)qd * 16u;        // byte offset inside a table row, table 0
+  const u32 laneoff1 = laneoff0 | 0x10000u;  // same, table 1 (at +64 KiB)
+  const int myrow0 = row0 + wave * RPW + g;  // row of step s = myrow0 + 4*s
+
+  uint4 acc[STEPS];
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) acc[s] = make_uint4(0, 0, 0, 0);
+
+  // B staging: 512 pieces of 32 B (64 rows x 8 pieces) per 64-bit block of the inner dimension
+  constexpr int PIECES = (512 + NT - 1) / NT;
+  uint4 breg[PIECES][2];
+  auto loadB = [&](int lb) {
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const int pc = tid + i * NT;
+      const int brow = lb * 64 + (pc >> 3), wd = w0 + (pc & 7) * 4;
+      uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
+      if (pc < 512 && brow < p.l) {
+        const u64 *src = B + (long long)brow * p.ldb + wd;
+        if (wd + 3 < widthB) {
+          v0 = *reinterpret_cast<const uint4 *>(src);
+          v1 = *reinterpret_cast<const uint4 *>(src + 2);
+        } else {
+          u64 x0 = (wd + 0 < widthB) ? src[0] : 0, x1 = (wd + 1 < widthB) ? src[1] : 0;
+          u64 x2 = (wd + 2 < widthB) ? src[2] : 0;
+          v0 = make_uint4((u32)x0, (u32)(x0 >> 32), (u32)x1, (u32)(x1 >> 32));
+          v1 = make_uint4((u32)x2, (u32)(x2 >> 32), 0, 0);
+        }
+      }
+      breg[i][0] = v0;
+      breg[i][1] = v1;
+    }
+  };
+  auto storeB = [&]() {
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const int pc = tid + i * NT;
+      if (pc < 512) {
+        uint4 *d = reinterpret_cast<uint4 *>(stg + (pc >> 3) * 256 + (pc & 7) * 32);
+        d[0] = breg[i][0];
+        d[1] = breg[i][1];
+      }
+    }
+  };
+
+  // table build: half-wave hw owns entries [hw*EPH, (hw+1)*EPH); lane j of the half owns word j.
+  constexpr int EPH = 256 / (2 * WAVES);
+  constexpr int LOWB = Log2<EPH>::value;
+  const int hw = wave * 2 + (lane >> 5), jw = lane & 31;
+  auto build = [&](int c, int tb) {
+    u64 rr[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) rr[b] = *reinterpret_cast<const u64 *>(stg + (8 * c + b) * 256 + jw * 8);
+    u64 cur = 0;
+#pragma unroll
+    for (int b = LOWB; b < 8; ++b)
+      if ((hw >> (b - LOWB)) & 1) cur ^= rr[b];
+    unsigned char *dst = lds + tb * kTableBytes + (hw << LOWB) * 256 + jw * 8;
+    *reinterpret_cast<u64 *>(dst) = cur;
+    unsigned e = 0;
+#pragma unroll
+    for (int i = 1; i < EPH; ++i) {
+      const int bit = __builtin_ctz(i);
+      cur ^= rr[bit];
+      e ^= 1u << bit;
+      *reinterpret_cast<u64 *>(dst + e * 256) = cur;
+    }
+  };
+
+  // A words are kept as 32-bit halves (one register per row): half h of 64-bit block lb is loaded
+  // while the previous half's last table is still being consumed, so the load latency sits under a
+  // table build + barrier.
+  u32 aw[STEPS];
+  const u32 maskA_lo = (u32)maskA, maskA_hi = (u32)(maskA >> 32);
+  // uniform tile base + 32-bit per-lane byte offsets; the offsets are recomputed per load (2 VALU)
+  // instead of being kept in 2*STEPS address registers -- the asm barrier stops hipcc hoisting them.
+  const char *const Atile = reinterpret_cast<const char *>(A + (long long)row0 * p.lda);
+  const u32 ldaB = (u32)p.lda * 8u;
+  const u32 rowoff0 = (u32)(wave * RPW + g) * ldaB;
+  const u32 maxoff = (u32)(min(p.m - row0, R) - 1) * ldaB;  // rows past m are clamped, computed, never stored
+  auto loadA = [&](int lb, int half) {
+    u32 ro = rowoff0;
+    asm volatile("" : "+v"(ro));
+    const char *base = Atile + (long long)lb * 8 + half * 4;
+    const u32 msk = (lb == widthA - 1) ? (half ? maskA_hi : maskA_lo) : 0xffffffffu;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      const u32 off = min(ro + (u32)s * 4u * ldaB, maxoff);
+      aw[s] = *reinterpret_cast<const u32 *>(base + off) & msk;
+    }
+  };
+
+  const int nlb = widthA;
+  if (nlb > 0) {
+    loadB(0);
+    loadA(0, 0);
+  }
+  for (int lb = 0; lb < nlb; ++lb) {
+    storeB();  // safe: every build of the previous block finished before its last barrier
+    if (lb + 1 < nlb) loadB(lb + 1);
+    __syncthreads();
+    const int lbits = p.l - lb * 64;  // valid bits in this block (>0)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll 1
+      for (int c4 = 0; c4 < 4; ++c4) {
+        const int c = half * 4 + c4;
+        if (c * 8 >= lbits) break;  // workgroup-uniform
+        const int tb = c4 & 1;
+        build(c, tb);
+        __syncthreads();
+        const u32 lo = tb ? laneoff1 : laneoff0;
+        // v_perm_b32 selector: byte0 <- lo.byte0, byte1 <- aw.byte[c4], byte2 <- lo.byte2, byte3 <- 0
+        const u32 sel = 0x0c020000u | ((4u + (u32)c4) << 8);
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+          const u32 addr = __builtin_amdgcn_perm(aw[s], lo, sel);
+          const uint4 tv = *reinterpret_cast<const uint4 *>(lds + addr);
+          acc[s] = xor4(acc[s], tv);
+        }
+      }
+      // next half's A words (wave-uniform control flow)
+      if (half == 0) {
+        if (lbits > 32) loadA(lb, 1);
+      } else if (lb + 1 < nlb) {
+        loadA(lb + 1, 0);
+      }
+    }
+  }
+
+  // epilogue: lane (g, qd) holds words w0+2qd, w0+2qd+1 of row myrow0+4s
+  const int wc = w0 + 2 * qd;
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    const int row = myrow0 + 4 * s;
+    if (row < p.m && wc < widthB) {
+      u64 *dst = C + (long long)row * p.ldc + wc;
+      u64 v0 = (u64)acc[s].x | ((u64)acc[s].y << 32);
+      u64 v1 = (u64)acc[s].z | ((u64)acc[s].w << 32);
+      if (wc == widthB - 1) v0 &= maskC;
+      if (wc + 1 == widthB - 1) v1 &= maskC;
+      if (wc + 1 < widthB) {
+        if (p.accumulate) {
+          const uint4 old = *reinterpret_cast<const uint4 *>(dst);
+          v0 ^= (u64)old.x | ((u64)old.y << 32);
+          v1 ^= (u64)old.z | ((u64)old.w << 32);
+        }
+        *reinterpret_cast<uint4 *>(dst) = make_uint4((u32)v0, (u32)(v0 >> 32), (u32)v1, (u32)(v1 >> 32));
+      } else {
+        if (p.accumulate) v0 ^= dst[0];
+        dst[0] = v0;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// row-parity kernel: C (m x n) (+)= A (m x l) * Bt^T, Bt is n x l   (_mzd_mul_naive, mzd.rs:154-168)
+// one lane per (row of A, 64-bit output word).  HBM-streaming over A.
+// ---------------------------------------------------------------------------------------------
+
+template <int WL>  // words of the inner dimension held in registers
+__global__ __launch_bounds__(256) void gf2_rowparity_kernel(const u64 *__restrict__ A, long long lda,
+                                                            const u64 *__restrict__ Bt, long long ldbt,
+                                                            u64 *__restrict__ C, long long ldc, int m, int l, int n,
+                                                            int accumulate) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int jw = blockIdx.y;
+  if (i >= m) return;
+  const int wl = (l + 63) >> 6;
+  const u64 maskL = (l & 63) ? ((1ull << (l & 63)) - 1) : ~0ull;
+  const int nb = min(64, n - 64 * jw);
+  u64 out = 0;
+  if constexpr (WL > 0) {
+    u64 a[WL];
+    const u64 *ar = A + i * lda;
+    if constexpr (WL % 2 == 0) {
+#pragma unroll
+      for (int t = 0; t < WL; t += 2) {
+        if (t + 1 < wl) {
+          const uint4 v = *reinterpret_cast<const uint4 *>(ar + t);
+          a[t] = (u64)v.x | ((u64)v.y << 32);
+          a[t + 1] = (u64)v.z | ((u64)v.w << 32);
+        } else {
+          a[t] = (t < wl) ? ar[t] : 0;
+          a[t + 1] = 0;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < WL; ++t) a[t] = (t < wl) ? ar[t] : 0;
+    }
+#pragma unroll
+    for (int t = 0; t < WL; ++t)
+      if (t == wl - 1) a[t] &= maskL;
+    for (int jj = 0; jj < nb; ++jj) {
+      const u64 *b = Bt + (long long)(64 * jw + jj) * ldbt;  // wave-uniform -> scalar loads
+      u64 x = 0;
+#pragma unroll
+      for (int t = 0; t < WL; ++t)
+        if (t < wl) x ^= a[t] & b[t];
+      out |= (u64)(__popcll(x) & 1) << jj;
+    }
+  } else {
+    const u64 *ar = A + i * lda;
+    for (int jj = 0; jj < nb; ++jj) {
+      const u64 *b = Bt + (long long)(64 * jw + jj) * ldbt;
+      u64 x = 0;
+      for (int t = 0; t < wl; ++t) {
+        u64 v = ar[t] & b[t];
+        if (t == wl - 1) v &= maskL;
+        x ^= v;
+      }
+      out |= (u64)(__popcll(x) & 1) << jj;
+    }
+  }
+  u64 *dst = C + i * ldc + jw;
+  if (accumulate) out ^= *dst;
+  *dst = out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// v*A kernel: C (m x n) (+)= A (m x l) * B (l x n) for a handful of rows m <= 8 (_mzd_mul_va,
+// mzd.rs:175-181 and `&v * &A`, binary_matrix.rs:552-563).  Streams B once; the inner dimension
+// is split over blockIdx.y and partial sums are combined with 64-bit atomic XOR.
+// ---------------------------------------------------------------------------------------------
+
+template <int M>
+__global__ __launch_bounds__(256) void gf2_va_kernel(const u64 *__restrict__ A, long long lda,
+                                                     const u64 *__restrict__ B, long long ldb, u64 *__restrict__ C,
+                                                     long long ldc, int m, int l, int n, int rows_per_split) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  const int wn = (n + 63) >> 6;
+  const int t0 = blockIdx.y * rows_per_split;
+  const int t1 = min(l, t0 + rows_per_split);
+  u64 acc[M];
+#pragma unroll
+  for (int i = 0; i < M; ++i) acc[i] = 0;
+  if (w < wn) {
+    for (int t = t0; t < t1; ++t) {
+      const u64 bw = B[(long long)t * ldb + w];
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
+        if (i < m) {
+          const u64 aw = A[(long long)i * lda + (t >> 6)];  // wave-uniform
+          if ((aw >> (t & 63)) & 1) acc[i] ^= bw;
+        }
+      }
+    }
+    const u64 maskC = (n & 63) ? ((1ull << (n & 63)) - 1) : ~0ull;
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+      if (i < m) {
+        u64 v = acc[i];
+        if (w == wn - 1) v &= maskC;
+        if (v) atomicXor(reinterpret_cast<unsigned long long *>(C + (long long)i * ldc + w), (unsigned long long)v);
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// streaming helpers
+// ---------------------------------------------------------------------------------------------
+
+// C = A ^ B over a rows x words region (mzd_add, mzd.rs:220-223); also copy (B == nullptr) and zero.
+__global__ __launch_bounds__(256) void gf2_xor2d_kernel(u64 *__restrict__ C, long long ldc, const u64 *A, long long lda,
+                                                        const u64 *B, long long ldb, int rows, int words) {
+  const int pairs = (words + 1) >> 1;
+  const long long total = (long long)rows * pairs;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(idx / pairs), w = (int)(idx % pairs) * 2;
+    if (w + 1 < words) {
+      uint4 a = A ? *reinterpret_cast<const uint4 *>(A + (long long)r * lda + w) : make_uint4(0, 0, 0, 0);
+      if (B) a = xor4(a, *reinterpret_cast<const uint4 *>(B + (long long)r * ldb + w));
+      *reinterpret_cast<uint4 *>(C + (long long)r * ldc + w) = a;
+    } else {
+      u64 a = A ? A[(long long)r * lda + w] : 0;
+      if (B) a ^= B[(long long)r * ldb + w];
+      C[(long long)r * ldc + w] = a;
+    }
+  }
+}
+
+// splitmix64 counter stream, identical to oracle_fill_random (test/bench input generator;
+// stands in for mzd_randomize, mzd.rs:183-184)
+__global__ __launch_bounds__(256) void gf2_fill_random_kernel(u64 *M, long long ld, int rows, int cols, u64 seed,
+                                                              long long row0) {
+  const int w = (cols + 63) >> 6;
+  const u64 tm = (cols & 63) ? ((1ull << (cols & 63)) - 1) : ~0ull;
+  const long long total = (long long)rows * w;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(idx / w), j = (int)(idx % w);
+    u64 z = seed + ((u64)(idx + row0 * w) + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    if (j == w - 1) z &= tm;
+    M[(long long)r * ld + j] = z;
+  }
+}
+
+// mzd_equal (mzd.rs:187): *diff != 0 iff some valid word differs
+__global__ __launch_bounds__(256) void gf2_diff_kernel(const u64 *A, long long lda, const u64 *B, long long ldb, int rows,
+                                                       int cols, int *diff) {
+  const int w = (cols + 63) >> 6;
+  const u64 tm = (cols & 63) ? ((1ull << (cols & 63)) - 1) : ~0ull;
+  const long long total = (long long)rows * w;
+  int bad = 0;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(idx / w), j = (int)(idx % w);
+    u64 x = A[(long long)r * lda + j] ^ B[(long long)r * ldb + j];
+    if (j == w - 1) x &= tm;
+    bad |= (x != 0);
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(diff, 1);
+}
+
+// mzd_transpose (mzd.rs:146-148): 64x64 bit blocks.  One wave per block: lane r loads word
+// (row 64*bi + r, word bj), the block is transposed with 6 butterfly exchange rounds over lanes,
+// lane c stores word (row 64*bj + c, word bi).
+__global__ __launch_bounds__(256) void gf2_transpose_kernel(u64 *__restrict__ D, long long ldd, const u64 *__restrict__ S,
+                                                            long long lds_, int rows, int cols) {
+  const int lane = threadIdx.x & 63;
+  const int wavesPerBlock = blockDim.x >> 6;
+  const int bj = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6);  // source word column
+  const int bi = blockIdx.y;                                       // source row block
+  const int sw = (cols + 63) >> 6, dw = (rows + 63) >> 6;
+  if (bj >= sw) return;
+  const int r = 64 * bi + lane;
+  u64 x = (r < rows) ? S[(long long)r * lds_ + bj] : 0;
+  if (bj == sw - 1 && (cols & 63)) x &= (1ull << (cols & 63)) - 1;
+  // butterfly transpose: after round with distance d, bit positions and lane indices swap bit log2(d)
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const u64 mask = (d == 32)  ? 0x00000000FFFFFFFFull
+                     : (d == 16) ? 0x0000FFFF0000FFFFull
+                     : (d == 8)  ? 0x00FF00FF00FF00FFull
+                     : (d == 4)  ? 0x0F0F0F0F0F0F0F0Full
+                     : (d == 2)  ? 0x3333333333333333ull
+                                 : 0x5555555555555555ull;
+    const u64 y = __shfl_xor(x, d, 64);
+    if (lane & d)
+      x = (x & ~mask) | ((y >> d) & mask);
+    else
+      x = (x & mask) | ((y << d) & ~mask);
+  }
+  const int orow = 64 * bj + lane;
+  if (orow < cols) D[(long long)orow * ldd + bi] = x;
+  (void)dw;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Strassen level kernels (mzd_mul, strassen.rs:8-18).  One pass per level and side:
+//   split:  X (2h x 2w words-blocks) -> 7 operands of h rows x w words each
+//   merge:  7 products -> the 4 quadrants of C
+// Classic Strassen over GF(2) (all signs +):
+//   M1=(A11+A22)(B11+B22) M2=(A21+A22)B11 M3=A11(B12+B22) M4=A22(B21+B11) M5=(A11+A12)B22
+//   M6=(A21+A11)(B11+B12) M7=(A12+A22)(B21+B22)
+//   C11=M1+M4+M5+M7 C12=M3+M5 C21=M2+M4 C22=M1+M2+M3+M6
+// Each source word is read once and each destination word written once (11 block-units of traffic).
+// blockIdx.z = batch (operands produced by the previous level).
+// ---------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void gf2_strassen_split_kernel(u64 *__restrict__ dst, long long ldd, long long dstStride,
+                                                                 const u64 *__restrict__ src, long long lds_,
+                                                                 long long srcStride, int h, int w, int side) {
+  // dst holds 7 consecutive operands per batch element: operand q at dst + (7*b + q)*dstStride
+  const int b = blockIdx.z;
+  const u64 *X = src + (long long)b * srcStride;
+  u64 *Y = dst + (long long)b * 7 * dstStride;
+  const int pairs = w >> 1;
+  const long long total = (long long)h * pairs;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(idx / pairs), c = (int)(idx % pairs) * 2;
+    const uint4 x11 = *reinterpret_cast<const uint4 *>(X + (long long)r * lds_ + c);
+    const uint4 x12 = *reinterpret_cast<const uint4 *>(X + (long long)r * lds_ + w + c);
+    const uint4 x21 = *reinterpret_cast<const uint4 *>(X + (long long)(r + h) * lds_ + c);
+    const uint4 x22 = *reinterpret_cast<const uint4 *>(X + (long long)(r + h) * lds_ + w + c);
+    uint4 o[7];
+    if (side == 0) {  // A side
+      o[0] = xor4(x11, x22);
+      o[1] = xor4(x21, x22);
+      o[2] = x11;
+      o[3] = x22;
+      o[4] = xor4(x11, x12);
+      o[5] = xor4(x21, x11);
+      o[6] = xor4(x12, x22);
+    } else {  // B side
+      o[0] = xor4(x11, x22);
+      o[1] = x11;
+      o[2] = xor4(x12, x22);
+      o[3] = xor4(x21, x11);
+      o[4] = x22;
+      o[5] = xor4(x11, x12);
+      o[6] = xor4(x21, x22);
+    }
+#pragma unroll
+    for (int q = 0; q < 7; ++q) *reinterpret_cast<uint4 *>(Y + q * dstStride + (long long)r * ldd + c) = o[q];
+  }
+}
+
+__global__ __launch_bounds__(256) void gf2_strassen_merge_kernel(u64 *__restrict__ dst, long long ldd, long long dstStride,
+                                                                 const u64 *__restrict__ src, long long lds_,
+                                                                 long long srcStride, int h, int w, int accumulate) {
+  const int b = blockIdx.z;
+  const u64 *M = src + (long long)b * 7 * srcStride;
+  u64 *Cq = dst + (long long)b * dstStride;
+  const int pairs = w >> 1;
+  const long long total = (long long)h * pairs;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(idx / pairs), c = (int)(idx % pairs) * 2;
+    uint4 m[7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) m[q] = *reinterpret_cast<const uint4 *>(M + q * srcStride + (long long)r * lds_ + c);
+    uint4 c11 = xor4(xor4(m[0], m[3]), xor4(m[4], m[6]));
+    uint4 c12 = xor4(m[2], m[4]);
+    uint4 c21 = xor4(m[1], m[3]);
+    uint4 c22 = xor4(xor4(m[0], m[1]), xor4(m[2], m[5]));
+    uint4 *p11 = reinterpret_cast<uint4 *>(Cq + (long long)r * ldd + c);
+    uint4 *p12 = reinterpret_cast<uint4 *>(Cq + (long long)r * ldd + w + c);
+    uint4 *p21 = reinterpret_cast<uint4 *>(Cq + (long long)(r + h) * ldd + c);
+    uint4 *p22 = reinterpret_cast<uint4 *>(Cq + (long long)(r + h) * ldd + w + c);
+    if (accumulate) {
+      c11 = xor4(c11, *p11);
+      c12 = xor4(c12, *p12);
+      c21 = xor4(c21, *p21);
+      c22 = xor4(c22, *p22);
+    }
+    *p11 = c11;
+    *p12 = c12;
+    *p21 = c21;
+    *p22 = c22;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers (internal C ABI used by m4ri_hip_api.cpp)
+// ---------------------------------------------------------------------------------------------
+
+static inline int grid_for(long long total, int block = 256, int cap = 256 * 8) {
+  long long g = (total + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+extern "C" int gf2k_m4rm_rows_per_tile(int cfg) { return cfg == 1 ? 256 : 1024; }
+
+extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {
+  if (a.m <= 0 || a.n <= 0 || a.batch <= 0) return hipSuccess;
+  const int R = gf2k_m4rm_rows_per_tile(cfg);
+  a.tiles_m = (a.m + R - 1) / R;
+  a.tiles_n = (a.n + 2047) / 2048;
+  const long long nwg = (long long)a.tiles_m * a.tiles_n * a.batch;
+  if (nwg > 0x7fffffffLL) return hipErrorInvalidValue;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gf2_m4rm_kernel<8, 128>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gf2_m4rm_kernel<4, 64>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  if (cfg == 1)
+    hipLaunchKernelGGL((gf2_m4rm_kernel<4, 64>), dim3((unsigned)nwg), dim3(256), kLdsBytes, stream, a);
+  else
+    hipLaunchKernelGGL((gf2_m4rm_kernel<8, 128>), dim3((unsigned)nwg), dim3(512), kLdsBytes, stream, a);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t gf2k_rowparity(const u64 *A, long long lda, const u64 *Bt, long long ldbt, u64 *C, long long ldc,
+                                     int m, int l, int n, int accumulate, hipStream_t stream) {
+  if (m <= 0 || n <= 0) return hipSuccess;
+  const int wl = (l + 63) >> 6;
+  dim3 grid((m + 255) / 256, (n + 63) / 64), block(256);
+  const bool vec_ok = (lda % 2 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+  if (wl <= 1)
+    hipLaunchKernelGGL((gf2_rowparity_kernel<1>), grid, block, 0, stream, A, lda, Bt, ldbt, C, ldc, m, l, n, accumulate);
+  else if (wl <= 2 && vec_ok)
+    hipLaunchKernelGGL((gf2_rowparity_kernel<2>), grid, block, 0, stream, A, lda, Bt, ldbt, C, ldc, m, l, n, accumulate);
+  else if (wl <= 4 && vec_ok)
+    hipLaunchKernelGGL((gf2_rowparity_kernel<4>), grid, block, 0, stream, A, lda, Bt, ldbt, C, ldc, m, l, n, accumulate);
+  else if (wl <= 8 && vec_ok)
+    hipLaunchKernelGGL((gf2_rowparity_kernel<8>), grid, block, 0, stream, A, lda, Bt, ldbt, C, ldc, m, l, n, accumulate);
+  else
+    hipLaunchKernelGGL((gf2_rowparity_kernel<0>), grid, block, 0, stream, A, lda, Bt, ldbt, C, ldc, m, l, n, accumulate);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t gf2k_va(const u64 *A, long long lda, const u64 *B, long long ldb, u64 *C, long long ldc, int m, int l,
+                              int n, hipStream_t stream) {
+  // C must already hold the value to accumulate into (zero for a plain product)
+  if (m <= 0 || n <= 0 || l <= 0) return hipSuccess;
+  const int wn = (n + 63) >> 6;
+  const int gx = (wn + 255) / 256;
+  int splits = (2048 + gx - 1) / gx;  // aim at ~2048 blocks
+  int rps = (l + splits - 1) / splits;
+  if (rps < 64) rps = 64;
+  splits = (l + rps - 1) / rps;
+  dim3 grid(gx, splits), block(256);
+  for (int i0 = 0; i0 < m; i0 += 8) {
+    const int mm = (m - i0 < 8) ? (m - i0) : 8;
+    hipLaunchKernelGGL((gf2_va_kernel<8>), grid, block, 0, stream, A + (long long)i0 * lda, lda, B, ldb,
+                       C + (long long)i0 * ldc, ldc, mm, l, n, rps);
+  }
+  return hipGetLastError();
+}
+
+extern "C" hipError_t gf2k_xor2d(u64 *C, long long ldc, const u64 *A, long long lda, const u64 *B, long long ldb, int rows,
+                                 int words, hipStream_t stream) {
+  if (rows <= 0 || words <= 0) return hipSuccess;
+  const long long total = (long long)rows * ((words + 1) / 2);
+  hipLaunchKernelGGL(gf2_xor2d_kernel, dim3(grid_for(total)), dim3(256), 0, stream, C, ldc, A, lda, B, ldb, rows, words);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t gf2k_fill_random(u64 *M, long long ld, int rows, int cols, u64 seed, long long row0,
+                                       hipStream_t stream) {
+  if (rows <= 0 || cols <= 0) return hipSuccess;
+  const long long total = (long long)rows * ((cols + 63) / 64);
+  hipLaunchKernelGGL(gf2_fill_random_kernel, dim3(grid_for(total)), dim3(256), 0, stream, M, ld, rows, cols, seed, row0);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t gf2k_diff(const u64 *A, long long lda, const u64 *B, long long ldb, int rows, int cols, int *diff,
+                                hipStream_t stream) {
+  if (rows <= 0 || cols <= 0) return hipSuccess;
+  const long long total = (long long)rows * ((cols + 63) / 64);
+  hipLaunchKernelGGL(gf2_diff_kernel, dim3(grid_for(total)), dim3(256), 0, stream, A, lda, B, ldb, rows, cols, diff);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t gf2k_transpose(u64 *D, long long ldd, const u64 *S, long long lds_, int rows, int cols,
+                                     hipStream_t stream) {
+  if (rows <= 0 || cols <= 0) return hipSuccess;
+  const int sw = (cols + 63) / 64, rb = (rows + 63) / 64;
+  dim3 grid((sw + 3) / 4, rb), block(256);
+  hipLaunchKernelGGL(gf2_transpose_kernel, grid, block, 0, stream, D, ldd, S, lds_, rows, cols);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t gf2k_strassen_split(u64 *dst, long long ldd, long long dstStride, const u64 *src, long long lds_,
+                                          long long srcStride, int h, int w, int side, int batch, hipStream_t stream) {
+  if (h <= 0 || w <= 0 || batch <= 0) return hipSuccess;
+  const long long total = (long long)h * (w / 2);
+  int gx = grid_for(total, 256, (4096 + batch - 1) / batch);
+  hipLaunchKernelGGL(gf2_strassen_split_kernel, dim3(gx, 1, batch), dim3(256), 0, stream, dst, ldd, dstStride, src, lds_,
+                     srcStride, h, w, side);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t gf2k_strassen_merge(u64 *dst, long long ldd, long long dstStride, const u64 *src, long long lds_,
+                                          long long srcStride, int h, int w, int accumulate, int batch,
+                                          hipStream_t stream) {
+  if (h <= 0 || w <= 0 || batch <= 0) return hipSuccess;
+  const long long total = (long long)h * (w / 2);
+  int gx = grid_for(total, 256, (4096 + batch - 1) / batch);
+  hipLaunchKernelGGL(gf2_strassen_merge_kernel, dim3(gx, 1, batch), dim3(256), 0, stream, dst, ldd, dstStride, src, lds_,
+                     srcStride, h, w, accumulate);
+  return hipGetLastError();
+}

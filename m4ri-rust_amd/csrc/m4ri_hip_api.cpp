@@ -1,0 +1,781 @@
+// m4ri_hip_api.cpp -- C-ABI of libm4ri_hip.so: the multiply family of M4RI on the GPU.
+//
+// Entry points replace (paths relative to /root/reference):
+//   mzd_mul_m4rm / mzd_addmul_m4rm   m4ri-sys/src/brilliantrussian.rs:210-224
+//   mzd_mul / mzd_addmul             m4ri-sys/src/strassen.rs:8-31
+//   mzd_mul_naive / mzd_addmul_naive / _mzd_mul_naive / _mzd_mul_va   m4ri-sys/src/mzd.rs:150-181
+// Ownership and error behaviour follow the callers in m4ri-rust/src/friendly/binary_matrix.rs:
+// C == NULL -> allocate (line 465), NULL return only on failure of the product (lines 467-469),
+// dimension mismatch aborts like m4ri_die.
+//
+// There is no CPU fallback in this file: every product is a HIP kernel launch.
+#include <hip/hip_runtime_api.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/m4ri_hip.h"
+#include "api_internal.h"
+#include "gf2_kernels.h"
+
+typedef uint64_t u64;
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+
+static thread_local std::string tls_error;
+
+static int fail(hipError_t e, const char *what) {
+  tls_error = std::string(what) + ": " + hipGetErrorString(e);
+  (void)hipGetLastError();
+  return (int)e ? (int)e : -1;
+}
+static int fail_msg(const char *what) {
+  tls_error = what;
+  return -1;
+}
+#define HIP_TRY(expr)                                 \
+  do {                                                \
+    hipError_t _e = (expr);                           \
+    if (_e != hipSuccess) return fail(_e, #expr);     \
+  } while (0)
+
+extern "C" const char *gf2_last_error(void) { return tls_error.c_str(); }
+
+extern "C" int gf2_device_count(void) {
+  static int n = [] {
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) {
+      (void)hipGetLastError();
+      c = 0;
+    }
+    return c;
+  }();
+  return n;
+}
+
+static int require_device() {
+  if (gf2_device_count() <= 0)
+    return fail_msg("no usable HIP device: libm4ri_hip has no CPU fallback for the multiply path");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device memory: small caching allocator (hipMalloc is slow and synchronising)
+// ---------------------------------------------------------------------------------------------
+
+namespace {
+struct DevPool {
+  std::mutex mu;
+  std::multimap<size_t, void *> free_;
+  size_t cached = 0;
+};
+DevPool g_pools[16];
+
+size_t round_size(size_t b) {
+  const size_t g = b < ((size_t)64 << 20) ? ((size_t)1 << 20) : ((size_t)64 << 20);
+  return ((b + g - 1) / g) * g;
+}
+
+int dev_alloc(void **p, size_t bytes) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  bytes = round_size(bytes ? bytes : 1);
+  DevPool &pool = g_pools[dev & 15];
+  {
+    std::lock_guard<std::mutex> lk(pool.mu);
+    auto it = pool.free_.lower_bound(bytes);
+    if (it != pool.free_.end() && it->first <= bytes + bytes / 4) {
+      *p = it->second;
+      pool.cached -= it->first;
+      pool.free_.erase(it);
+      return 0;
+    }
+  }
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess) {
+    // drop the cache and retry once
+    std::lock_guard<std::mutex> lk(pool.mu);
+    for (auto &kv : pool.free_) (void)hipFree(kv.second);
+    pool.free_.clear();
+    pool.cached = 0;
+    (void)hipGetLastError();
+    e = hipMalloc(p, bytes);
+  }
+  if (e != hipSuccess) return fail(e, "hipMalloc");
+  return 0;
+}
+
+void dev_free(void *p, size_t bytes) {
+  if (!p) return;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return;
+  bytes = round_size(bytes ? bytes : 1);
+  DevPool &pool = g_pools[dev & 15];
+  std::lock_guard<std::mutex> lk(pool.mu);
+  static const size_t kMaxCached = (size_t)32 << 30;
+  if (pool.cached + bytes > kMaxCached) {
+    (void)hipFree(p);
+    return;
+  }
+  pool.free_.emplace(bytes, p);
+  pool.cached += bytes;
+}
+
+struct TlsStream {
+  hipStream_t s = nullptr;
+  int dev = -1;
+};
+thread_local TlsStream tls_stream;
+
+int get_stream(void *user, hipStream_t *out) {
+  if (user) {
+    *out = static_cast<hipStream_t>(user);
+    return 0;
+  }
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (!tls_stream.s || tls_stream.dev != dev) {
+    HIP_TRY(hipStreamCreateWithFlags(&tls_stream.s, hipStreamNonBlocking));
+    tls_stream.dev = dev;
+  }
+  *out = tls_stream.s;
+  return 0;
+}
+
+// scratch buffer that returns to the pool when it goes out of scope; the caller must have
+// synchronised (or ordered on the same stream) every kernel that uses it before that.
+struct Scratch {
+  void *p = nullptr;
+  size_t bytes = 0;
+  int alloc(size_t b) {
+    bytes = b;
+    return dev_alloc(&p, b);
+  }
+  ~Scratch() { dev_free(p, bytes); }
+};
+
+// deferred frees for asynchronous device-API calls: buffers used by work queued on a stream are
+// handed back to the pool only after an event recorded behind that work has completed.
+struct Deferred {
+  hipEvent_t ev;
+  void *p;
+  size_t bytes;
+};
+std::mutex g_deferred_mu;
+std::vector<Deferred> g_deferred;
+
+void reap_deferred(bool wait) {
+  std::lock_guard<std::mutex> lk(g_deferred_mu);
+  size_t k = 0;
+  for (size_t i = 0; i < g_deferred.size(); ++i) {
+    Deferred &d = g_deferred[i];
+    hipError_t q = wait ? hipEventSynchronize(d.ev) : hipEventQuery(d.ev);
+    if (q == hipSuccess) {
+      (void)hipEventDestroy(d.ev);
+      dev_free(d.p, d.bytes);
+    } else {
+      (void)hipGetLastError();
+      g_deferred[k++] = d;
+    }
+  }
+  g_deferred.resize(k);
+}
+
+int free_after(hipStream_t s, void *p, size_t bytes) {
+  hipEvent_t ev;
+  HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(ev, s));
+  std::lock_guard<std::mutex> lk(g_deferred_mu);
+  g_deferred.push_back({ev, p, bytes});
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel timing (bench.py roofline): events around the dominant multiply kernel
+// ---------------------------------------------------------------------------------------------
+
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+struct ProfPair {
+  hipEvent_t a, b;
+};
+std::vector<ProfPair> g_prof;
+
+}  // namespace
+
+extern "C" void gf2_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_on = on != 0;
+}
+
+extern "C" int gf2_prof_read(int *launches, double *ms, int reset) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  double total = 0;
+  for (auto &pp : g_prof) {
+    HIP_TRY(hipEventSynchronize(pp.b));
+    float t = 0;
+    HIP_TRY(hipEventElapsedTime(&t, pp.a, pp.b));
+    total += t;
+  }
+  if (launches) *launches = (int)g_prof.size();
+  if (ms) *ms = total;
+  if (reset) {
+    for (auto &pp : g_prof) {
+      (void)hipEventDestroy(pp.a);
+      (void)hipEventDestroy(pp.b);
+    }
+    g_prof.clear();
+  }
+  return 0;
+}
+
+static int launch_m4rm(gf2k_mul_args a, int cfg, hipStream_t s) {
+  bool on;
+  {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    on = g_prof_on;
+  }
+  ProfPair pp{};
+  if (on) {
+    HIP_TRY(hipEventCreate(&pp.a));
+    HIP_TRY(hipEventCreate(&pp.b));
+    HIP_TRY(hipEventRecord(pp.a, s));
+  }
+  HIP_TRY(gf2k_m4rm(a, cfg, s));
+  if (on) {
+    HIP_TRY(hipEventRecord(pp.b, s));
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back(pp);
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device products
+// ---------------------------------------------------------------------------------------------
+
+static inline int words_of(int bits) { return (bits + 63) >> 6; }
+
+static int env_int(const char *name, int dflt) {
+  const char *e = std::getenv(name);
+  return e ? std::atoi(e) : dflt;
+}
+
+// number of Strassen levels: `req` > 0 explicit; 0 automatic.  Automatic = keep splitting while the
+// eighth of the leaf work a level saves outweighs the two streaming passes it adds (split: 4 reads +
+// 7 writes per operand word on each side, merge: 7 reads + 4 writes).  `leaf_min` bounds the leaf
+// dimensions from below (mzd_mul's cutoff argument, strassen.rs:8-18).
+static int pick_levels(int m, int l, int n, int req, int leaf_min) {
+  static const int max_auto = env_int("M4RI_HIP_STRASSEN_MAX_LEVELS", 3);
+  static const double rate = (double)env_int("M4RI_HIP_M4RM_TBITMACS", 6000) * 1e12;  // kernel bit-MAC/s
+  static const double bw = (double)env_int("M4RI_HIP_STREAM_GBS", 4500) * 1e9;        // streaming B/s
+  const int cap = req > 0 ? (req > 6 ? 6 : req) : max_auto;
+  int L = 0;
+  double count = 1;
+  while (L < cap) {
+    const int d = 1 << (L + 1);
+    if (m % d || l % (128 * d) || n % (128 * d)) break;  // leaf rows integral, leaf widths an even word count
+    if (req <= 0) {
+      const double mi = (double)(m >> L), li = (double)(l >> L), ni = (double)(n >> L);  // operands being split
+      if ((m >> (L + 1)) < (leaf_min < 1024 ? leaf_min : 1024) || (l >> (L + 1)) < leaf_min || (n >> (L + 1)) < leaf_min)
+        break;
+      const double saved = count * mi * li * ni / rate / 8.0;
+      const double extra = count * 2.75 * (mi * li + li * ni + mi * ni) / 8.0 / bw;
+      if (saved < 1.25 * extra) break;
+    }
+    count *= 7;
+    ++L;
+  }
+  return L;
+}
+
+static size_t strassen_ws_words(int m, int l, int n, int L) {
+  size_t total = 0, p7 = 1;
+  for (int i = 1; i <= L; ++i) {
+    p7 *= 7;
+    const size_t mi = (size_t)m >> i, li = (size_t)l >> i, ni = (size_t)n >> i;
+    total += p7 * (mi * (li / 64) + li * (ni / 64) + mi * (ni / 64));
+  }
+  return total;
+}
+
+static int m4rm_cfg_for(int m, int n, int batch) {
+  // big tile (1024 x 2048, 8 waves) unless it would leave most CUs idle
+  const long long big = (long long)((m + 1023) / 1024) * ((n + 2047) / 2048) * batch;
+  return (big < 128 && m > 256) ? 1 : (m <= 256 ? 1 : 0);
+}
+
+static int mul_m4rm_plain(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int accumulate, hipStream_t s) {
+  const int m = A->nrows, l = A->ncols, n = B->ncols;
+  if (m == 0 || n == 0) return 0;
+  if (l == 0) {
+    if (!accumulate) HIP_TRY(gf2k_xor2d(C->data, C->ld, nullptr, 0, nullptr, 0, m, words_of(n), s));
+    return 0;
+  }
+  if (m <= 8) {  // a handful of rows: stream B once (v*A path, binary_matrix.rs:552-563)
+    if (!accumulate) HIP_TRY(gf2k_xor2d(C->data, C->ld, nullptr, 0, nullptr, 0, m, words_of(n), s));
+    HIP_TRY(gf2k_va(A->data, A->ld, B->data, B->ld, C->data, C->ld, m, l, n, s));
+    return 0;
+  }
+  gf2k_mul_args a{};
+  a.A = A->data;
+  a.B = B->data;
+  a.C = C->data;
+  a.lda = A->ld;
+  a.ldb = B->ld;
+  a.ldc = C->ld;
+  a.m = m;
+  a.l = l;
+  a.n = n;
+  a.batch = 1;
+  a.accumulate = accumulate;
+  return launch_m4rm(a, m4rm_cfg_for(m, n, 1), s);
+}
+
+static int mul_strassen(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int accumulate, int L, hipStream_t s,
+                        bool sync_free) {
+  const int m = A->nrows, l = A->ncols, n = B->ncols;
+  if (L <= 0) return mul_m4rm_plain(C, A, B, accumulate, s);
+  const size_t ws_bytes = strassen_ws_words(m, l, n, L) * sizeof(u64);
+  void *ws = nullptr;
+  if (int rc = dev_alloc(&ws, ws_bytes)) return rc;
+  u64 *cur = static_cast<u64 *>(ws);
+  std::vector<u64 *> Aop(L + 1), Bop(L + 1), Pop(L + 1);
+  size_t p7 = 1;
+  for (int i = 1; i <= L; ++i) {
+    p7 *= 7;
+    const size_t mi = (size_t)m >> i, li = (size_t)l >> i, ni = (size_t)n >> i;
+    Aop[i] = cur;
+    cur += p7 * mi * (li / 64);
+    Bop[i] = cur;
+    cur += p7 * li * (ni / 64);
+    Pop[i] = cur;
+    cur += p7 * mi * (ni / 64);
+  }
+  int rc = 0;
+  auto run = [&]() -> int {
+    // operand trees: level i holds 7^i operands of (m/2^i x l/2^i) and (l/2^i x n/2^i)
+    int batch = 1;
+    for (int i = 1; i <= L; ++i) {
+      const int mi = m >> i, li = l >> i, ni = n >> i;
+      const u64 *srcA = (i == 1) ? A->data : Aop[i - 1];
+      const long long ldsA = (i == 1) ? A->ld : (long long)((l >> (i - 1)) / 64);
+      const long long strA = (i == 1) ? 0 : (long long)(m >> (i - 1)) * ldsA;
+      HIP_TRY(gf2k_strassen_split(Aop[i], li / 64, (long long)mi * (li / 64), srcA, ldsA, strA, mi, li / 64, 0, batch, s));
+      const u64 *srcB = (i == 1) ? B->data : Bop[i - 1];
+      const long long ldsB = (i == 1) ? B->ld : (long long)((n >> (i - 1)) / 64);
+      const long long strB = (i == 1) ? 0 : (long long)(l >> (i - 1)) * ldsB;
+      HIP_TRY(gf2k_strassen_split(Bop[i], ni / 64, (long long)li * (ni / 64), srcB, ldsB, strB, li, ni / 64, 1, batch, s));
+      batch *= 7;
+    }
+    // 7^L leaf products in one batched launch
+    {
+      const int mi = m >> L, li = l >> L, ni = n >> L;
+      gf2k_mul_args a{};
+      a.A = Aop[L];
+      a.B = Bop[L];
+      a.C = Pop[L];
+      a.lda = li / 64;
+      a.ldb = ni / 64;
+      a.ldc = ni / 64;
+      a.sA = (long long)mi * a.lda;
+      a.sB = (long long)li * a.ldb;
+      a.sC = (long long)mi * a.ldc;
+      a.m = mi;
+      a.l = li;
+      a.n = ni;
+      a.batch = batch;
+      a.accumulate = 0;
+      if (int r = launch_m4rm(a, m4rm_cfg_for(mi, ni, batch), s)) return r;
+    }
+    // fold the products back up
+    for (int i = L; i >= 1; --i) {
+      batch /= 7;
+      const int mi = m >> i, ni = n >> i;
+      u64 *dst = (i == 1) ? C->data : Pop[i - 1];
+      const long long ldd = (i == 1) ? C->ld : (long long)((n >> (i - 1)) / 64);
+      const long long strD = (i == 1) ? 0 : (long long)(m >> (i - 1)) * ldd;
+      HIP_TRY(gf2k_strassen_merge(dst, ldd, strD, Pop[i], ni / 64, (long long)mi * (ni / 64), mi, ni / 64,
+                                  (i == 1) ? accumulate : 0, batch, s));
+    }
+    return 0;
+  };
+  rc = run();
+  if (sync_free) {
+    if (rc == 0 && hipStreamSynchronize(s) != hipSuccess) rc = fail(hipGetLastError(), "hipStreamSynchronize");
+    dev_free(ws, ws_bytes);
+  } else {
+    reap_deferred(false);
+    if (free_after(s, ws, ws_bytes) != 0) {
+      (void)hipStreamSynchronize(s);
+      dev_free(ws, ws_bytes);
+    }
+  }
+  return rc;
+}
+
+static int mul_naive_dev(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int accumulate, hipStream_t s,
+                         bool sync_free) {
+  // mzd_mul_naive (mzd.rs:150-152) = transpose B, then the row-parity product (mzd.rs:154-168).
+  // For wide B the table kernel computes the same bits far faster, so only narrow products
+  // (C one word wide: the matrix x vector path of mul_slice, binary_matrix.rs:416-431) take this route.
+  const int m = A->nrows, l = A->ncols, n = B->ncols;
+  if (n > 64 || l == 0) return mul_m4rm_plain(C, A, B, accumulate, s);
+  if (m == 0 || n == 0) return 0;
+  const long long ldbt = (words_of(l) + 1) & ~1ll;
+  const size_t bytes = (size_t)n * ldbt * sizeof(u64);
+  void *bt = nullptr;
+  if (int rc = dev_alloc(&bt, bytes)) return rc;
+  int rc = 0;
+  do {
+    hipError_t e = gf2k_transpose(static_cast<u64 *>(bt), ldbt, B->data, B->ld, l, n, s);
+    if (e != hipSuccess) {
+      rc = fail(e, "gf2k_transpose");
+      break;
+    }
+    e = gf2k_rowparity(A->data, A->ld, static_cast<u64 *>(bt), ldbt, C->data, C->ld, m, l, n, accumulate, s);
+    if (e != hipSuccess) rc = fail(e, "gf2k_rowparity");
+  } while (0);
+  if (sync_free) {
+    if (rc == 0 && hipStreamSynchronize(s) != hipSuccess) rc = fail(hipGetLastError(), "hipStreamSynchronize");
+    dev_free(bt, bytes);
+  } else {
+    reap_deferred(false);
+    if (free_after(s, bt, bytes) != 0) {
+      (void)hipStreamSynchronize(s);
+      dev_free(bt, bytes);
+    }
+  }
+  return rc;
+}
+
+static int check_mul_dims(const gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B) {
+  if (!C || !A || !B || !C->data || !A->data || !B->data) return fail_msg("gf2_mul_dev: null operand");
+  if (A->ncols != B->nrows || C->nrows != A->nrows || C->ncols != B->ncols)
+    return fail_msg("gf2_mul_dev: dimension mismatch");
+  if (A->ld < words_of(A->ncols) || B->ld < words_of(B->ncols) || C->ld < words_of(C->ncols))
+    return fail_msg("gf2_mul_dev: row stride smaller than row width");
+  return 0;
+}
+
+static int mul_dispatch(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int accumulate, int algo, int param,
+                        hipStream_t s, bool sync_free) {
+  switch (algo) {
+    case GF2_ALGO_NAIVE:
+      return mul_naive_dev(C, A, B, accumulate, s, sync_free);
+    case GF2_ALGO_M4RM: {
+      int rc = mul_m4rm_plain(C, A, B, accumulate, s);
+      if (rc == 0 && sync_free && hipStreamSynchronize(s) != hipSuccess)
+        rc = fail(hipGetLastError(), "hipStreamSynchronize");
+      return rc;
+    }
+    case GF2_ALGO_AUTO:
+    case GF2_ALGO_STRASSEN: {
+      static const int leaf_min = env_int("M4RI_HIP_STRASSEN_LEAF_MIN", 2048);
+      const int L = pick_levels(A->nrows, A->ncols, B->ncols, param, leaf_min);
+      return mul_strassen(C, A, B, accumulate, L, s, sync_free);
+    }
+    default:
+      return fail_msg("gf2_mul_dev: unknown algorithm");
+  }
+}
+
+extern "C" int gf2_mul_dev(gf2_dmat *C, gf2_dmat const *A, gf2_dmat const *B, int accumulate, int algo, int param,
+                           void *stream) {
+  if (int rc = require_device()) return rc;
+  if (int rc = check_mul_dims(C, A, B)) return rc;
+  hipStream_t s;
+  if (int rc = get_stream(stream, &s)) return rc;
+  return mul_dispatch(C, A, B, accumulate, algo, param, s, /*sync_free=*/false);
+}
+
+extern "C" int gf2_mul_nt_dev(gf2_dmat *C, gf2_dmat const *A, gf2_dmat const *Bt, int accumulate, void *stream) {
+  if (int rc = require_device()) return rc;
+  if (!C || !A || !Bt || !C->data || !A->data || !Bt->data) return fail_msg("gf2_mul_nt_dev: null operand");
+  if (A->ncols != Bt->ncols || C->nrows != A->nrows || C->ncols != Bt->nrows)
+    return fail_msg("gf2_mul_nt_dev: dimension mismatch");
+  hipStream_t s;
+  if (int rc = get_stream(stream, &s)) return rc;
+  HIP_TRY(gf2k_rowparity(A->data, A->ld, Bt->data, Bt->ld, C->data, C->ld, A->nrows, A->ncols, Bt->nrows, accumulate, s));
+  return 0;
+}
+
+extern "C" size_t gf2_mul_workspace_bytes(int m, int l, int n, int algo, int param) {
+  if (algo == GF2_ALGO_NAIVE) return n <= 64 ? (size_t)n * ((words_of(l) + 1) & ~1) * 8 : 0;
+  if (algo == GF2_ALGO_M4RM) return 0;
+  static const int leaf_min = env_int("M4RI_HIP_STRASSEN_LEAF_MIN", 2048);
+  return strassen_ws_words(m, l, n, pick_levels(m, l, n, param, leaf_min)) * sizeof(u64);
+}
+
+extern "C" int gf2_add_dev(gf2_dmat *C, gf2_dmat const *A, gf2_dmat const *B, void *stream) {
+  if (int rc = require_device()) return rc;
+  if (A->nrows != B->nrows || A->ncols != B->ncols || C->nrows != A->nrows || C->ncols != A->ncols)
+    return fail_msg("gf2_add_dev: dimension mismatch");
+  hipStream_t s;
+  if (int rc = get_stream(stream, &s)) return rc;
+  HIP_TRY(gf2k_xor2d(C->data, C->ld, A->data, A->ld, B->data, B->ld, A->nrows, words_of(A->ncols), s));
+  return 0;
+}
+
+extern "C" int gf2_transpose_dev(gf2_dmat *D, gf2_dmat const *S, void *stream) {
+  if (int rc = require_device()) return rc;
+  if (D->nrows != S->ncols || D->ncols != S->nrows) return fail_msg("gf2_transpose_dev: dimension mismatch");
+  hipStream_t s;
+  if (int rc = get_stream(stream, &s)) return rc;
+  HIP_TRY(gf2k_transpose(D->data, D->ld, S->data, S->ld, S->nrows, S->ncols, s));
+  return 0;
+}
+
+extern "C" int gf2_equal_dev(gf2_dmat const *A, gf2_dmat const *B, int *equal, void *stream) {
+  if (int rc = require_device()) return rc;
+  if (A->nrows != B->nrows || A->ncols != B->ncols) {
+    *equal = 0;
+    return 0;
+  }
+  hipStream_t s;
+  if (int rc = get_stream(stream, &s)) return rc;
+  void *flag = nullptr;
+  if (int rc = dev_alloc(&flag, sizeof(int))) return rc;
+  int host = 0, rc = 0;
+  do {
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), s);
+    if (e == hipSuccess) e = gf2k_diff(A->data, A->ld, B->data, B->ld, A->nrows, A->ncols, static_cast<int *>(flag), s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&host, flag, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) rc = fail(e, "gf2_equal_dev");
+  } while (0);
+  dev_free(flag, sizeof(int));
+  *equal = host ? 0 : 1;
+  return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device matrices <-> host mzd_t
+// ---------------------------------------------------------------------------------------------
+
+static inline long long dev_ld_for(int ncols) {
+  const long long w = words_of(ncols);
+  return w <= 1 ? (w ? w : 1) : ((w + 1) & ~1ll);
+}
+
+extern "C" int gf2_dmat_alloc(gf2_dmat *M, int nrows, int ncols) {
+  if (int rc = require_device()) return rc;
+  if (!M || nrows < 0 || ncols < 0) return fail_msg("gf2_dmat_alloc: bad arguments");
+  M->nrows = nrows;
+  M->ncols = ncols;
+  M->ld = dev_ld_for(ncols);
+  void *p = nullptr;
+  if (int rc = dev_alloc(&p, (size_t)(nrows ? nrows : 1) * M->ld * sizeof(u64))) return rc;
+  M->data = static_cast<u64 *>(p);
+  return 0;
+}
+
+extern "C" void gf2_dmat_free(gf2_dmat *M) {
+  if (!M || !M->data) return;
+  dev_free(M->data, (size_t)(M->nrows ? M->nrows : 1) * M->ld * sizeof(u64));
+  M->data = nullptr;
+}
+
+extern "C" int gf2_dmat_fill_random_rows(gf2_dmat *M, uint64_t seed, int64_t row0, void *stream) {
+  if (int rc = require_device()) return rc;
+  hipStream_t s;
+  if (int rc = get_stream(stream, &s)) return rc;
+  HIP_TRY(gf2k_fill_random(M->data, M->ld, M->nrows, M->ncols, seed, row0, s));
+  return 0;
+}
+
+extern "C" int gf2_dmat_fill_random(gf2_dmat *M, uint64_t seed, void *stream) {
+  return gf2_dmat_fill_random_rows(M, seed, 0, stream);
+}
+
+extern "C" int gf2_strassen_levels(int m, int l, int n, int algo, int param) {
+  if (algo != GF2_ALGO_AUTO && algo != GF2_ALGO_STRASSEN) return 0;
+  static const int leaf_min = env_int("M4RI_HIP_STRASSEN_LEAF_MIN", 2048);
+  return pick_levels(m, l, n, param, leaf_min);
+}
+
+// host rows -> device. Our mzd_t are single-block with a constant rowstride (mzd_host.cpp), windows included.
+extern "C" int gf2_dmat_upload(gf2_dmat *dst, mzd_t const *src, void *stream) {
+  if (int rc = require_device()) return rc;
+  if (dst->nrows != src->nrows || dst->ncols != src->ncols) return fail_msg("gf2_dmat_upload: dimension mismatch");
+  if (src->nrows == 0 || src->ncols == 0) return 0;
+  hipStream_t s;
+  if (int rc = get_stream(stream, &s)) return rc;
+  const size_t wbytes = (size_t)src->width * sizeof(word);
+  if (dst->ld == src->rowstride)
+    HIP_TRY(hipMemcpyAsync(dst->data, src->rows[0], ((size_t)(src->nrows - 1) * src->rowstride + src->width) * sizeof(word),
+                           hipMemcpyHostToDevice, s));
+  else
+    HIP_TRY(hipMemcpy2DAsync(dst->data, (size_t)dst->ld * sizeof(u64), src->rows[0], (size_t)src->rowstride * sizeof(word),
+                             wbytes, src->nrows, hipMemcpyHostToDevice, s));
+  return 0;
+}
+
+extern "C" int gf2_dmat_download(mzd_t *dst, gf2_dmat const *src, void *stream) {
+  if (int rc = require_device()) return rc;
+  if (dst->nrows != src->nrows || dst->ncols != src->ncols) return fail_msg("gf2_dmat_download: dimension mismatch");
+  if (dst->nrows == 0 || dst->ncols == 0) return 0;
+  hipStream_t s;
+  if (int rc = get_stream(stream, &s)) return rc;
+  const size_t wbytes = (size_t)dst->width * sizeof(word);
+  const bool windowed = (dst->flags & mzd_flag_windowed_zerooffset) != 0;
+  if (windowed && dst->high_bitmask != m4ri_ffff) {
+    // the last word of each row is shared with the parent matrix: merge under the mask
+    std::vector<word> tmp((size_t)dst->nrows * dst->width);
+    HIP_TRY(hipMemcpy2DAsync(tmp.data(), wbytes, src->data, (size_t)src->ld * sizeof(u64), wbytes, dst->nrows,
+                             hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (rci_t i = 0; i < dst->nrows; ++i) {
+      word *d = dst->rows[i];
+      const word *t = tmp.data() + (size_t)i * dst->width;
+      for (wi_t j = 0; j + 1 < dst->width; ++j) d[j] = t[j];
+      d[dst->width - 1] = (d[dst->width - 1] & ~dst->high_bitmask) | (t[dst->width - 1] & dst->high_bitmask);
+    }
+    return 0;
+  }
+  if (!windowed && src->ld == dst->rowstride)
+    HIP_TRY(hipMemcpyAsync(dst->rows[0], src->data, ((size_t)(dst->nrows - 1) * dst->rowstride + dst->width) * sizeof(word),
+                           hipMemcpyDeviceToHost, s));
+  else
+    HIP_TRY(hipMemcpy2DAsync(dst->rows[0], (size_t)dst->rowstride * sizeof(word), src->data,
+                             (size_t)src->ld * sizeof(u64), wbytes, dst->nrows, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// M4RI entry points on host mzd_t: upload, multiply on the device, download
+// ---------------------------------------------------------------------------------------------
+
+namespace {
+struct DMatOwner {
+  gf2_dmat d{};
+  ~DMatOwner() { gf2_dmat_free(&d); }
+};
+
+// device copy whose row stride equals the host row stride when the host block is contiguous, so that
+// the transfer is one linear DMA
+int to_device(DMatOwner &o, const mzd_t *M, hipStream_t s, bool copy) {
+  o.d.nrows = M->nrows;
+  o.d.ncols = M->ncols;
+  const bool windowed = (M->flags & mzd_flag_windowed_zerooffset) != 0;
+  o.d.ld = (!windowed && M->rowstride >= 1) ? M->rowstride : dev_ld_for(M->ncols);
+  void *p = nullptr;
+  if (int rc = dev_alloc(&p, (size_t)(M->nrows ? M->nrows : 1) * o.d.ld * sizeof(u64))) return rc;
+  o.d.data = static_cast<u64 *>(p);
+  if (copy) return gf2_dmat_upload(&o.d, M, s);
+  return 0;
+}
+
+mzd_t *host_mul(mzd_t *C, const mzd_t *A, const mzd_t *B, int accumulate, int algo, int param, const char *name) {
+  if (A->ncols != B->nrows) gf2_die((std::string(name) + ": A ncols need to match B nrows.").c_str());
+  if (accumulate && !C) gf2_die((std::string(name) + ": C must not be NULL.").c_str());
+  const bool allocated = (C == nullptr);
+  if (C && (C->nrows != A->nrows || C->ncols != B->ncols))
+    gf2_die((std::string(name) + ": C (ret) has wrong dimensions.").c_str());
+  auto bail = [&](const char *why) -> mzd_t * {
+    std::fprintf(stderr, "m4ri_hip: %s failed: %s (%s)\n", name, why, gf2_last_error());
+    return nullptr;
+  };
+  if (require_device()) return bail("no device");
+  if (!C) C = mzd_init(A->nrows, B->ncols);
+  if (A->nrows == 0 || B->ncols == 0) return C;
+  hipStream_t s;
+  if (get_stream(nullptr, &s)) {
+    if (allocated) mzd_free(C);
+    return bail("stream");
+  }
+  int rc = 0;
+  {
+    DMatOwner dA, dB, dC;
+    rc = to_device(dA, A, s, true);
+    if (!rc) rc = to_device(dB, B, s, true);
+    if (!rc) rc = to_device(dC, C, s, accumulate != 0);
+    if (!rc) rc = mul_dispatch(&dC.d, &dA.d, &dB.d, accumulate, algo, param, s, /*sync_free=*/true);
+    if (!rc) rc = gf2_dmat_download(C, &dC.d, s);
+    if (rc) (void)hipStreamSynchronize(s);
+  }
+  if (rc) {
+    if (allocated) mzd_free(C);
+    return bail("device product");
+  }
+  return C;
+}
+}  // namespace
+
+// Strassen levels from M4RI's cutoff argument: recursion continues while the halved dimension stays
+// >= cutoff (strassen.rs:8-18: "Minimal dimension for Strassen recursion"); 0 = library default.
+static int levels_from_cutoff(const mzd_t *A, const mzd_t *B, int cutoff) {
+  if (cutoff <= 0) return 0;  // automatic
+  const int mn = A->nrows < A->ncols ? (A->nrows < B->ncols ? A->nrows : B->ncols)
+                                     : (A->ncols < B->ncols ? A->ncols : B->ncols);
+  int L = 0;
+  while (L < 6 && (mn >> (L + 1)) >= cutoff) ++L;
+  return L ? L : -1;  // -1: explicit "no recursion"
+}
+
+extern "C" mzd_t *mzd_mul_m4rm(mzd_t *C, mzd_t const *A, mzd_t const *B, int k) {
+  (void)k;  // table size hint; the kernel's tables are fixed at 8 bits (LDS bank-row geometry)
+  return host_mul(C, A, B, 0, GF2_ALGO_M4RM, 0, "mzd_mul_m4rm");
+}
+extern "C" mzd_t *mzd_addmul_m4rm(mzd_t *C, mzd_t const *A, mzd_t const *B, int k) {
+  (void)k;
+  return host_mul(C, A, B, 1, GF2_ALGO_M4RM, 0, "mzd_addmul_m4rm");
+}
+extern "C" mzd_t *mzd_mul(mzd_t *C, mzd_t const *A, mzd_t const *B, int cutoff) {
+  const int L = levels_from_cutoff(A, B, cutoff);
+  if (L < 0) return host_mul(C, A, B, 0, GF2_ALGO_M4RM, 0, "mzd_mul");
+  return host_mul(C, A, B, 0, GF2_ALGO_STRASSEN, L, "mzd_mul");
+}
+extern "C" mzd_t *mzd_addmul(mzd_t *C, mzd_t const *A, mzd_t const *B, int cutoff) {
+  const int L = levels_from_cutoff(A, B, cutoff);
+  if (L < 0) return host_mul(C, A, B, 1, GF2_ALGO_M4RM, 0, "mzd_addmul");
+  return host_mul(C, A, B, 1, GF2_ALGO_STRASSEN, L, "mzd_addmul");
+}
+extern "C" mzd_t *mzd_mul_naive(mzd_t *C, mzd_t const *A, mzd_t const *B) {
+  return host_mul(C, A, B, 0, GF2_ALGO_NAIVE, 0, "mzd_mul_naive");
+}
+extern "C" mzd_t *mzd_addmul_naive(mzd_t *C, mzd_t const *A, mzd_t const *B) {
+  return host_mul(C, A, B, 1, GF2_ALGO_NAIVE, 0, "mzd_addmul_naive");
+}
+
+extern "C" mzd_t *_mzd_mul_naive(mzd_t *C, mzd_t const *A, mzd_t const *Bt, int clear) {
+  // C (+)= A * Bt^T, Bt pre-transposed (mzd.rs:154-168); C is "preallocated" upstream
+  if (!C) gf2_die("_mzd_mul_naive: C must be preallocated.");
+  if (A->ncols != Bt->ncols || C->nrows != A->nrows || C->ncols != Bt->nrows)
+    gf2_die("_mzd_mul_naive: dimension mismatch.");
+  if (require_device()) {
+    std::fprintf(stderr, "m4ri_hip: _mzd_mul_naive failed: %s\n", gf2_last_error());
+    return nullptr;
+  }
+  if (A->nrows == 0 || Bt->nrows == 0) return C;
+  hipStream_t s;
+  if (get_stream(nullptr, &s)) return nullptr;
+  int rc;
+  {
+    DMatOwner dA, dB, dC;
+    rc = to_device(dA, A, s, true);
+    if (!rc) rc = to_device(dB, Bt, s, true);
+    if (!rc) rc = to_device(dC, C, s, clear == 0);
+    if (!rc) rc = gf2_mul_nt_dev(&dC.d, &dA.d, &dB.d, clear == 0, s);
+    if (!rc) rc = gf2_dmat_download(C, &dC.d, s);
+    if (rc) (void)hipStreamSynchronize(s);
+  }
+  if (rc) {
+    std::fprintf(stderr, "m4ri_hip: _mzd_mul_naive failed: %s\n", gf2_last_error());
+    return nullptr;
+  }
+  return C;
+}
+
+extern "C" mzd_t *_mzd_mul_va(mzd_t *C, mzd_t const *v, mzd_t const *A, int clear) {
+  if (!C) gf2_die("_mzd_mul_va: C must be preallocated.");
+  return host_mul(C, v, A, clear == 0, GF2_ALGO_M4RM, 0, "_mzd_mul_va");
+}

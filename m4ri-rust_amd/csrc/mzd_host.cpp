@@ -1,0 +1,342 @@
+// mzd_host.cpp -- host-side mzd_t container of libm4ri_hip.so.
+//
+// Keeps M4RI's 64-byte mzd_t byte for byte (m4ri-sys/src/mzd.rs:24-79): the Rust wrapper
+// dereferences rows / nrows / ncols directly (m4ri-rust/src/friendly/binary_matrix.rs:138,176,286)
+// and recomputes row addresses from blocks / offset_vector / rowstride (mzd.rs:277-313).
+// Matrices are always single-block; blocks of >= pin threshold are allocated as pinned host
+// memory so that the multiply entry points can DMA them at PCIe rate.
+#include <hip/hip_runtime_api.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/m4ri_hip.h"
+#include "api_internal.h"
+
+static_assert(sizeof(mzd_t) == 64, "mzd_t must stay 64 bytes (mzd.rs:385)");
+static_assert(offsetof(mzd_t, flags) == 24 && offsetof(mzd_t, high_bitmask) == 40 && offsetof(mzd_t, blocks) == 48 &&
+                  offsetof(mzd_t, rows) == 56,
+              "mzd_t field offsets are part of the ABI");
+
+static const wi_t mzd_paddingwidth = 3;
+enum { kAllocMalloc = 0, kAllocPinned = 1 };
+
+[[noreturn]] void gf2_die(const char *msg) {
+  // M4RI's m4ri_die: print and abort (dimension mismatches are programming errors upstream too)
+  std::fprintf(stderr, "m4ri_hip: %s\n", msg);
+  std::abort();
+}
+
+static size_t pin_threshold() {
+  static size_t t = [] {
+    const char *e = std::getenv("M4RI_HIP_PIN_MIN_BYTES");
+    return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)1 << 20;
+  }();
+  return t;
+}
+
+static void *block_alloc(size_t bytes, uint8_t *kind) {
+  *kind = kAllocMalloc;
+  if (bytes >= pin_threshold() && gf2_device_count() > 0) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess && p) {
+      std::memset(p, 0, bytes);
+      *kind = kAllocPinned;
+      return p;
+    }
+    (void)hipGetLastError();
+  }
+  void *p = nullptr;
+  if (posix_memalign(&p, 64, bytes ? bytes : 64) != 0) gf2_die("out of memory");
+  std::memset(p, 0, bytes);
+  return p;
+}
+
+static void block_free(void *p, uint8_t kind) {
+  if (!p) return;
+  if (kind == kAllocPinned)
+    (void)hipHostFree(p);
+  else
+    std::free(p);
+}
+
+extern "C" mzd_t *mzd_init(rci_t r, rci_t c) {
+  if (r < 0 || c < 0) gf2_die("mzd_init: negative dimension");
+  mzd_t *A = nullptr;
+  if (posix_memalign(reinterpret_cast<void **>(&A), 64, sizeof(mzd_t)) != 0) gf2_die("out of memory");
+  std::memset(A, 0, sizeof(mzd_t));
+  A->nrows = r;
+  A->ncols = c;
+  A->width = (c + m4ri_radix - 1) / m4ri_radix;
+  A->rowstride = (A->width < mzd_paddingwidth || (A->width & 1) == 0) ? A->width : A->width + 1;
+  A->high_bitmask = (c % m4ri_radix) ? ((m4ri_one << (c % m4ri_radix)) - 1) : m4ri_ffff;
+  A->flags = (A->high_bitmask != m4ri_ffff) ? mzd_flag_nonzero_excess : 0;
+  A->offset_vector = 0;
+  A->row_offset = 0;
+  uint8_t lg = 0;
+  while (((long long)1 << lg) < (long long)(r > 1 ? r : 1)) ++lg;
+  A->blockrows_log = lg;  // single block: (row_offset + row) >> blockrows_log == 0 for every row
+  if (r && c) {
+    const size_t bytes = (size_t)r * (size_t)A->rowstride * sizeof(word);
+    mzd_block_t *blocks = static_cast<mzd_block_t *>(std::calloc(2, sizeof(mzd_block_t)));  // [1] = terminator
+    if (!blocks) gf2_die("out of memory");
+    uint8_t kind;
+    blocks[0].begin = static_cast<word *>(block_alloc(bytes, &kind));
+    blocks[0].size = bytes;
+    blocks[0].end = blocks[0].begin + (size_t)r * A->rowstride;
+    A->padding[0] = kind;
+    A->blocks = blocks;
+    A->rows = static_cast<word **>(std::malloc(((size_t)r + 1) * sizeof(word *)));
+    if (!A->rows) gf2_die("out of memory");
+    for (rci_t i = 0; i < r; ++i) A->rows[i] = blocks[0].begin + (size_t)i * A->rowstride;
+    A->rows[r] = nullptr;
+  }
+  return A;
+}
+
+static bool is_windowed(const mzd_t *A) { return (A->flags & mzd_flag_windowed_zerooffset) != 0; }
+static bool owns_blocks(const mzd_t *A) {
+  return A->blocks && (!is_windowed(A) || (A->flags & mzd_flag_windowed_ownsblocks));
+}
+
+extern "C" void mzd_free(mzd_t *A) {
+  if (!A) return;
+  std::free(A->rows);
+  if (owns_blocks(A)) {
+    block_free(A->blocks[0].begin, A->padding[0]);
+    std::free(A->blocks);
+  }
+  std::free(A);
+}
+
+extern "C" mzd_t *mzd_init_window(mzd_t *M, rci_t lowr, rci_t lowc, rci_t highr, rci_t highc) {
+  if (lowc % m4ri_radix) gf2_die("mzd_init_window: lowc must be a multiple of 64");
+  if (lowr < 0 || lowc < 0 || highr > M->nrows || highc > M->ncols || highr < lowr || highc < lowc)
+    gf2_die("mzd_init_window: window out of range");
+  mzd_t *W = nullptr;
+  if (posix_memalign(reinterpret_cast<void **>(&W), 64, sizeof(mzd_t)) != 0) gf2_die("out of memory");
+  std::memset(W, 0, sizeof(mzd_t));
+  W->nrows = highr - lowr;
+  W->ncols = highc - lowc;
+  W->width = (W->ncols + m4ri_radix - 1) / m4ri_radix;
+  W->rowstride = M->rowstride;
+  W->high_bitmask = (W->ncols % m4ri_radix) ? ((m4ri_one << (W->ncols % m4ri_radix)) - 1) : m4ri_ffff;
+  W->flags = mzd_flag_windowed_zerooffset;
+  W->flags |= (W->ncols % m4ri_radix == 0) ? mzd_flag_windowed_zeroexcess : mzd_flag_nonzero_excess;
+  W->blockrows_log = M->blockrows_log;
+  W->row_offset = M->row_offset + lowr;
+  W->offset_vector = M->offset_vector + lowr * M->rowstride + lowc / m4ri_radix;
+  W->blocks = M->blocks;
+  W->padding[0] = M->padding[0];
+  if (W->nrows) {
+    W->rows = static_cast<word **>(std::malloc(((size_t)W->nrows + 1) * sizeof(word *)));
+    if (!W->rows) gf2_die("out of memory");
+    for (rci_t i = 0; i < W->nrows; ++i) W->rows[i] = M->rows[lowr + i] + lowc / m4ri_radix;
+    W->rows[W->nrows] = nullptr;
+  }
+  return W;
+}
+
+static inline void copy_row_masked(word *d, const word *s, wi_t width, word mask) {
+  if (width <= 0) return;
+  if (width > 1) std::memcpy(d, s, (size_t)(width - 1) * sizeof(word));
+  d[width - 1] = (d[width - 1] & ~mask) | (s[width - 1] & mask);
+}
+
+extern "C" mzd_t *mzd_copy(mzd_t *N, mzd_t const *P) {
+  if (N == P) return N;
+  if (!N)
+    N = mzd_init(P->nrows, P->ncols);
+  else if (N->nrows < P->nrows || N->ncols < P->ncols)
+    gf2_die("mzd_copy: Target matrix is too small.");
+  for (rci_t i = 0; i < P->nrows; ++i) copy_row_masked(N->rows[i], P->rows[i], P->width, P->high_bitmask);
+  return N;
+}
+
+extern "C" int mzd_equal(mzd_t const *A, mzd_t const *B) {
+  if (A->nrows != B->nrows || A->ncols != B->ncols) return 0;
+  if (A == B) return 1;
+  const wi_t w = A->width;
+  for (rci_t i = 0; i < A->nrows; ++i) {
+    const word *a = A->rows[i], *b = B->rows[i];
+    for (wi_t j = 0; j + 1 < w; ++j)
+      if (a[j] != b[j]) return 0;
+    if (w && ((a[w - 1] ^ b[w - 1]) & A->high_bitmask)) return 0;
+  }
+  return 1;
+}
+
+extern "C" int mzd_is_zero(mzd_t const *A) {
+  for (rci_t i = 0; i < A->nrows; ++i) {
+    const word *a = A->rows[i];
+    for (wi_t j = 0; j + 1 < A->width; ++j)
+      if (a[j]) return 0;
+    if (A->width && (a[A->width - 1] & A->high_bitmask)) return 0;
+  }
+  return 1;
+}
+
+extern "C" void mzd_randomize(mzd_t *A) {
+  // M4RI draws from libc random(); here a process-wide counter-based splitmix64 stream (thread safe,
+  // successive calls give fresh bits as the reference's tests expect: mzd.rs:389-394).
+  static std::atomic<uint64_t> ctr{0x243F6A8885A308D3ull};
+  const uint64_t nwords = (uint64_t)A->nrows * (uint64_t)A->width;
+  uint64_t t = ctr.fetch_add(nwords + 1);
+  for (rci_t i = 0; i < A->nrows; ++i) {
+    word *a = A->rows[i];
+    for (wi_t j = 0; j < A->width; ++j) {
+      uint64_t z = (t += 0x9E3779B97F4A7C15ull);
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+      z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+      z ^= z >> 31;
+      if (j == A->width - 1)
+        a[j] = (a[j] & ~A->high_bitmask) | (z & A->high_bitmask);
+      else
+        a[j] = z;
+    }
+  }
+}
+
+extern "C" void mzd_set_ui(mzd_t *A, unsigned int value) {
+  for (rci_t i = 0; i < A->nrows; ++i) {
+    word *a = A->rows[i];
+    for (wi_t j = 0; j + 1 < A->width; ++j) a[j] = 0;
+    if (A->width) a[A->width - 1] &= ~A->high_bitmask;
+  }
+  if (value % 2 == 0) return;
+  const rci_t k = A->nrows < A->ncols ? A->nrows : A->ncols;
+  for (rci_t i = 0; i < k; ++i) A->rows[i][i / m4ri_radix] |= m4ri_one << (i % m4ri_radix);
+}
+
+// 64x64 bit-block transpose (recursive block swap), in place on 64 words
+static inline void transpose64(word x[64]) {
+  word mask = 0x00000000FFFFFFFFull;
+  for (int d = 32; d >= 1; d >>= 1, mask ^= mask << d) {
+    for (int k = 0; k < 64; k = (k + d + 1) & ~d) {
+      const word t = ((x[k] >> d) ^ x[k + d]) & mask;
+      x[k] ^= t << d;
+      x[k + d] ^= t;
+    }
+  }
+}
+
+extern "C" mzd_t *mzd_transpose(mzd_t *DST, mzd_t const *A) {
+  if (!DST)
+    DST = mzd_init(A->ncols, A->nrows);
+  else if (DST->nrows != A->ncols || DST->ncols != A->nrows)
+    gf2_die("mzd_transpose: Wrong size for return matrix.");
+  if (A->nrows == 0 || A->ncols == 0) return DST;
+  word blk[64];
+  for (rci_t bi = 0; bi < A->nrows; bi += 64) {
+    const int nr = (A->nrows - bi < 64) ? (A->nrows - bi) : 64;
+    for (wi_t bj = 0; bj < A->width; ++bj) {
+      for (int r = 0; r < 64; ++r) {
+        word v = (r < nr) ? A->rows[bi + r][bj] : 0;
+        if (bj == A->width - 1) v &= A->high_bitmask;
+        blk[r] = v;
+      }
+      transpose64(blk);
+      const int nc = (A->ncols - 64 * bj < 64) ? (A->ncols - 64 * bj) : 64;
+      const wi_t dw = bi / 64;
+      for (int c = 0; c < nc; ++c) {
+        word *d = DST->rows[64 * bj + c] + dw;
+        if (dw == DST->width - 1)
+          *d = (*d & ~DST->high_bitmask) | (blk[c] & DST->high_bitmask);
+        else
+          *d = blk[c];
+      }
+    }
+  }
+  return DST;
+}
+
+extern "C" mzd_t *mzd_add(mzd_t *C, mzd_t const *A, mzd_t const *B) {
+  if (A->nrows != B->nrows || A->ncols != B->ncols) gf2_die("mzd_add: rows and columns must match.");
+  if (!C)
+    C = mzd_init(A->nrows, A->ncols);
+  else if (C != A && (C->nrows != A->nrows || C->ncols != A->ncols))
+    gf2_die("mzd_add: rows and columns of returned matrix must match.");
+  const wi_t w = A->width;
+  for (rci_t i = 0; i < A->nrows; ++i) {
+    word *c = C->rows[i];
+    const word *a = A->rows[i], *b = B->rows[i];
+    for (wi_t j = 0; j + 1 < w; ++j) c[j] = a[j] ^ b[j];
+    if (w) c[w - 1] = (c[w - 1] & ~C->high_bitmask) | ((a[w - 1] ^ b[w - 1]) & C->high_bitmask);
+  }
+  return C;
+}
+
+extern "C" mzd_t *mzd_sub(mzd_t *C, mzd_t const *A, mzd_t const *B) { return mzd_add(C, A, B); }
+
+static inline BIT read_bit(const mzd_t *M, rci_t r, rci_t c) {
+  return (BIT)((M->rows[r][c / m4ri_radix] >> (c % m4ri_radix)) & 1);
+}
+static inline void write_bit(mzd_t *M, rci_t r, rci_t c, BIT v) {
+  word *w = &M->rows[r][c / m4ri_radix];
+  *w = (*w & ~(m4ri_one << (c % m4ri_radix))) | ((word)(v & 1) << (c % m4ri_radix));
+}
+
+extern "C" mzd_t *mzd_concat(mzd_t *C, mzd_t const *A, mzd_t const *B) {
+  if (A->nrows != B->nrows) gf2_die("mzd_concat: Bad arguments to concat!");
+  if (!C)
+    C = mzd_init(A->nrows, A->ncols + B->ncols);
+  else if (C->nrows != A->nrows || C->ncols != A->ncols + B->ncols)
+    gf2_die("mzd_concat: C has wrong dimension!");
+  for (rci_t i = 0; i < A->nrows; ++i) {
+    copy_row_masked(C->rows[i], A->rows[i], A->width, A->high_bitmask);
+    for (rci_t j = 0; j < B->ncols; ++j) write_bit(C, i, A->ncols + j, read_bit(B, i, j));
+  }
+  return C;
+}
+
+extern "C" mzd_t *mzd_stack(mzd_t *C, mzd_t const *A, mzd_t const *B) {
+  if (A->ncols != B->ncols) gf2_die("mzd_stack: A->ncols != B->ncols!");
+  if (!C)
+    C = mzd_init(A->nrows + B->nrows, A->ncols);
+  else if (C->nrows != A->nrows + B->nrows || C->ncols != A->ncols)
+    gf2_die("mzd_stack: C has wrong dimension!");
+  for (rci_t i = 0; i < A->nrows; ++i) copy_row_masked(C->rows[i], A->rows[i], A->width, A->high_bitmask);
+  for (rci_t i = 0; i < B->nrows; ++i) copy_row_masked(C->rows[A->nrows + i], B->rows[i], B->width, B->high_bitmask);
+  return C;
+}
+
+extern "C" mzd_t *mzd_submatrix(mzd_t *S, mzd_t const *M, rci_t lowr, rci_t lowc, rci_t highr, rci_t highc) {
+  const rci_t nrows = highr - lowr, ncols = highc - lowc;
+  if (!S)
+    S = mzd_init(nrows, ncols);
+  else if (S->nrows < nrows || S->ncols < ncols)
+    gf2_die("mzd_submatrix: got S with wrong dimensions");
+  for (rci_t i = 0; i < nrows; ++i)
+    for (rci_t j = 0; j < ncols; ++j) write_bit(S, i, j, read_bit(M, lowr + i, lowc + j));
+  return S;
+}
+
+extern "C" void mzd_row_swap(mzd_t *M, rci_t a, rci_t b) {
+  if (a == b) return;
+  word *x = M->rows[a], *y = M->rows[b];
+  for (wi_t j = 0; j < M->width; ++j) {
+    const word mask = (j == M->width - 1) ? M->high_bitmask : m4ri_ffff;
+    const word t = (x[j] ^ y[j]) & mask;
+    x[j] ^= t;
+    y[j] ^= t;
+  }
+}
+
+extern "C" void mzd_copy_row(mzd_t *B, rci_t i, mzd_t const *A, rci_t j) {
+  if (A->ncols > B->ncols) gf2_die("mzd_copy_row: source wider than target");
+  copy_row_masked(B->rows[i], A->rows[j], A->width, A->high_bitmask);
+}
+
+extern "C" int m4ri_opt_k(int a, int b, int c) {
+  // graycode.rs:44-56: 0.75*log2(n), n = b for multiplication (c != 0), min(a,b) otherwise.
+  // Only a hint here: the device kernel always uses 8-bit tables.
+  int n = (c != 0) ? b : (a < b ? a : b);
+  int lg = 0;
+  while ((1 << (lg + 1)) <= n && lg < 30) ++lg;
+  int k = (int)(0.75 * (double)(1 + lg));
+  if (k < 1) k = 1;
+  if (k > 16) k = 16;
+  return k;
+}

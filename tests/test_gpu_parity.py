@@ -1,0 +1,251 @@
+"""GPU parity tests: the HIP path, called through the C ABI (mzd_* entry points and the
+device-resident gf2_* API), against the CPU oracle, the committed golden vectors and
+size-independent algebraic properties.  Bit-exact everywhere (integer work)."""
+import glob
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import gf2util as g
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def pkg(built):
+    import m4ri_rust_amd as p
+    from m4ri_rust_amd import device
+    device.require_gpu()
+    return p
+
+
+@pytest.fixture(scope="module")
+def dev(pkg):
+    from m4ri_rust_amd import device
+    return device
+
+
+def _host_mul(pkg, a, b, m, l, n, strategy):
+    pkg.set_mul_strategy(strategy)
+    try:
+        A = pkg.BinMatrix.from_words(a, l)
+        B = pkg.BinMatrix.from_words(b, n)
+        C = A * B
+        assert C.nrows() == m and C.ncols() == n
+        return C.to_words()
+    finally:
+        pkg.set_mul_strategy("strassen")
+
+
+# ---- the reference's own known answers (binary_matrix.rs:662-686) ------------------------------
+
+def test_ref_mul_identity(pkg):
+    m1, m2, m3 = (pkg.BinMatrix.identity(8) for _ in range(3))
+    assert (m1 * m2) == m3
+
+
+def test_ref_vecmul(pkg):
+    m1 = pkg.BinMatrix.identity(10)
+    binvec = pkg.BinVector.from_elem(10, True)
+    assert (m1 * binvec) == binvec
+    assert (binvec * m1) == binvec
+    m1 = pkg.BinMatrix.random(10, 3)
+    assert len(binvec * m1) == 3
+
+
+@pytest.mark.parametrize("strategy", ["strassen", "m4rm", "naive"])
+def test_identity_products_all_strategies(pkg, strategy):
+    pkg.set_mul_strategy(strategy)
+    try:
+        for n in (1, 8, 63, 64, 65, 200, 1000):
+            a = pkg.BinMatrix.random(n, n)
+            i = pkg.BinMatrix.identity(n)
+            assert (a * i) == a and (i * a) == a
+    finally:
+        pkg.set_mul_strategy("strassen")
+
+
+# ---- golden vectors -------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))), ids=os.path.basename)
+@pytest.mark.parametrize("strategy", ["strassen", "m4rm", "naive"])
+def test_golden_full(pkg, path, strategy):
+    z = np.load(path)
+    m, l, n = (int(x) for x in z["dims"])
+    c = _host_mul(pkg, z["a"], z["b"], m, l, n, strategy)
+    assert np.array_equal(c, z["c"])
+
+
+def test_golden_digests(pkg, dev):
+    with open(os.path.join(GOLDEN, "digests.json")) as f:
+        dig = json.load(f)
+    for name, d in sorted(dig.items()):
+        m, l, n = d["m"], d["l"], d["n"]
+        A = dev.DMat.random(m, l, d["seed_a"])
+        B = dev.DMat.random(l, n, d["seed_b"])
+        for algo in ("m4rm", "strassen", "naive"):
+            c = dev.mul(A, B, algo=algo).to_words()
+            assert hashlib.sha256(c.tobytes()).hexdigest() == d["sha256_c"], (name, algo)
+
+
+# ---- device generator == oracle generator ---------------------------------------------------------
+
+def test_device_random_matches_oracle(dev):
+    for (r, c) in [(1, 1), (7, 63), (65, 130), (300, 1000)]:
+        assert np.array_equal(dev.DMat.random(r, c, 99).to_words(), g.random_words(r, c, 99))
+
+
+# ---- random shapes against the oracle -------------------------------------------------------------
+
+SHAPES = [(1, 1, 1), (3, 5, 7), (64, 64, 64), (65, 65, 65), (127, 129, 63), (1, 300, 500), (9, 300, 500),
+          (500, 1, 300), (257, 2049, 33), (1025, 70, 2049), (1300, 900, 4100), (2048, 2048, 2048), (300, 4096, 64)]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_random_vs_oracle(pkg, shape):
+    m, l, n = shape
+    a, b = g.random_words(m, l, 11), g.random_words(l, n, 12)
+    ref = g.o_mul_m4rm(a, b, m, l, n)
+    for strategy in ("strassen", "m4rm", "naive"):
+        assert np.array_equal(_host_mul(pkg, a, b, m, l, n, strategy), ref), strategy
+
+
+def test_addmul_and_prealloc(pkg):
+    L = pkg._lib.lib()
+    m, l, n = 130, 200, 190
+    a, b, c0 = g.random_words(m, l, 1), g.random_words(l, n, 2), g.random_words(m, n, 3)
+    prod = g.o_mul_m4rm(a, b, m, l, n)
+    A, B = pkg.BinMatrix.from_words(a, l), pkg.BinMatrix.from_words(b, n)
+    for fn, extra in ((L.mzd_addmul_m4rm, (0,)), (L.mzd_addmul, (0,)), (L.mzd_addmul_naive, ())):
+        C = pkg.BinMatrix.from_words(c0, n)
+        r = fn(C.mzd, A.mzd, B.mzd, *extra)
+        assert r and np.array_equal(C.to_words(), c0 ^ prod)
+    for fn, extra in ((L.mzd_mul_m4rm, (0,)), (L.mzd_mul, (0,)), (L.mzd_mul_naive, ())):
+        C = pkg.BinMatrix.from_words(c0, n)  # preallocated, overwritten
+        r = fn(C.mzd, A.mzd, B.mzd, *extra)
+        assert r and np.array_equal(C.to_words(), prod)
+
+
+def test_mul_naive_t_and_va(pkg):
+    L = pkg._lib.lib()
+    m, l, n = 300, 256, 70
+    a, b = g.random_words(m, l, 5), g.random_words(l, n, 6)
+    prod = g.o_mul_naive(a, b, m, l, n)
+    A = pkg.BinMatrix.from_words(a, l)
+    Bt = pkg.BinMatrix.from_words(g.o_transpose(b, l, n), l)
+    C = pkg.BinMatrix.from_words(g.random_words(m, n, 7), n)
+    assert L._mzd_mul_naive(C.mzd, A.mzd, Bt.mzd, 1) and np.array_equal(C.to_words(), prod)
+    c0 = C.to_words()
+    assert L._mzd_mul_naive(C.mzd, A.mzd, Bt.mzd, 0) and np.array_equal(C.to_words(), c0 ^ prod)
+    # v * A
+    v = g.random_words(1, m, 8)
+    V = pkg.BinMatrix.from_words(v, m)
+    Am = pkg.BinMatrix.from_words(a, l)
+    ref = g.o_mul_m4rm(v, a, 1, m, l)
+    C = pkg.BinMatrix.zero(1, l)
+    assert L._mzd_mul_va(C.mzd, V.mzd, Am.mzd, 1) and np.array_equal(C.to_words(), ref)
+    assert L._mzd_mul_va(C.mzd, V.mzd, Am.mzd, 0) and not C.to_words().any()
+
+
+def test_windows(pkg):
+    L = pkg._lib.lib()
+    big = pkg.BinMatrix.from_words(g.random_words(300, 500, 21), 500)
+    bw = big.to_words()
+    W = L.mzd_init_window(big.mzd, 10, 64, 210, 64 + 130)  # 200 x 130 window, ragged tail
+    B = pkg.BinMatrix.from_words(g.random_words(130, 77, 22), 77)
+    C = L.mzd_mul_m4rm(None, W, B.mzd, 0)
+    sub = g.bits_to_words(g.words_to_bits(bw, 500)[10:210, 64:194])
+    ref = g.o_mul_m4rm(sub, B.to_words(), 200, 130, 77)
+    assert np.array_equal(pkg.BinMatrix(C).to_words(), ref)
+    # window as destination: the parent's bits outside the window must survive
+    dst = pkg.BinMatrix.from_words(g.random_words(250, 300, 23), 300)
+    before = g.words_to_bits(dst.to_words(), 300)
+    Wd = L.mzd_init_window(dst.mzd, 20, 128, 220, 128 + 77)
+    assert L.mzd_mul_m4rm(Wd, W, B.mzd, 0)
+    after = g.words_to_bits(dst.to_words(), 300)
+    expect = before.copy()
+    expect[20:220, 128:205] = g.words_to_bits(ref, 77)
+    assert np.array_equal(after, expect)
+    L.mzd_free(W)
+    L.mzd_free(Wd)
+
+
+def test_matrix_vector_lpn(pkg):
+    """A (2^k x 256) * v: the mul_slice path (binary_matrix.rs:416-431,528-542)."""
+    m, l = 5000, 256
+    a = g.random_words(m, l, 3)
+    A = pkg.BinMatrix.from_words(a, l)
+    v = pkg.BinVector(g.random_words(1, l, 4)[0], l)
+    res = A * v
+    ref = g.o_mul_naive(a, g.o_transpose(v.get_storage().reshape(1, -1), 1, l), m, l, 1)
+    assert len(res) == m
+    assert np.array_equal(res.get_storage(), g.o_transpose(ref, m, 1)[0])
+
+
+# ---- device-resident API, larger sizes ------------------------------------------------------------
+
+def test_dev_mul_4096_vs_oracle(dev):
+    n = 4096
+    a, b = g.random_words(n, n, 1), g.random_words(n, n, 2)
+    ref = g.o_mul_fast(a, b, n, n, n)
+    A, B = dev.DMat.random(n, n, 1), dev.DMat.random(n, n, 2)
+    for algo, param in (("m4rm", 0), ("strassen", 1), ("strassen", 2), ("strassen", 3), ("auto", 0)):
+        assert np.array_equal(dev.mul(A, B, algo=algo, param=param).to_words(), ref), (algo, param)
+
+
+def test_dev_accumulate_and_nt(dev):
+    m, l, n = 1500, 2000, 2500
+    A, B, C0 = dev.DMat.random(m, l, 1), dev.DMat.random(l, n, 2), dev.DMat.random(m, n, 3)
+    P = dev.mul(A, B, algo="m4rm")
+    C = dev.add(C0, C0)  # zero
+    C = dev.add(C, C0)   # copy of C0
+    dev.mul(A, B, C=C, accumulate=True, algo="m4rm")
+    assert dev.equal(C, dev.add(C0, P))
+    Bt = dev.transpose(B)
+    assert dev.equal(dev.transpose(Bt), B)
+    small_n = 64
+    B2 = dev.DMat.random(l, small_n, 5)
+    assert dev.equal(dev.mul_nt(A, dev.transpose(B2)), dev.mul(A, B2, algo="m4rm"))
+
+
+def test_dev_transpose_vs_oracle(dev):
+    for (r, c) in [(1, 1), (64, 64), (65, 63), (300, 1000), (1000, 1)]:
+        w = g.random_words(r, c, 17)
+        assert np.array_equal(dev.transpose(dev.DMat.from_words(w, c)).to_words(), g.o_transpose(w, r, c))
+
+
+@pytest.mark.parametrize("n,levels", [(8192, 1), (16384, 2)])
+def test_dev_strassen_equals_m4rm_large(dev, n, levels):
+    A, B = dev.DMat.random(n, n, 1), dev.DMat.random(n, n, 2)
+    P0 = dev.mul(A, B, algo="m4rm")
+    P1 = dev.mul(A, B, algo="strassen", param=levels)
+    assert dev.equal(P0, P1)
+    # spot-check 64 random rows of the product against the oracle's row-vector product
+    rng = np.random.default_rng(5)
+    rows = np.sort(rng.choice(n, size=8, replace=False))
+    a = g.random_words(n, n, 1)[rows]
+    b = g.random_words(n, n, 2)
+    ref = g.o_mul_m4rm(np.ascontiguousarray(a), b, len(rows), n, n)
+    assert np.array_equal(P1.to_words()[rows], ref)
+
+
+def test_dev_properties_full_size(dev):
+    """Size-independent properties at a BASELINE config size (32768): linearity in B and
+    associativity with a vector, (A*B)*x == A*(B*x)."""
+    n = 32768
+    A, B, B2 = dev.DMat.random(n, n, 1), dev.DMat.random(n, n, 2), dev.DMat.random(n, n, 3)
+    P = dev.mul(A, B)           # auto: Strassen over M4RM
+    P2 = dev.mul(A, B2)
+    S = dev.mul(A, dev.add(B, B2))
+    assert dev.equal(S, dev.add(P, P2))
+    x = dev.DMat.random(n, 64, 4)
+    assert dev.equal(dev.mul(P, x, algo="m4rm"), dev.mul(A, dev.mul(B, x, algo="m4rm"), algo="m4rm"))
+    I = dev.DMat(n, n)
+    from m4ri_rust_amd import BinMatrix
+    I = dev.DMat.from_host(BinMatrix.identity(n))
+    assert dev.equal(dev.mul(A, I), A) and dev.equal(dev.mul(I, A, algo="m4rm"), A)

@@ -1,0 +1,206 @@
+"""CPU tests of the drop-in boundary: libm4ri_hip.so loads, exports everything include/m4ri_hip.h
+declares, keeps M4RI's mzd_t layout, and its host-side container functions behave as the
+reference's tests expect (m4ri-sys/src/mzd.rs:374-461, binary_matrix.rs:588-774, binary_vector.rs:217-288).
+No compute call is made (no GPU here): the multiply entry points must fail loudly instead."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import gf2util as g
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def pkg(built):
+    import m4ri_rust_amd as p
+    return p
+
+
+def test_header_symbols_are_exported(pkg):
+    hdr = open(os.path.join(ROOT, "include", "m4ri_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(_?mzd_\w+|m4ri_opt_k|gf2_\w+)\s*\(", hdr))
+    declared -= {"gf2_dmat"}
+    assert len(declared) > 40
+    out = subprocess.check_output(["nm", "-D", "--defined-only", pkg._lib.LIB_PATH], text=True)
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    assert declared <= exported, sorted(declared - exported)
+    assert declared == set(pkg._lib.DECLARED_SYMBOLS), sorted(declared ^ set(pkg._lib.DECLARED_SYMBOLS))
+
+
+def test_header_compiles_as_c_and_struct_is_64_bytes(tmp_path):
+    src = tmp_path / "t.c"
+    src.write_text('#include "m4ri_hip.h"\n#include <stddef.h>\n'
+                   "_Static_assert(sizeof(mzd_t)==64, \"size\");\n"
+                   "_Static_assert(offsetof(mzd_t,nrows)==0 && offsetof(mzd_t,ncols)==4 && offsetof(mzd_t,width)==8 && "
+                   "offsetof(mzd_t,rowstride)==12 && offsetof(mzd_t,offset_vector)==16 && offsetof(mzd_t,row_offset)==20 && "
+                   "offsetof(mzd_t,flags)==24 && offsetof(mzd_t,blockrows_log)==25 && offsetof(mzd_t,high_bitmask)==40 && "
+                   "offsetof(mzd_t,blocks)==48 && offsetof(mzd_t,rows)==56, \"offsets\");\n"
+                   "_Static_assert(sizeof(mzd_block_t)==24, \"block\");\nint main(void){return 0;}\n")
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o", str(tmp_path / "t.o")])
+
+
+def test_mzd_init_like_reference(pkg):
+    """mzd.rs:381-399 `init` and :401-422 (mzd_first_row / mzd_row address rule)."""
+    L = pkg._lib.lib()
+    for _ in range(20):
+        m = L.mzd_init(10, 10)
+        z = m.contents
+        assert bool(z.blocks) and bool(z.rows)
+        L.mzd_randomize(m)
+        assert L.mzd_equal(m, m) == 1
+        m2 = L.mzd_copy(None, m)
+        assert L.mzd_equal(m2, m) == 1
+        L.mzd_randomize(m2)
+        assert L.mzd_equal(m2, m) == 0
+        # mzd_first_row: blocks[0].begin + offset_vector == rows[0]; mzd_row: + row*rowstride
+        base = ctypes.addressof(z.blocks[0].begin.contents)
+        for r in range(10):
+            assert ctypes.addressof(z.rows[r].contents) == base + 8 * (z.offset_vector + r * z.rowstride)
+        assert (z.row_offset + 9) >> z.blockrows_log == 0 and not (z.flags & 0x20)
+        L.mzd_free(m)
+        L.mzd_free(m2)
+
+
+@pytest.mark.parametrize("cols,width,stride", [(1, 1, 1), (64, 1, 1), (65, 2, 2), (129, 3, 4), (256, 4, 4), (300, 5, 6)])
+def test_rowstride_rule(pkg, cols, width, stride):
+    """mzd.rs:34-38: rowstride = width, +1 if odd and >= padding width."""
+    L = pkg._lib.lib()
+    m = L.mzd_init(3, cols)
+    z = m.contents
+    assert (z.width, z.rowstride) == (width, stride)
+    assert z.high_bitmask == ((1 << (cols % 64)) - 1 if cols % 64 else 2 ** 64 - 1)
+    L.mzd_free(m)
+
+
+def test_read_write_bit_identity(pkg):
+    """mzd.rs:425-460: set_ui(1) is the unit matrix under the LSB-first bit rule."""
+    I = pkg.BinMatrix.identity(1000)
+    bits = g.words_to_bits(I.to_words(), 1000)
+    assert np.array_equal(bits, np.eye(1000, dtype=np.uint8))
+    assert I.bit(999, 999) and not I.bit(999, 998)
+
+
+def test_binmatrix_construction(pkg):
+    """binary_matrix.rs:595-659 (new, identity), :722-755 (zero, set_window), :758 (random unequal)."""
+    BM, BV = pkg.BinMatrix, pkg.BinVector
+    BM.new([BV.from_bools([True, False, True]), BV.from_bools([True, True, True])])
+    ident = BM.new([BV.from_bools([i == j for j in range(10)]) for i in range(10)])
+    assert ident == BM.identity(10)
+    z = BM.zero(10, 3)
+    assert not any(z.bit(i, j) for i in range(10) for j in range(3))
+    m1 = BM.zero(10, 10)
+    m1.set_window(5, 5, BM.identity(5))
+    for i in range(10):
+        for j in range(10):
+            assert m1.bit(i, j) == (i == j and i >= 5)
+    assert BM.random(100, 100) != BM.random(100, 100)
+    with pytest.raises(pkg.PanicError):
+        BM.zero(0, 5)
+    with pytest.raises(pkg.PanicError):
+        BM.from_slices([], 5)
+    # tail of from_slices is masked (binary_matrix.rs:151-155)
+    m = BM.from_slices([[2 ** 64 - 1]], 10)
+    assert m.to_words()[0, 0] == 1023
+
+
+def test_as_vector_roundtrips(pkg):
+    """binary_matrix.rs:702-719 and binary_vector.rs:262-277."""
+    BM, BV = pkg.BinMatrix, pkg.BinVector
+    for i in range(1, 25):
+        m1 = BM.random(i, 1)
+        vec = m1.as_vector()
+        assert len(vec) == i and m1 == vec.as_column_matrix()
+        m2 = BM.random(1, i)
+        vec = m2.as_vector()
+        assert len(vec) == i and m2 == vec.as_matrix()
+    a = BV.random(10)
+    assert a.as_matrix().ncols() == 10 and a.as_matrix().nrows() == 1 and a.as_matrix().as_vector() == a
+    assert a.as_column_matrix().nrows() == 10 and a.as_column_matrix().as_vector() == a
+
+
+def test_count_ones(pkg):
+    """binary_matrix.rs:765-773."""
+    rng = np.random.default_rng(1)
+    for _ in range(100):
+        size = int(rng.integers(1, 1000))
+        v = pkg.BinVector.random(size, rng)
+        assert v.count_ones() == v.as_matrix().count_ones() == v.as_column_matrix().count_ones()
+
+
+def test_binvector_semantics(pkg):
+    """binary_vector.rs:222-287."""
+    BV = pkg.BinVector
+    assert len(BV.from_elem(10, False)) == 10
+    assert len(BV.from_bytes(bytes([0xFF]))) == 8
+    b = BV.from_bytes(bytes([0b1000_0000]))
+    assert b.get(0) is True and b.get(1) is False
+    a, b = BV.from_elem(10, False), BV.from_elem(10, False)
+    c = a + b
+    assert len(c) == 10 and c == BV.from_elem(10, False)
+    assert (BV.from_elem(10, True) * BV.from_elem(10, False)) is False
+    assert (BV.from_elem(11, True) * BV.from_elem(11, True)) is True
+    assert BV.from_elem(10, True).count_ones() == 10 and BV.from_bytes(bytes([0b1010_1000])).count_ones() == 3
+    v = BV.from_function(4, lambda i: i % 2 == 0)
+    assert v.get(0) is True and v.get(1) is False
+    with pytest.raises(pkg.PanicError):
+        BV.from_elem(3, True) + BV.from_elem(4, True)
+
+
+def test_host_transpose_add_concat_stack_vs_oracle(pkg):
+    BM = pkg.BinMatrix
+    for (r, c) in [(1, 1), (64, 64), (65, 63), (100, 257), (1000, 1), (1, 1000), (300, 500)]:
+        w = g.random_words(r, c, 3)
+        m = BM.from_words(w, c)
+        assert np.array_equal(m.transposed().to_words(), g.o_transpose(w, r, c))
+        w2 = g.random_words(r, c, 4)
+        assert np.array_equal((m + BM.from_words(w2, c)).to_words(), w ^ w2)
+        mm = m.clone()
+        mm += BM.from_words(w2, c)
+        assert np.array_equal(mm.to_words(), w ^ w2)
+    a, b = BM.from_words(g.random_words(5, 70, 1), 70), BM.from_words(g.random_words(5, 3, 2), 3)
+    cat = g.words_to_bits(a.augmented(b).to_words(), 73)
+    assert np.array_equal(cat[:, :70], g.words_to_bits(a.to_words(), 70)) and np.array_equal(cat[:, 70:], g.words_to_bits(b.to_words(), 3))
+    s = a.stacked(BM.from_words(g.random_words(2, 70, 9), 70))
+    assert s.nrows() == 7 and np.array_equal(s.to_words()[:5], a.to_words())
+    win = a.get_window(1, 3, 4, 69)
+    assert np.array_equal(g.words_to_bits(win.to_words(), 66), g.words_to_bits(a.to_words(), 70)[1:4, 3:69])
+
+
+def test_window_shares_memory(pkg):
+    L = pkg._lib.lib()
+    big = pkg.BinMatrix.from_words(g.random_words(20, 200, 5), 200)
+    W = L.mzd_init_window(big.mzd, 2, 64, 10, 150)
+    z = W.contents
+    assert (z.nrows, z.ncols, z.width) == (8, 86, 2) and z.flags & 0x4
+    assert ctypes.addressof(z.rows[0].contents) == ctypes.addressof(big.mzd.contents.rows[2].contents) + 8
+    L.mzd_free(W)
+    assert big.bit(0, 0) in (True, False)  # parent still alive and readable
+
+
+def test_mul_fails_loudly_without_gpu(pkg):
+    from m4ri_rust_amd import device
+    if device.device_count() > 0:
+        pytest.skip("a GPU is present: the loud-failure path is for GPU-less hosts")
+    with pytest.raises(pkg.PanicError, match="Multiplication failed"):
+        pkg.BinMatrix.identity(8) * pkg.BinMatrix.identity(8)
+    with pytest.raises(pkg._lib.HipError):
+        device.DMat(4, 4)
+    with pytest.raises(pkg._lib.HipError):
+        device.require_gpu()
+
+
+def test_product_code_never_touches_the_oracle():
+    """The product path must not import, link or execute anything under oracle/."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "m4ri-rust_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "gf2_oracle" not in txt and "libgf2oracle" not in txt and "gf2util" not in txt, f
+    out = subprocess.check_output(["ldd", os.path.join(ROOT, "m4ri-rust_amd", "lib", "libm4ri_hip.so")], text=True)
+    assert "oracle" not in out
