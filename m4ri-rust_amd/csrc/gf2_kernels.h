@@ -19,6 +19,7 @@ struct gf2k_mul_args {
 extern "C" {
 int gf2k_m4rm_rows_per_tile(int cfg);
 hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream);
+hipError_t gf2k_dbg_sec(unsigned long long *out8);
 hipError_t gf2k_rowparity(const uint64_t *A, long long lda, const uint64_t *Bt, long long ldbt, uint64_t *C, long long ldc,
                           int m, int l, int n, int accumulate, hipStream_t stream);
 hipError_t gf2k_va(const uint64_t *A, long long lda, const uint64_t *B, long long ldb, uint64_t *C, long long ldc, int m,

@@ -21,6 +21,9 @@
 //  * everything else is an HBM-streaming kernel with 16-byte accesses.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <type_traits>
+#include <utility>
 #include "gf2_kernels.h"
 
 typedef uint64_t u64;
@@ -220,6 +223,298 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel(const gf2k_mul_arg
       u64 *dst = C + (long long)row * p.ldc + wc;
       u64 v0 = (u64)acc[s].x | ((u64)acc[s].y << 32);
       u64 v1 = (u64)acc[s].z | ((u64)acc[s].w << 32);
+      if (wc == widthB - 1) v0 &= maskC;
+      if (wc + 1 == widthB - 1) v1 &= maskC;
+      if (wc + 1 < widthB) {
+        if (p.accumulate) {
+          const uint4 old = *reinterpret_cast<const uint4 *>(dst);
+          v0 ^= (u64)old.x | ((u64)old.y << 32);
+          v1 ^= (u64)old.z | ((u64)old.w << 32);
+        }
+        *reinterpret_cast<uint4 *>(dst) = make_uint4((u32)v0, (u32)(v0 >> 32), (u32)v1, (u32)(v1 >> 32));
+      } else {
+        if (p.accumulate) v0 ^= dst[0];
+        dst[0] = v0;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// helpers for the v3 kernel
+// ---------------------------------------------------------------------------------------------
+
+template <int N, typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+  static_for_impl<N>(static_cast<F &&>(f), std::make_integer_sequence<int, N>{});
+}
+
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const u32x4 lds_cu32x4;
+typedef __attribute__((address_space(3))) const u64 lds_cu64;
+typedef __attribute__((address_space(3))) u64 lds_u64;
+typedef __attribute__((address_space(3))) u32 lds_u32;
+
+// ---------------------------------------------------------------------------------------------
+// M4RM tile kernel v3: instruction-count-minimal form ("issue model").
+// Measured on gfx950 (tools/ubench): a SIMD issues at most one instruction per ~2.2 cycles whatever
+// its type (s_waitcnt / s_mov / s_nop included), v_perm_b32 is half rate, ds_read_b128 costs 4 LDS
+// cycles per CU and ds_write_addtid_b32 2.2.  One chunk (8 bits of the inner dimension) of a
+// 1024 x 2048 tile is 256 table-row reads + 256 table-entry writes: ~1600 LDS cycles, and about as
+// many issue cycles if every step is {wait, 4 xor, perm, read, xor, write}.  So:
+//  * B rows come straight from global memory (buffer loads, two chunks ahead) into registers:
+//    no LDS staging, no staging barriers;
+//  * A words are re-fetched in place with buffer loads (row bound check by the buffer descriptor);
+//  * the table of chunk i+1 is written (ds_write_addtid_b32, M0 set once per chunk) between the
+//    lookups of chunk i; G lookups are in flight per wave (rolling window, hand-placed s_waitcnt).
+// ---------------------------------------------------------------------------------------------
+
+// outstanding-LDS-op count to wait for at step st: the reads issued after read(st) plus the table
+// writes issued since (all in order behind it); one write per step when `wps` is 1.
+constexpr int v3_wait_count(int st, int G, int STEPS, int wps) {
+  int reads = 0, writes = 0;
+  if (st >= G) {
+    for (int j = st - G + 1; j <= st - 1; ++j) reads += (j + G < STEPS) ? 1 : 0;
+    writes = G * wps;
+  } else {
+    for (int j = st + 1; j < G; ++j) reads += 1;
+    for (int j = 0; j < st; ++j) reads += (j + G < STEPS) ? 1 : 0;
+    writes = st * wps;
+  }
+  const int n = reads + writes;
+  return n > 15 ? 15 : n;
+}
+
+__device__ unsigned long long gf2_dbg_sec[16];  // diagnostic builds only (DBG != 0): per-section cycle sums
+
+template <int WAVES, int RPW, int G, int DBG = 0>
+__global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v3(const gf2k_mul_args p) {
+  unsigned long long sec[4] = {0, 0, 0, 0};
+  auto stamp = [&]() __attribute__((always_inline)) -> unsigned long long {
+    unsigned long long tt;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return tt;
+  };
+  constexpr int R = WAVES * RPW;
+  constexpr int STEPS = RPW / 4;
+  constexpr int EPW = 256 / WAVES;  // table entries built per wave
+  constexpr int LOWB = Log2<EPW>::value;
+  constexpr int WPS = (EPW + STEPS - 1) / STEPS;  // entry writes per lookup step
+  static_assert(EPW * WAVES == 256 && G <= STEPS && EPW <= WPS * STEPS, "geometry");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int t;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = t % p.tiles_m;
+  t /= p.tiles_m;
+  const int tn = t % p.tiles_n;
+  const int bt = t / p.tiles_n;
+  const u64 *__restrict__ A = p.A + (long long)bt * p.sA;
+  const u64 *__restrict__ B = p.B + (long long)bt * p.sB;
+  u64 *__restrict__ C = p.C + (long long)bt * p.sC;
+
+  const int row0 = tm * R, w0 = tn * kTileWords;
+  const int widthA = (p.l + 63) >> 6, widthB = (p.n + 63) >> 6;
+  const u64 maskC = (p.n & 63) ? ((1ull << (p.n & 63)) - 1) : ~0ull;
+  const int nw32 = (p.l + 31) >> 5;
+  const int nchunks = nw32 * 4;
+  (void)widthA;
+
+  const int g = lane >> 4, qd = lane & 15;
+  const u32 laneoff0 = (u32)qd * 16u, laneoff1 = laneoff0 | 0x10000u;
+  const int myrow0 = row0 + wave * RPW + g;
+
+  // accumulators as scalars (not 128-bit tuples): the allocator can place them anywhere
+  u32 acc[STEPS][4];
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) acc[s][0] = acc[s][1] = acc[s][2] = acc[s][3] = 0;
+
+  // ---- A: 32-bit word j of the row of each step; rows past m read as zero (descriptor bound) ----
+  const u32 ldaB = (u32)p.lda * 8u;
+  const int rows_here = min(p.m - row0, R);
+  const __amdgpu_buffer_rsrc_t rsrcA =
+      __builtin_amdgcn_make_buffer_rsrc((void *)(A + (long long)row0 * p.lda), (short)0, (int)((u32)rows_here * ldaB), 0x00020000);
+  const u32 voffA0 = (u32)(wave * RPW + g) * ldaB;
+  const u32 tailA = (p.l & 31) ? ((1u << (p.l & 31)) - 1u) : 0xffffffffu;  // valid bits of the last 32-bit word
+  u32 aw[STEPS];
+  auto loadA_all = [&](int j) __attribute__((always_inline)) {
+    u32 vo = voffA0;
+    asm volatile("" : "+v"(vo));
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      aw[s] = __builtin_amdgcn_raw_buffer_load_b32(rsrcA, vo, j * 4, 0);
+      vo += 4u * ldaB;
+    }
+  };
+
+  // ---- B: dword `lane` of the 8 rows of a chunk, straight into registers ----
+  const u32 ldbB = (u32)p.ldb * 8u;
+  const int validB = min(256, (widthB - w0) * 8);            // bytes of this tile's columns that exist
+  const u32 voffB = ((int)(lane * 4) < validB) ? (u32)lane * 4u : 0x80000000u;  // out of range -> reads 0
+  auto rsrcB_for = [&](int c) __attribute__((always_inline)) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(B + (long long)c * 8 * p.ldb + w0), (short)0, (int)(8u * ldbB), 0x00020000);
+  };
+  // FAST: all 8 rows exist.  Otherwise rows past the inner dimension read as zero (wave-uniform test).
+  auto loadBrow = [&](auto fast, const __amdgpu_buffer_rsrc_t &rs, int c, int b) __attribute__((always_inline)) -> u32 {
+    if constexpr (decltype(fast)::value) {
+      return __builtin_amdgcn_raw_buffer_load_b32(rs, voffB, b * (int)ldbB, 0);
+    } else {
+      u32 x = 0;
+      if (c * 8 + b < p.l) x = __builtin_amdgcn_raw_buffer_load_b32(rs, voffB, b * (int)ldbB, 0);
+      return x;
+    }
+  };
+
+  // ---- table build: wave w owns entries [EPW*w, EPW*(w+1)), one ds_write_addtid_b32 per entry ----
+  u32 cur32 = 0;
+  auto build_begin = [&](const u32 (&rr)[8], u32 tbase) __attribute__((always_inline)) {
+    cur32 = 0;
+#pragma unroll
+    for (int b = LOWB; b < 8; ++b)
+      if ((wave >> (b - LOWB)) & 1) cur32 ^= rr[b];
+    // LDS address of an addtid write = M0[15:0] + imm16 + 4*lane; the upper table lies above 64 KiB, so the
+    // constant is split (kOff): M0 = (w+1)*EPW*256 - 4 <= 0xFFFC and imm <= 0xFF04 for every wave (verified on
+    // gfx950: the sum is not wrapped at 16 bits)
+    const u32 kOff = tbase ? (0x10004u - (u32)(EPW * 256)) : 0u;
+    const u32 m0v = tbase + (u32)wave * (u32)(EPW * 256) - kOff;
+    asm volatile("s_mov_b32 m0, %0" ::"s"(m0v) : "memory");
+  };
+  auto build_entry = [&](auto itag, auto ttag, const u32 (&rr)[8]) __attribute__((always_inline)) {
+    constexpr int i = decltype(itag)::value;
+    constexpr u32 tbase = decltype(ttag)::value;
+    constexpr unsigned e = (unsigned)i ^ ((unsigned)i >> 1);
+    constexpr u32 kOff = tbase ? (0x10004u - (u32)(EPW * 256)) : 0u;
+    if constexpr (i > 0) cur32 ^= rr[__builtin_ctz(i | 256)];
+    asm volatile("ds_write_addtid_b32 %0 offset:%1" ::"v"(cur32), "n"(kOff + e * 256u) : "memory");
+  };
+
+  // ---- prologue: rows of chunk 0 -> table 0, rows of chunk 1 -> rrB, A column 0 ----
+  u32 rrA[8], rrB[8];
+  {
+    const __amdgpu_buffer_rsrc_t rs0 = rsrcB_for(0), rs1 = rsrcB_for(1);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      rrA[b] = loadBrow(std::false_type{}, rs0, 0, b);
+      rrB[b] = loadBrow(std::false_type{}, rs1, 1, b);
+    }
+  }
+  loadA_all(0);
+  if (nw32 == 1) {
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) aw[s] &= tailA;
+  }
+  build_begin(rrA, 0u);
+  static_for<EPW>([&](auto it) __attribute__((always_inline)) { build_entry(it, std::integral_constant<u32, 0u>{}, rrA); });
+  __syncthreads();
+
+  // one chunk: look up chunk i in table (C4&1); build chunk i+1 from `rows` into the other table; fetch the
+  // rows of chunk i+2 into `next` and (last chunk of a 32-bit column) the next A column in place.  Every load
+  // is issued between lookup steps, so the texture path works under the LDS traffic instead of after it.
+  auto chunk_iter = [&](int i, auto c4tag, auto fast, const u32 (&rows)[8], u32 (&next)[8]) __attribute__((always_inline)) {
+    constexpr int C4 = decltype(c4tag)::value;
+    const u32 sel = 0x0c020000u | ((4u + (u32)C4) << 8);
+    const u32 lo = (C4 & 1) ? laneoff1 : laneoff0;
+    using tnext = std::integral_constant<u32, (C4 & 1) ? 0u : (u32)kTableBytes>;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    if constexpr (DBG) t0 = stamp();
+    build_begin(rows, tnext::value);
+    const __amdgpu_buffer_rsrc_t rsN = rsrcB_for(i + 2);
+    const int jn = (i >> 2) + 1;
+    u32 voA = voffA0;
+    asm volatile("" : "+v"(voA));
+    u32x4 tv[G];
+    auto issue = [&](int st, u32x4 &dst) __attribute__((always_inline)) {
+      u32 addr;
+      asm volatile("v_perm_b32 %1, %2, %3, %4\n\tds_read_b128 %0, %1" : "=v"(dst), "=&v"(addr) : "v"(aw[st]), "v"(lo), "s"(sel) : "memory");
+    };
+#pragma unroll
+    for (int k = 0; k < G; ++k) issue(k, tv[k]);
+    static_for<STEPS>([&](auto stag) __attribute__((always_inline)) {
+      constexpr int st = decltype(stag)::value;
+      constexpr int N = v3_wait_count(st, G, STEPS, WPS);
+      asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(tv[st % G]) : "n"(N) : "memory");
+      acc[st][0] ^= tv[st % G].x;
+      acc[st][1] ^= tv[st % G].y;
+      acc[st][2] ^= tv[st % G].z;
+      acc[st][3] ^= tv[st % G].w;
+      // no reassociation across chunks (it would keep every table row read alive until the last one)
+      asm volatile("" : "+v"(acc[st][0]), "+v"(acc[st][1]), "+v"(acc[st][2]), "+v"(acc[st][3]));
+      if constexpr (st + G < STEPS) issue(st + G, tv[st % G]);
+      static_for<WPS>([&](auto ktag) __attribute__((always_inline)) {
+        constexpr int e = st * WPS + decltype(ktag)::value;
+        if constexpr (e < EPW) build_entry(std::integral_constant<int, e>{}, tnext{}, rows);
+      });
+      if constexpr (st < 8) next[st] = loadBrow(fast, rsN, i + 2, st);
+      if constexpr (C4 == 3) {  // aw[st] was consumed G steps ago: fetch the next column's word in place
+        aw[st] = __builtin_amdgcn_raw_buffer_load_b32(rsrcA, voA, jn * 4, 0);
+        voA += 4u * ldaB;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if constexpr (DBG) t1 = stamp();
+    if constexpr (C4 == 3) {
+      if (jn == nw32 - 1 && tailA != 0xffffffffu) {
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) aw[s] &= tailA;
+      }
+    }
+    if constexpr (DBG) t2 = stamp();
+    __syncthreads();
+    if constexpr (DBG) {
+      t3 = stamp();
+      sec[0] += t1 - t0;  // steps (lookups + build + interleaved loads)
+      sec[1] += t2 - t1;  // tail mask
+      sec[2] += t3 - t2;  // barrier wait
+      sec[3] += 1;
+    }
+  };
+
+  // two separate loops (not one loop with a branch): the register allocator otherwise spills the
+  // accumulators around the merge point
+  int i = 0;
+#pragma unroll 1
+  for (; (i + 6) * 8 <= p.l; i += 4) {  // chunks i+2 .. i+5 lie wholly inside the inner dimension
+    chunk_iter(i + 0, std::integral_constant<int, 0>{}, std::true_type{}, rrB, rrA);
+    chunk_iter(i + 1, std::integral_constant<int, 1>{}, std::true_type{}, rrA, rrB);
+    chunk_iter(i + 2, std::integral_constant<int, 2>{}, std::true_type{}, rrB, rrA);
+    chunk_iter(i + 3, std::integral_constant<int, 3>{}, std::true_type{}, rrA, rrB);
+  }
+#pragma unroll 1
+  for (; i < nchunks; i += 4) {  // ragged end
+    chunk_iter(i + 0, std::integral_constant<int, 0>{}, std::false_type{}, rrB, rrA);
+    chunk_iter(i + 1, std::integral_constant<int, 1>{}, std::false_type{}, rrA, rrB);
+    chunk_iter(i + 2, std::integral_constant<int, 2>{}, std::false_type{}, rrB, rrA);
+    chunk_iter(i + 3, std::integral_constant<int, 3>{}, std::false_type{}, rrA, rrB);
+  }
+
+  if constexpr (DBG) {
+    if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == WAVES - 1)) {
+      const int o = wave ? 4 : 0;
+      gf2_dbg_sec[o + 0] = sec[0];
+      gf2_dbg_sec[o + 1] = sec[1];
+      gf2_dbg_sec[o + 2] = sec[2];
+      gf2_dbg_sec[o + 3] = sec[3];
+    }
+  }
+  const int wc = w0 + 2 * qd;
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    const int row = myrow0 + 4 * s;
+    if (row < p.m && wc < widthB) {
+      u64 *dst = C + (long long)row * p.ldc + wc;
+      u64 v0 = (u64)acc[s][0] | ((u64)acc[s][1] << 32);
+      u64 v1 = (u64)acc[s][2] | ((u64)acc[s][3] << 32);
       if (wc == widthB - 1) v0 &= maskC;
       if (wc + 1 == widthB - 1) v1 &= maskC;
       if (wc + 1 < widthB) {
@@ -532,8 +827,23 @@ static inline int grid_for(long long total, int block = 256, int cap = 256 * 8) 
   return (int)g;
 }
 
-extern "C" int gf2k_m4rm_rows_per_tile(int cfg) { return cfg == 1 ? 256 : 1024; }
+extern "C" int gf2k_m4rm_rows_per_tile(int cfg) { return (cfg == 1 || cfg == 20) ? 256 : 1024; }
 
+template <typename K>
+static hipError_t launch_tile_kernel(K kernel, int threads, const gf2k_mul_args &a, long long nwg, hipStream_t stream) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     kLdsBytes);
+  if (e != hipSuccess) {
+    fprintf(stderr, "gf2k: hipFuncSetAttribute failed: %s\n", hipGetErrorString(e));
+    return e;
+  }
+  hipLaunchKernelGGL(kernel, dim3((unsigned)nwg), dim3(threads), kLdsBytes, stream, a);
+  e = hipGetLastError();
+  if (e != hipSuccess) fprintf(stderr, "gf2k: tile kernel launch failed: %s\n", hipGetErrorString(e));
+  return e;
+}
+
+// cfg: 0 = v1 8x128, 1 = v1 4x64 (small m), 2.. = pipelined variants (see kbench)
 extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {
   if (a.m <= 0 || a.n <= 0 || a.batch <= 0) return hipSuccess;
   const int R = gf2k_m4rm_rows_per_tile(cfg);
@@ -541,21 +851,20 @@ extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {
   a.tiles_n = (a.n + 2047) / 2048;
   const long long nwg = (long long)a.tiles_m * a.tiles_n * a.batch;
   if (nwg > 0x7fffffffLL) return hipErrorInvalidValue;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gf2_m4rm_kernel<8, 128>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gf2_m4rm_kernel<4, 64>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-    if (e != hipSuccess) return e;
-    attr_set = true;
+  switch (cfg) {
+    case 0: return launch_tile_kernel(&gf2_m4rm_kernel<8, 128>, 512, a, nwg, stream);
+    case 1: return launch_tile_kernel(&gf2_m4rm_kernel<4, 64>, 256, a, nwg, stream);
+    case 6: return launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 6>, 512, a, nwg, stream);
+    case 7: return launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4>, 512, a, nwg, stream);
+    case 8: return launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 7>, 512, a, nwg, stream);
+    case 20: return launch_tile_kernel(&gf2_m4rm_kernel_v3<4, 64, 4>, 256, a, nwg, stream);
+    case 9: return launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 6, 1>, 512, a, nwg, stream);  // section stamps
+    default: return hipErrorInvalidValue;
   }
-  if (cfg == 1)
-    hipLaunchKernelGGL((gf2_m4rm_kernel<4, 64>), dim3((unsigned)nwg), dim3(256), kLdsBytes, stream, a);
-  else
-    hipLaunchKernelGGL((gf2_m4rm_kernel<8, 128>), dim3((unsigned)nwg), dim3(512), kLdsBytes, stream, a);
-  return hipGetLastError();
+}
+
+extern "C" hipError_t gf2k_dbg_sec(unsigned long long *out8) {
+  return hipMemcpyFromSymbol(out8, HIP_SYMBOL(gf2_dbg_sec), 8 * sizeof(unsigned long long));
 }
 
 extern "C" hipError_t gf2k_rowparity(const u64 *A, long long lda, const u64 *Bt, long long ldbt, u64 *C, long long ldc,

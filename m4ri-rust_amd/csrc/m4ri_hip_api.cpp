@@ -197,6 +197,39 @@ int free_after(hipStream_t s, void *p, size_t bytes) {
   return 0;
 }
 
+// Per-stream scratch arena: work queued on one stream is serialised, so consecutive products on the same
+// stream can share one workspace without waiting for each other.  It only ever grows.
+struct StreamWs {
+  void *p = nullptr;
+  size_t bytes = 0;
+};
+std::mutex g_ws_mu;
+std::map<std::pair<int, hipStream_t>, StreamWs> g_ws;
+
+int stream_workspace(hipStream_t s, size_t bytes, void **out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  StreamWs &w = g_ws[{dev, s}];
+  if (w.bytes < bytes) {
+    if (w.p) {  // still referenced by queued work: hand it back once the stream has drained past this point
+      if (free_after(s, w.p, w.bytes) != 0) {
+        (void)hipStreamSynchronize(s);
+        dev_free(w.p, w.bytes);
+      }
+      w.p = nullptr;
+      w.bytes = 0;
+    }
+    reap_deferred(false);
+    void *p = nullptr;
+    if (int rc = dev_alloc(&p, bytes)) return rc;
+    w.p = p;
+    w.bytes = bytes;
+  }
+  *out = w.p;
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // kernel timing (bench.py roofline): events around the dominant multiply kernel
 // ---------------------------------------------------------------------------------------------
@@ -307,9 +340,12 @@ static size_t strassen_ws_words(int m, int l, int n, int L) {
 }
 
 static int m4rm_cfg_for(int m, int n, int batch) {
-  // big tile (1024 x 2048, 8 waves) unless it would leave most CUs idle
+  // kernel variants (gf2_kernels.hip): 7 = v3 1024x2048 tile (8 waves), 20 = v3 256x2048 tile (4 waves);
+  // M4RI_HIP_M4RM_CFG overrides (0/1 = first-generation kernels, kept for A/B runs)
+  static const int forced = env_int("M4RI_HIP_M4RM_CFG", -1);
+  if (forced >= 0) return forced;
   const long long big = (long long)((m + 1023) / 1024) * ((n + 2047) / 2048) * batch;
-  return (big < 128 && m > 256) ? 1 : (m <= 256 ? 1 : 0);
+  return (m <= 256 || (big < 128 && m > 256)) ? 20 : 7;
 }
 
 static int mul_m4rm_plain(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int accumulate, hipStream_t s) {
@@ -345,7 +381,7 @@ static int mul_strassen(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int a
   if (L <= 0) return mul_m4rm_plain(C, A, B, accumulate, s);
   const size_t ws_bytes = strassen_ws_words(m, l, n, L) * sizeof(u64);
   void *ws = nullptr;
-  if (int rc = dev_alloc(&ws, ws_bytes)) return rc;
+  if (int rc = stream_workspace(s, ws_bytes, &ws)) return rc;
   u64 *cur = static_cast<u64 *>(ws);
   std::vector<u64 *> Aop(L + 1), Bop(L + 1), Pop(L + 1);
   size_t p7 = 1;
@@ -408,16 +444,7 @@ static int mul_strassen(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int a
     return 0;
   };
   rc = run();
-  if (sync_free) {
-    if (rc == 0 && hipStreamSynchronize(s) != hipSuccess) rc = fail(hipGetLastError(), "hipStreamSynchronize");
-    dev_free(ws, ws_bytes);
-  } else {
-    reap_deferred(false);
-    if (free_after(s, ws, ws_bytes) != 0) {
-      (void)hipStreamSynchronize(s);
-      dev_free(ws, ws_bytes);
-    }
-  }
+  if (sync_free && rc == 0 && hipStreamSynchronize(s) != hipSuccess) rc = fail(hipGetLastError(), "hipStreamSynchronize");
   return rc;
 }
 
@@ -432,28 +459,13 @@ static int mul_naive_dev(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int 
   const long long ldbt = (words_of(l) + 1) & ~1ll;
   const size_t bytes = (size_t)n * ldbt * sizeof(u64);
   void *bt = nullptr;
-  if (int rc = dev_alloc(&bt, bytes)) return rc;
-  int rc = 0;
-  do {
-    hipError_t e = gf2k_transpose(static_cast<u64 *>(bt), ldbt, B->data, B->ld, l, n, s);
-    if (e != hipSuccess) {
-      rc = fail(e, "gf2k_transpose");
-      break;
-    }
-    e = gf2k_rowparity(A->data, A->ld, static_cast<u64 *>(bt), ldbt, C->data, C->ld, m, l, n, accumulate, s);
-    if (e != hipSuccess) rc = fail(e, "gf2k_rowparity");
-  } while (0);
-  if (sync_free) {
-    if (rc == 0 && hipStreamSynchronize(s) != hipSuccess) rc = fail(hipGetLastError(), "hipStreamSynchronize");
-    dev_free(bt, bytes);
-  } else {
-    reap_deferred(false);
-    if (free_after(s, bt, bytes) != 0) {
-      (void)hipStreamSynchronize(s);
-      dev_free(bt, bytes);
-    }
-  }
-  return rc;
+  if (int rc = stream_workspace(s, bytes, &bt)) return rc;
+  hipError_t e = gf2k_transpose(static_cast<u64 *>(bt), ldbt, B->data, B->ld, l, n, s);
+  if (e != hipSuccess) return fail(e, "gf2k_transpose");
+  e = gf2k_rowparity(A->data, A->ld, static_cast<u64 *>(bt), ldbt, C->data, C->ld, m, l, n, accumulate, s);
+  if (e != hipSuccess) return fail(e, "gf2k_rowparity");
+  if (sync_free && hipStreamSynchronize(s) != hipSuccess) return fail(hipGetLastError(), "hipStreamSynchronize");
+  return 0;
 }
 
 static int check_mul_dims(const gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B) {
@@ -465,8 +477,14 @@ static int check_mul_dims(const gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *
   return 0;
 }
 
+// Products that use the per-stream workspace enqueue several kernels that must stay contiguous on the stream
+// (another host thread enqueueing on the SAME stream in between would reuse the arena under them).
+static std::mutex g_enqueue_mu;
+
 static int mul_dispatch(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int accumulate, int algo, int param,
                         hipStream_t s, bool sync_free) {
+  std::unique_lock<std::mutex> lk(g_enqueue_mu, std::defer_lock);
+  if (algo != GF2_ALGO_M4RM && !sync_free) lk.lock();  // host-path calls own a private (thread-local) stream
   switch (algo) {
     case GF2_ALGO_NAIVE:
       return mul_naive_dev(C, A, B, accumulate, s, sync_free);

@@ -1,0 +1,51 @@
+// kbench -- kernel micro-benchmark for the M4RM tile kernel variants (development tool, not shipped).
+//   kbench <n> <batch> <reps> <cfg> [<cfg> ...]
+// Runs each variant on `batch` independent n x n x n products of seeded random bits, checks every variant's
+// output bit for bit against cfg 0, prints avg kernel time (HIP events) and derived rates.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../m4ri-rust_amd/csrc/gf2_kernels.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+int main(int argc, char **argv) {
+  if (argc < 5) { fprintf(stderr, "usage: kbench n batch reps cfg...\n"); return 2; }
+  const int n = atoi(argv[1]), batch = atoi(argv[2]), reps = atoi(argv[3]);
+  const long long ld = n / 64, words = (long long)n * ld;
+  uint64_t *A, *B, *C, *Cref;
+  CK(hipMalloc(&A, words * 8 * batch)); CK(hipMalloc(&B, words * 8 * batch));
+  CK(hipMalloc(&C, words * 8 * batch)); CK(hipMalloc(&Cref, words * 8 * batch));
+  CK(gf2k_fill_random(A, ld, n * batch, n, 1, 0, 0));
+  CK(gf2k_fill_random(B, ld, n * batch, n, 2, 0, 0));
+  int *diff; CK(hipMalloc(&diff, 4));
+  gf2k_mul_args a{};
+  a.A = A; a.B = B; a.lda = a.ldb = a.ldc = ld; a.sA = a.sB = a.sC = words; a.m = a.l = a.n = n; a.batch = batch;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  a.C = Cref;
+  CK(gf2k_m4rm(a, 0, 0)); CK(hipDeviceSynchronize());
+  for (int i = 4; i < argc; ++i) {
+    const int cfg = atoi(argv[i]);
+    a.C = C;
+    CK(hipMemset(C, 0xff, words * 8 * batch));
+    CK(gf2k_m4rm(a, cfg, 0)); CK(hipDeviceSynchronize());
+    CK(hipMemset(diff, 0, 4));
+    CK(gf2k_diff(C, ld, Cref, ld, n * batch, n, diff, 0));
+    int h = -1; CK(hipMemcpy(&h, diff, 4, hipMemcpyDeviceToHost));
+    CK(hipEventRecord(e0, 0));
+    for (int r = 0; r < reps; ++r) CK(gf2k_m4rm(a, cfg, 0));
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+    const double macs = (double)n * n * n * batch;
+    printf("cfg %d  n=%d batch=%d  %s  %.3f ms  %.2f Tbitmac/s  lds-read %.1f TB/s\n", cfg, n, batch,
+           h == 0 ? "OK " : "MISMATCH", ms, macs / ms / 1e9, macs / 64 / ms / 1e9);
+    if (cfg == 9) {
+      unsigned long long d[8]; CK(gf2k_dbg_sec(d));
+      for (int w = 0; w < 2; ++w)
+        printf("   wave %s: per chunk: steps %.0f  loads %.0f  barrier %.0f cycles (%llu chunks)\n", w ? "last" : "0", (double)d[4*w]/d[4*w+3], (double)d[4*w+1]/d[4*w+3], (double)d[4*w+2]/d[4*w+3], d[4*w+3]);
+    }
+    fflush(stdout);
+  }
+  return 0;
+}
