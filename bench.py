@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--n", type=int, default=65536, help="matrix dimension (BASELINE metric: 65536)")
     ap.add_argument("--algo", default="auto", choices=["auto", "m4rm", "strassen"])
     ap.add_argument("--levels", type=int, default=0, help="Strassen levels (0 = automatic)")
-    ap.add_argument("--cpu-n", type=int, default=16384, help="dimension of the CPU-baseline sample product")
+    ap.add_argument("--cpu-n", type=int, default=32768, help="dimension of the CPU-baseline sample product")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--check", action="store_true", help="spot-check rows of C against the oracle after timing")
     args = ap.parse_args()

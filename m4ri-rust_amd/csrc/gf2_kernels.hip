@@ -291,7 +291,7 @@ constexpr int v3_wait_count(int st, int G, int STEPS, int wps) {
 
 __device__ unsigned long long gf2_dbg_sec[16];  // diagnostic builds only (DBG != 0): per-section cycle sums
 
-template <int WAVES, int RPW, int G, int DBG = 0>
+template <int WAVES, int RPW, int G, int DBG = 0, int PRIO = 0>
 __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v3(const gf2k_mul_args p) {
   unsigned long long sec[4] = {0, 0, 0, 0};
   auto stamp = [&]() __attribute__((always_inline)) -> unsigned long long {
@@ -310,6 +310,13 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v3(const gf2k_mul_
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if constexpr (PRIO == 1) {  // the later-dispatched half loses VALU arbitration to the older half: lift it
+    if (wave >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
+  } else if constexpr (PRIO == 2) {
+    if (wave < WAVES / 2) __builtin_amdgcn_s_setprio(1);
+  } else if constexpr (PRIO == 3) {
+    if (wave & 1) __builtin_amdgcn_s_setprio(1);
+  }
   int t;
   {
     const int nwg = gridDim.x, bid = blockIdx.x;
@@ -390,13 +397,17 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v3(const gf2k_mul_
     const u32 m0v = tbase + (u32)wave * (u32)(EPW * 256) - kOff;
     asm volatile("s_mov_b32 m0, %0" ::"s"(m0v) : "memory");
   };
-  auto build_entry = [&](auto itag, auto ttag, const u32 (&rr)[8]) __attribute__((always_inline)) {
+  auto build_write = [&cur32](auto itag, auto ttag) __attribute__((always_inline)) {  // entry i (Gray order) <- cur32
     constexpr int i = decltype(itag)::value;
     constexpr u32 tbase = decltype(ttag)::value;
     constexpr unsigned e = (unsigned)i ^ ((unsigned)i >> 1);
     constexpr u32 kOff = tbase ? (0x10004u - (u32)(EPW * 256)) : 0u;
-    if constexpr (i > 0) cur32 ^= rr[__builtin_ctz(i | 256)];
     asm volatile("ds_write_addtid_b32 %0 offset:%1" ::"v"(cur32), "n"(kOff + e * 256u) : "memory");
+  };
+  auto build_entry = [&](auto itag, auto ttag, const u32 (&rr)[8]) __attribute__((always_inline)) {
+    constexpr int i = decltype(itag)::value;
+    if constexpr (i > 0) cur32 ^= rr[__builtin_ctz(i | 256)];
+    build_write(itag, ttag);
   };
 
   // ---- prologue: rows of chunk 0 -> table 0, rows of chunk 1 -> rrB, A column 0 ----
@@ -442,18 +453,37 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v3(const gf2k_mul_
     for (int k = 0; k < G; ++k) issue(k, tv[k]);
     static_for<STEPS>([&](auto stag) __attribute__((always_inline)) {
       constexpr int st = decltype(stag)::value;
-      constexpr int N = v3_wait_count(st, G, STEPS, WPS);
-      asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(tv[st % G]) : "n"(N) : "memory");
-      acc[st][0] ^= tv[st % G].x;
-      acc[st][1] ^= tv[st % G].y;
-      acc[st][2] ^= tv[st % G].z;
-      acc[st][3] ^= tv[st % G].w;
-      // no reassociation across chunks (it would keep every table row read alive until the last one)
-      asm volatile("" : "+v"(acc[st][0]), "+v"(acc[st][1]), "+v"(acc[st][2]), "+v"(acc[st][3]));
-      if constexpr (st + G < STEPS) issue(st + G, tv[st % G]);
+      // one s_waitcnt per PAIR of steps (it covers the younger read of the pair): every instruction,
+      // waits included, costs a SIMD issue slot
+      if constexpr (st % 2 == 0 || st + 1 >= STEPS) {
+        constexpr int sw = (st % 2 == 0 && st + 1 < STEPS) ? st + 1 : st;
+        constexpr int N = v3_wait_count(sw, G, STEPS, WPS) - (sw - st) * (1 + WPS);
+        static_assert(N >= 0, "window too small for paired waits");
+        if constexpr (sw != st)
+          asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(tv[st % G]), "+v"(tv[sw % G]) : "n"(N) : "memory");
+        else
+          asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(tv[st % G]) : "n"(N) : "memory");
+      }
+      // the table-build XOR goes first: it is independent of the reads and fills the wait state hipcc
+      // otherwise pads with s_nop between an inline-asm result and its first VALU use
       static_for<WPS>([&](auto ktag) __attribute__((always_inline)) {
         constexpr int e = st * WPS + decltype(ktag)::value;
-        if constexpr (e < EPW) build_entry(std::integral_constant<int, e>{}, tnext{}, rows);
+        if constexpr (e < EPW && e > 0 && decltype(ktag)::value == 0) cur32 ^= rows[__builtin_ctz(e | 256)];
+      });
+      // XOR in place through asm: opaque to LLVM (no reassociation of the four chunks' XOR chains into a
+      // tree that keeps every table row alive) and pinned to the accumulator's own register
+      asm("v_xor_b32 %0, %1, %0" : "+v"(acc[st][0]) : "v"(tv[st % G].x));
+      asm("v_xor_b32 %0, %1, %0" : "+v"(acc[st][1]) : "v"(tv[st % G].y));
+      asm("v_xor_b32 %0, %1, %0" : "+v"(acc[st][2]) : "v"(tv[st % G].z));
+      asm("v_xor_b32 %0, %1, %0" : "+v"(acc[st][3]) : "v"(tv[st % G].w));
+      if constexpr (st + G < STEPS) issue(st + G, tv[st % G]);
+      static_for<WPS>([&](auto ktag) __attribute__((always_inline)) {
+        constexpr int k = decltype(ktag)::value;
+        constexpr int e = st * WPS + k;
+        if constexpr (e < EPW) {
+          if constexpr (k > 0 && e > 0) cur32 ^= rows[__builtin_ctz(e | 256)];
+          build_write(std::integral_constant<int, e>{}, tnext{});
+        }
       });
       if constexpr (st < 8) next[st] = loadBrow(fast, rsN, i + 2, st);
       if constexpr (C4 == 3) {  // aw[st] was consumed G steps ago: fetch the next column's word in place
@@ -854,9 +884,7 @@ extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {
   switch (cfg) {
     case 0: return launch_tile_kernel(&gf2_m4rm_kernel<8, 128>, 512, a, nwg, stream);
     case 1: return launch_tile_kernel(&gf2_m4rm_kernel<4, 64>, 256, a, nwg, stream);
-    case 6: return launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 6>, 512, a, nwg, stream);
     case 7: return launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4>, 512, a, nwg, stream);
-    case 8: return launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 7>, 512, a, nwg, stream);
     case 20: return launch_tile_kernel(&gf2_m4rm_kernel_v3<4, 64, 4>, 256, a, nwg, stream);
     case 9: return launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 6, 1>, 512, a, nwg, stream);  // section stamps
     default: return hipErrorInvalidValue;

@@ -307,7 +307,7 @@ static int env_int(const char *name, int dflt) {
 // dimensions from below (mzd_mul's cutoff argument, strassen.rs:8-18).
 static int pick_levels(int m, int l, int n, int req, int leaf_min) {
   static const int max_auto = env_int("M4RI_HIP_STRASSEN_MAX_LEVELS", 3);
-  static const double rate = (double)env_int("M4RI_HIP_M4RM_TBITMACS", 6000) * 1e12;  // kernel bit-MAC/s
+  static const double rate = (double)env_int("M4RI_HIP_M4RM_TBITMACS", 4200) * 1e12;  // kernel bit-MAC/s
   static const double bw = (double)env_int("M4RI_HIP_STREAM_GBS", 4500) * 1e9;        // streaming B/s
   const int cap = req > 0 ? (req > 6 ? 6 : req) : max_auto;
   int L = 0;
