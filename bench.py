@@ -71,7 +71,11 @@ def main():
     assert n % (64 * world) == 0
     rows = n // world
     ldw = n // 64
-    stream = torch.cuda.current_stream().cuda_stream
+    # all work (kernels and RCCL collectives) is issued under one explicit torch stream: torch orders its
+    # collectives against the current stream, and the library launches on the very same hipStream_t
+    comp = torch.cuda.Stream()
+    torch.cuda.set_stream(comp)
+    stream = comp.cuda_stream
 
     # resident operands (torch owns the memory; the library sees raw device pointers)
     A_t = torch.empty((rows, ldw), dtype=torch.int64, device="cuda")

@@ -134,11 +134,9 @@ struct TlsStream {
 };
 thread_local TlsStream tls_stream;
 
-int get_stream(void *user, hipStream_t *out) {
-  if (user) {
-    *out = static_cast<hipStream_t>(user);
-    return 0;
-  }
+// private per-thread stream of the host (mzd_t) entry points: concurrent calls from several host threads
+// (BinMatrix is Send + Sync) never serialise on, or race through, a shared stream
+int get_private_stream(hipStream_t *out) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   if (!tls_stream.s || tls_stream.dev != dev) {
@@ -146,6 +144,12 @@ int get_stream(void *user, hipStream_t *out) {
     tls_stream.dev = dev;
   }
   *out = tls_stream.s;
+  return 0;
+}
+
+// device-resident API: the caller's stream; NULL is the (legacy, synchronising) default stream
+int get_stream(void *user, hipStream_t *out) {
+  *out = static_cast<hipStream_t>(user);
   return 0;
 }
 
@@ -706,7 +710,7 @@ mzd_t *host_mul(mzd_t *C, const mzd_t *A, const mzd_t *B, int accumulate, int al
   if (!C) C = mzd_init(A->nrows, B->ncols);
   if (A->nrows == 0 || B->ncols == 0) return C;
   hipStream_t s;
-  if (get_stream(nullptr, &s)) {
+  if (get_private_stream(&s)) {
     if (allocated) mzd_free(C);
     return bail("stream");
   }
@@ -775,7 +779,7 @@ extern "C" mzd_t *_mzd_mul_naive(mzd_t *C, mzd_t const *A, mzd_t const *Bt, int 
   }
   if (A->nrows == 0 || Bt->nrows == 0) return C;
   hipStream_t s;
-  if (get_stream(nullptr, &s)) return nullptr;
+  if (get_private_stream(&s)) return nullptr;
   int rc;
   {
     DMatOwner dA, dB, dC;

@@ -25,7 +25,9 @@ def levels_used(m, l, n, algo, levels):
 
 
 def _hip_local_mul(a_block, b, c_block, ncols_inner, ncols_out, algo="auto", levels=0):
-    """Default local product: torch int64 CUDA tensors -> gf2_mul_dev on torch's current stream."""
+    """Default local product: torch int64 CUDA tensors -> gf2_mul_dev on torch's current stream (the stream
+    torch orders its collectives against; if that is the default stream the handle is NULL = legacy default
+    stream, which synchronises with every other stream)."""
     import torch
     device.require_gpu()
     stream = torch.cuda.current_stream().cuda_stream
