@@ -628,6 +628,79 @@ __global__ __launch_bounds__(256) void gf2_rowparity_kernel(const u64 *__restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// narrow product kernel: C (m x n) (+)= A (m x l) * B (l x n) with n <= 64 -- mzd_mul_naive as mul_slice calls
+// it (binary_matrix.rs:416-431: A * v^T with v an l x 1 column).  One launch: every block first transposes B
+// into LDS with wave ballots (word tw of B^T row j = ballot over the 64 lanes holding rows 64tw..64tw+63 of
+// bit j), then streams A exactly like the row-parity kernel with B^T read from LDS (broadcast reads).
+// ---------------------------------------------------------------------------------------------
+
+template <int WL>
+__global__ __launch_bounds__(256) void gf2_narrow_kernel(const u64 *__restrict__ A, long long lda,
+                                                         const u64 *__restrict__ B, long long ldb, u64 *__restrict__ C,
+                                                         long long ldc, int m, int l, int n, int accumulate) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  u64 *bt = reinterpret_cast<u64 *>(lds);  // n rows x wl words
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wl = (l + 63) >> 6;
+  for (int tw = wave; tw < wl; tw += 4) {
+    const int r = 64 * tw + lane;
+    const u64 v = (r < l) ? B[(long long)r * ldb] : 0;
+    for (int j = 0; j < n; ++j) {
+      const u64 mk = __ballot((v >> j) & 1);
+      if (lane == 0) bt[j * wl + tw] = mk;
+    }
+  }
+  __syncthreads();
+  const u64 maskL = (l & 63) ? ((1ull << (l & 63)) - 1) : ~0ull;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x) {
+    const u64 *ar = A + i * lda;
+    u64 out = 0;
+    if constexpr (WL > 0) {
+      u64 a[WL];
+      if constexpr (WL % 2 == 0) {
+#pragma unroll
+        for (int t = 0; t < WL; t += 2) {
+          if (t + 1 < wl) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(ar + t);
+            a[t] = (u64)v.x | ((u64)v.y << 32);
+            a[t + 1] = (u64)v.z | ((u64)v.w << 32);
+          } else {
+            a[t] = (t < wl) ? ar[t] : 0;
+            a[t + 1] = 0;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < WL; ++t) a[t] = (t < wl) ? ar[t] : 0;
+      }
+#pragma unroll
+      for (int t = 0; t < WL; ++t)
+        if (t == wl - 1) a[t] &= maskL;
+      for (int j = 0; j < n; ++j) {
+        u64 x = 0;
+#pragma unroll
+        for (int t = 0; t < WL; ++t)
+          if (t < wl) x ^= a[t] & bt[j * wl + t];
+        out |= (u64)(__popcll(x) & 1) << j;
+      }
+    } else {
+      for (int j = 0; j < n; ++j) {
+        u64 x = 0;
+        for (int t = 0; t < wl; ++t) {
+          u64 v = ar[t] & bt[j * wl + t];
+          if (t == wl - 1) v &= maskL;
+          x ^= v;
+        }
+        out |= (u64)(__popcll(x) & 1) << j;
+      }
+    }
+    u64 *dst = C + i * ldc;
+    if (accumulate) out ^= *dst;
+    *dst = out;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // v*A kernel: C (m x n) (+)= A (m x l) * B (l x n) for a handful of rows m <= 8 (_mzd_mul_va,
 // mzd.rs:175-181 and `&v * &A`, binary_matrix.rs:552-563).  Streams B once; the inner dimension
 // is split over blockIdx.y and partial sums are combined with 64-bit atomic XOR.
@@ -911,6 +984,30 @@ extern "C" hipError_t gf2k_rowparity(const u64 *A, long long lda, const u64 *Bt,
     hipLaunchKernelGGL((gf2_rowparity_kernel<8>), grid, block, 0, stream, A, lda, Bt, ldbt, C, ldc, m, l, n, accumulate);
   else
     hipLaunchKernelGGL((gf2_rowparity_kernel<0>), grid, block, 0, stream, A, lda, Bt, ldbt, C, ldc, m, l, n, accumulate);
+  return hipGetLastError();
+}
+
+// n <= 64 and n * ceil(l/64) * 8 <= 64 KiB of LDS; returns hipErrorInvalidValue otherwise (caller takes the two-kernel path)
+extern "C" hipError_t gf2k_narrow(const u64 *A, long long lda, const u64 *B, long long ldb, u64 *C, long long ldc, int m,
+                                  int l, int n, int accumulate, hipStream_t stream) {
+  if (m <= 0 || n <= 0) return hipSuccess;
+  const int wl = (l + 63) >> 6;
+  const size_t lds = (size_t)n * wl * 8;
+  if (n > 64 || lds > 65536 || l <= 0) return hipErrorInvalidValue;
+  long long blocks = ((long long)m + 255) / 256;
+  if (blocks > 2048) blocks = 2048;  // grid-stride: every block pays the B transpose once
+  dim3 grid((unsigned)blocks), block(256);
+  const bool vec_ok = (lda % 2 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+  if (wl <= 1)
+    hipLaunchKernelGGL((gf2_narrow_kernel<1>), grid, block, lds, stream, A, lda, B, ldb, C, ldc, m, l, n, accumulate);
+  else if (wl <= 2 && vec_ok)
+    hipLaunchKernelGGL((gf2_narrow_kernel<2>), grid, block, lds, stream, A, lda, B, ldb, C, ldc, m, l, n, accumulate);
+  else if (wl <= 4 && vec_ok)
+    hipLaunchKernelGGL((gf2_narrow_kernel<4>), grid, block, lds, stream, A, lda, B, ldb, C, ldc, m, l, n, accumulate);
+  else if (wl <= 8 && vec_ok)
+    hipLaunchKernelGGL((gf2_narrow_kernel<8>), grid, block, lds, stream, A, lda, B, ldb, C, ldc, m, l, n, accumulate);
+  else
+    hipLaunchKernelGGL((gf2_narrow_kernel<0>), grid, block, lds, stream, A, lda, B, ldb, C, ldc, m, l, n, accumulate);
   return hipGetLastError();
 }
 

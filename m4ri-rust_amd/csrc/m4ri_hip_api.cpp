@@ -460,6 +460,12 @@ static int mul_naive_dev(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int 
   const int m = A->nrows, l = A->ncols, n = B->ncols;
   if (n > 64 || l == 0) return mul_m4rm_plain(C, A, B, accumulate, s);
   if (m == 0 || n == 0) return 0;
+  if ((size_t)n * words_of(l) * 8 <= 65536) {  // one launch: B is transposed into LDS by every block
+    hipError_t e1 = gf2k_narrow(A->data, A->ld, B->data, B->ld, C->data, C->ld, m, l, n, accumulate, s);
+    if (e1 != hipSuccess) return fail(e1, "gf2k_narrow");
+    if (sync_free && hipStreamSynchronize(s) != hipSuccess) return fail(hipGetLastError(), "hipStreamSynchronize");
+    return 0;
+  }
   const long long ldbt = (words_of(l) + 1) & ~1ll;
   const size_t bytes = (size_t)n * ldbt * sizeof(u64);
   void *bt = nullptr;

@@ -37,7 +37,10 @@ class DMat:
 
     def __del__(self):
         if getattr(self, "_owned", False) and self.s.data:
-            _lib.lib().gf2_dmat_free(ctypes.byref(self.s))
+            try:
+                _lib.lib().gf2_dmat_free(ctypes.byref(self.s))
+            except Exception:  # interpreter shutdown: module globals may already be gone
+                pass
 
     nrows = property(lambda self: self.s.nrows)
     ncols = property(lambda self: self.s.ncols)
