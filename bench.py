@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--levels", type=int, default=0, help="Strassen levels (0 = automatic)")
     ap.add_argument("--cpu-n", type=int, default=32768, help="dimension of the CPU-baseline sample product")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--panels", type=int, default=4, help="column panels of B per step when N > 1 (RCCL/compute overlap)")
     ap.add_argument("--check", action="store_true", help="spot-check rows of C against the oracle after timing")
     args = ap.parse_args()
 
@@ -77,24 +78,37 @@ def main():
     torch.cuda.set_stream(comp)
     stream = comp.cuda_stream
 
-    # resident operands (torch owns the memory; the library sees raw device pointers)
+    # resident operands (torch owns the memory; the library sees raw device pointers).
+    # synthetic data: seeded splitmix64 bits (same stream as the oracle generator); rank r holds rows
+    # [r*rows, (r+1)*rows) of the global A (seed 1), B has seed 2.
     A_t = torch.empty((rows, ldw), dtype=torch.int64, device="cuda")
-    B_t = torch.empty((n, ldw), dtype=torch.int64, device="cuda")
-    C_t = torch.empty((rows, ldw), dtype=torch.int64, device="cuda")
     A = device.DMat.from_torch(A_t, n)
-    B = device.DMat.from_torch(B_t, n)
-    C = device.DMat.from_torch(C_t, n)
-    # synthetic data: seeded splitmix64 bits (same stream as the oracle generator); rank r holds
-    # rows [r*rows, (r+1)*rows) of the global A (seed 1), B has seed 2
     sharded.fill_row_block(A, seed=1, row0=rank * rows, stream=stream)
-    if rank == 0:
+    P = max(1, args.panels) if world > 1 else 1
+    assert ldw % (2 * P) == 0
+    wp, ncp = ldw // P, n // P
+    if world == 1:
+        B_t = torch.empty((n, ldw), dtype=torch.int64, device="cuda")
+        C_t = torch.empty((rows, ldw), dtype=torch.int64, device="cuda")
+        B = device.DMat.from_torch(B_t, n)
+        C = device.DMat.from_torch(C_t, n)
         B.fill_random(2, stream)
-    Cfull_t = torch.empty((n, ldw), dtype=torch.int64, device="cuda") if (rank == 0 and world > 1) else None
+    else:
+        # B and C are kept as P column panels ("tiles"), each contiguous, so that a panel can be broadcast /
+        # gathered by RCCL while the previous one is being multiplied
+        Bp_t = [torch.empty((n, wp), dtype=torch.int64, device="cuda") for _ in range(P)]
+        Cp_t = [torch.empty((rows, wp), dtype=torch.int64, device="cuda") for _ in range(P)]
+        Bp = [device.DMat.from_torch(t, ncp) for t in Bp_t]
+        Cp = [device.DMat.from_torch(t, ncp) for t in Cp_t]
+        Cfull_t = [torch.empty((n, wp), dtype=torch.int64, device="cuda") for _ in range(P)] if rank == 0 else None
+        if rank == 0:
+            for pnl in range(P):
+                sharded.fill_block(Bp[pnl], 2, 0, pnl * wp, n, stream)
     torch.cuda.synchronize()
 
     def step():
         if world > 1:
-            sharded.step(A_t, B_t, C_t, Cfull_t, A, B, C, algo=args.algo, levels=args.levels, stream=stream)
+            sharded.step_pipelined(A, Bp_t, Cp_t, Cfull_t, Bp, Cp, algo=args.algo, levels=args.levels, stream=stream)
         else:
             device.mul(A, B, C=C, algo=args.algo, param=args.levels, stream=stream)
 
@@ -132,8 +146,9 @@ def main():
 
     # dominant kernel: the (batched) M4RM tile kernel. Algorithmic bytes of ONE launch = what that
     # launch's products read and write once: batch * (m*l + l*n + m*n)/8 with the leaf dims.
-    levels = sharded.levels_used(rows, n, n, args.algo, args.levels)
-    mi, li, ni, batch = rows >> levels, n >> levels, n >> levels, 7 ** levels
+    ncols_launch = n // P  # columns of B one launch sees (a column panel when N > 1)
+    levels = sharded.levels_used(rows, n, ncols_launch, args.algo, args.levels)
+    mi, li, ni, batch = rows >> levels, n >> levels, ncols_launch >> levels, 7 ** levels
     alg_bytes_launch = batch * (mi * li + li * ni + mi * ni) / 8.0
     avg_kernel_ms = kernel_ms / max(launches, 1)
     achieved = alg_bytes_launch / (avg_kernel_ms * 1e-3) / 1e9 if launches else 0.0
@@ -167,7 +182,8 @@ def main():
                 n, n, n, "Strassen(%d levels)-over-M4RM" % levels if levels else "M4RM only"),
             "n": n, "algo": args.algo, "strassen_levels": levels,
             "parallelism": "row-block shard of A over %d GPU(s)%s" % (
-                world, ", RCCL broadcast(B) + gather(C) per step" if world > 1 else ""),
+                world, ", B in %d column panels: RCCL broadcast(panel p+1) / gather(C panel p-1) overlap the product of panel p" % P
+                if world > 1 else ""),
         },
         "roofline": {
             "bound": "hbm",

@@ -140,6 +140,8 @@ int gf2_dmat_download(mzd_t *dst, gf2_dmat const *src, void *stream); /* device 
 int gf2_dmat_fill_random(gf2_dmat *M, uint64_t seed, void *stream);   /* splitmix64 stream, same as the oracle */
 /* same stream, but M holds rows [row0, row0 + M->nrows) of the full matrix (row-block shards) */
 int gf2_dmat_fill_random_rows(gf2_dmat *M, uint64_t seed, int64_t row0, void *stream);
+/* general block: rows [row0, ..) x words [col_word0, ..) of a seeded matrix with full_ncols columns (column-panel shards) */
+int gf2_dmat_fill_random_block(gf2_dmat *M, uint64_t seed, int64_t row0, int64_t col_word0, int full_ncols, void *stream);
 
 /* C (+)= A*B on `stream` (hipStream_t, NULL = default stream); asynchronous.
  * algo: GF2_ALGO_*; param: Strassen levels when algo==STRASSEN (0 = automatic), else ignored. */

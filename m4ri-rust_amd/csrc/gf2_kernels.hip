@@ -765,15 +765,16 @@ __global__ __launch_bounds__(256) void gf2_xor2d_kernel(u64 *__restrict__ C, lon
 
 // splitmix64 counter stream, identical to oracle_fill_random (test/bench input generator;
 // stands in for mzd_randomize, mzd.rs:183-184)
+// M holds rows [row0, row0+rows) x words [colw0, colw0 + ceil(cols/64)) of a seeded matrix that is `fullw` words wide
 __global__ __launch_bounds__(256) void gf2_fill_random_kernel(u64 *M, long long ld, int rows, int cols, u64 seed,
-                                                              long long row0) {
+                                                              long long row0, long long fullw, long long colw0) {
   const int w = (cols + 63) >> 6;
   const u64 tm = (cols & 63) ? ((1ull << (cols & 63)) - 1) : ~0ull;
   const long long total = (long long)rows * w;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
     const int r = (int)(idx / w), j = (int)(idx % w);
-    u64 z = seed + ((u64)(idx + row0 * w) + 1) * 0x9E3779B97F4A7C15ull;
+    u64 z = seed + ((u64)((row0 + r) * fullw + colw0 + j) + 1) * 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     z = z ^ (z >> 31);
@@ -1038,11 +1039,12 @@ extern "C" hipError_t gf2k_xor2d(u64 *C, long long ldc, const u64 *A, long long 
   return hipGetLastError();
 }
 
-extern "C" hipError_t gf2k_fill_random(u64 *M, long long ld, int rows, int cols, u64 seed, long long row0,
-                                       hipStream_t stream) {
+extern "C" hipError_t gf2k_fill_random(u64 *M, long long ld, int rows, int cols, u64 seed, long long row0, long long fullw,
+                                       long long colw0, hipStream_t stream) {
+  if (fullw <= 0) fullw = (cols + 63) / 64;
   if (rows <= 0 || cols <= 0) return hipSuccess;
   const long long total = (long long)rows * ((cols + 63) / 64);
-  hipLaunchKernelGGL(gf2_fill_random_kernel, dim3(grid_for(total)), dim3(256), 0, stream, M, ld, rows, cols, seed, row0);
+  hipLaunchKernelGGL(gf2_fill_random_kernel, dim3(grid_for(total)), dim3(256), 0, stream, M, ld, rows, cols, seed, row0, fullw, colw0);
   return hipGetLastError();
 }
 

@@ -611,12 +611,18 @@ extern "C" void gf2_dmat_free(gf2_dmat *M) {
   M->data = nullptr;
 }
 
-extern "C" int gf2_dmat_fill_random_rows(gf2_dmat *M, uint64_t seed, int64_t row0, void *stream) {
+extern "C" int gf2_dmat_fill_random_block(gf2_dmat *M, uint64_t seed, int64_t row0, int64_t col_word0, int full_ncols,
+                                          void *stream) {
   if (int rc = require_device()) return rc;
   hipStream_t s;
   if (int rc = get_stream(stream, &s)) return rc;
-  HIP_TRY(gf2k_fill_random(M->data, M->ld, M->nrows, M->ncols, seed, row0, s));
+  HIP_TRY(gf2k_fill_random(M->data, M->ld, M->nrows, M->ncols, seed, row0, full_ncols > 0 ? words_of(full_ncols) : 0,
+                           col_word0, s));
   return 0;
+}
+
+extern "C" int gf2_dmat_fill_random_rows(gf2_dmat *M, uint64_t seed, int64_t row0, void *stream) {
+  return gf2_dmat_fill_random_block(M, seed, row0, 0, 0, stream);
 }
 
 extern "C" int gf2_dmat_fill_random(gf2_dmat *M, uint64_t seed, void *stream) {

@@ -61,6 +61,59 @@ def mul_row_sharded(a_block, b, c_block, c_full, ncols_inner, ncols_out, local_m
         c_full.copy_(c_block)
 
 
+def fill_block(M, seed, row0, col_word0, full_ncols, stream=None):
+    """Rows [row0, ..) x 64-bit words [col_word0, ..) of the seeded global matrix with `full_ncols` columns."""
+    _lib.check(_lib.lib().gf2_dmat_fill_random_block(ctypes.byref(M.s), seed, row0, col_word0, full_ncols, stream),
+               "gf2_dmat_fill_random_block")
+
+
+def mul_row_sharded_pipelined(a_block, b_panels, c_panels, c_full_panels, ncols_inner, ncols_panel, local_mul=None,
+                              group=None, **kw):
+    """Row-sharded product with B moved in column panels ("tiles"): panel p+1 is on the wire while panel p is being
+    multiplied, and the gather of C panel p overlaps the product of panel p+1.
+
+    b_panels[p]      : (l, ceil(ncols_panel/64)) int64, contiguous; columns [p*ncols_panel, (p+1)*ncols_panel) of B
+                       (significant on rank 0, overwritten elsewhere)
+    c_panels[p]      : (rows_local, ceil(ncols_panel/64)) int64, this rank's rows of C panel p
+    c_full_panels[p] : on rank 0 (rows_total, ceil(ncols_panel/64)) receiving C panel p, None elsewhere
+    """
+    import torch.distributed as dist
+    local_mul = local_mul or _hip_local_mul
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    P = len(b_panels)
+    if world == 1:
+        for p in range(P):
+            local_mul(a_block, b_panels[p], c_panels[p], ncols_inner, ncols_panel, **kw)
+            if c_full_panels is not None:
+                c_full_panels[p].copy_(c_panels[p])
+        return
+    bcasts = [dist.broadcast(b_panels[p], src=0, group=group, async_op=True) for p in range(P)]
+    gathers = []
+    for p in range(P):
+        bcasts[p].wait()  # orders the consumer (current stream on GPUs) behind the arrival of panel p
+        local_mul(a_block, b_panels[p], c_panels[p], ncols_inner, ncols_panel, **kw)
+        glist = list(c_full_panels[p].chunk(world, dim=0)) if rank == 0 else None
+        gathers.append(dist.gather(c_panels[p], gather_list=glist, dst=0, group=group, async_op=True))
+    for w in gathers:
+        w.wait()
+
+
+def step_pipelined(A, Bp_t, Cp_t, Cfull_t, Bp, Cp, algo="auto", levels=0, stream=None):
+    """bench.py's timed step for N > 1 ranks, B in column panels (DMat wrappers pre-built)."""
+    import torch.distributed as dist
+    world, rank, P = dist.get_world_size(), dist.get_rank(), len(Bp_t)
+    bcasts = [dist.broadcast(Bp_t[p], src=0, async_op=True) for p in range(P)]
+    gathers = []
+    for p in range(P):
+        bcasts[p].wait()
+        device.mul(A, Bp[p], C=Cp[p], algo=algo, param=levels, stream=stream)
+        glist = list(Cfull_t[p].chunk(world, dim=0)) if rank == 0 else None
+        gathers.append(dist.gather(Cp_t[p], gather_list=glist, dst=0, async_op=True))
+    for w in gathers:
+        w.wait()
+
+
 def step(A_t, B_t, C_t, Cfull_t, A, B, C, algo="auto", levels=0, stream=None):
     """bench.py's timed step for N > 1 ranks (DMat wrappers are pre-built to keep Python overhead out)."""
     import torch.distributed as dist

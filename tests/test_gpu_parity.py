@@ -100,6 +100,18 @@ def test_device_random_matches_oracle(dev):
         assert np.array_equal(dev.DMat.random(r, c, 99).to_words(), g.random_words(r, c, 99))
 
 
+def test_device_random_blocks_match_full_matrix(dev):
+    """Row-block and column-panel shards of the seeded matrix (multi-GPU layout) equal slices of the full one."""
+    from m4ri_rust_amd import sharded
+    full = g.random_words(200, 512, 77)
+    blk = dev.DMat(64, 512)
+    sharded.fill_row_block(blk, 77, 100)
+    assert np.array_equal(blk.to_words(), full[100:164])
+    pan = dev.DMat(200, 128)
+    sharded.fill_block(pan, 77, 0, 4, 512)
+    assert np.array_equal(pan.to_words(), full[:, 4:6])
+
+
 # ---- random shapes against the oracle -------------------------------------------------------------
 
 SHAPES = [(1, 1, 1), (3, 5, 7), (64, 64, 64), (65, 65, 65), (127, 129, 63), (1, 300, 500), (9, 300, 500),

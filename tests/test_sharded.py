@@ -55,6 +55,50 @@ def _worker(rank, world, port, m, l, n, out_path):
     dist.destroy_process_group()
 
 
+def _worker_panels(rank, world, port, m, l, n, P, out_path):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    import gf2util as gg
+    import m4ri_rust_amd  # noqa: F401
+    from m4ri_rust_amd import sharded
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rows, wp, ncp = m // world, gg.width(n) // P, n // P
+    a_block = torch.from_numpy(gg.random_words(m, l, 1)[rank * rows:(rank + 1) * rows].copy().view(np.int64))
+    b_full = gg.random_words(l, n, 2)
+    b_panels = [torch.from_numpy(b_full[:, p * wp:(p + 1) * wp].copy().view(np.int64)) if rank == 0
+                else torch.zeros((l, wp), dtype=torch.int64) for p in range(P)]
+    c_panels = [torch.zeros((rows, wp), dtype=torch.int64) for _ in range(P)]
+    c_full = [torch.zeros((m, wp), dtype=torch.int64) for _ in range(P)] if rank == 0 else None
+
+    def oracle_local_mul(a_t, b_t, c_t, ncols_inner, ncols_out, **_kw):
+        a = np.ascontiguousarray(a_t.numpy().view(np.uint64))
+        bb = np.ascontiguousarray(b_t.numpy().view(np.uint64))
+        c_t.copy_(torch.from_numpy(gg.o_mul_m4rm(a, bb, a.shape[0], ncols_inner, ncols_out).view(np.int64)))
+
+    for _ in range(2):  # two steps back to back: panels are re-broadcast into the same buffers
+        sharded.mul_row_sharded_pipelined(a_block, b_panels, c_panels, c_full, l, ncp, local_mul=oracle_local_mul)
+    if rank == 0:
+        np.save(out_path, np.concatenate([t.numpy().view(np.uint64) for t in c_full], axis=1))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pipelined_column_panels_world2_gloo(tmp_path, built):
+    """B moved in column panels with asynchronous broadcast / gather (the N > 1 step of bench.py)."""
+    import torch.multiprocessing as mp
+    m, l, n, P = 128, 192, 256, 2
+    out = str(tmp_path / "c.npy")
+    mp.spawn(_worker_panels, args=(2, _free_port(), m, l, n, P, out), nprocs=2, join=True)
+    ref = g.o_mul_m4rm(g.random_words(m, l, 1), g.random_words(l, n, 2), m, l, n)
+    assert np.array_equal(np.load(out), ref)
+
+
 @pytest.mark.parametrize("shape", [(128, 200, 130), (64, 64, 64)], ids=lambda s: "x".join(map(str, s)))
 def test_row_sharded_product_world2_gloo(tmp_path, shape, built):
     import torch.multiprocessing as mp

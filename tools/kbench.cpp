@@ -17,8 +17,8 @@ int main(int argc, char **argv) {
   uint64_t *A, *B, *C, *Cref;
   CK(hipMalloc(&A, words * 8 * batch)); CK(hipMalloc(&B, words * 8 * batch));
   CK(hipMalloc(&C, words * 8 * batch)); CK(hipMalloc(&Cref, words * 8 * batch));
-  CK(gf2k_fill_random(A, ld, n * batch, n, 1, 0, 0));
-  CK(gf2k_fill_random(B, ld, n * batch, n, 2, 0, 0));
+  CK(gf2k_fill_random(A, ld, n * batch, n, 1, 0, 0, 0, 0));
+  CK(gf2k_fill_random(B, ld, n * batch, n, 2, 0, 0, 0, 0));
   int *diff; CK(hipMalloc(&diff, 4));
   gf2k_mul_args a{};
   a.A = A; a.B = B; a.lda = a.ldb = a.ldc = ld; a.sA = a.sB = a.sC = words; a.m = a.l = a.n = n; a.batch = batch;
