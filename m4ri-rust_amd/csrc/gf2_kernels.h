@@ -12,6 +12,8 @@ struct gf2k_mul_args {
   long long sA, sB, sC;     // batch strides
   int m, l, n;              // bits
   int tiles_m, tiles_n;     // filled in by the launcher
+  int ksplit;               // slices of the inner dimension (<= 1: none); combined with atomic XOR
+  int kwords;               // 32-bit words of the inner dimension per slice (filled in by the launcher)
   int batch;
   int accumulate;  // 0: C = A*B, 1: C ^= A*B
 };
@@ -36,6 +38,10 @@ hipError_t gf2k_transpose(uint64_t *D, long long ldd, const uint64_t *S, long lo
                           hipStream_t stream);
 hipError_t gf2k_strassen_split(uint64_t *dst, long long ldd, long long dstStride, const uint64_t *src, long long lds_,
                                long long srcStride, int h, int w, int side, int batch, hipStream_t stream);
+hipError_t gf2k_strassen_split2(uint64_t *dst, long long ldd, long long dstStride, const uint64_t *src, long long lds_,
+                                long long srcStride, int h, int w, int side, int batch, hipStream_t stream);
+hipError_t gf2k_strassen_merge2(uint64_t *dst, long long ldd, long long dstStride, const uint64_t *src, long long lds_,
+                                long long srcStride, int h, int w, int accumulate, int batch, hipStream_t stream);
 hipError_t gf2k_strassen_merge(uint64_t *dst, long long ldd, long long dstStride, const uint64_t *src, long long lds_,
                                long long srcStride, int h, int w, int accumulate, int batch, hipStream_t stream);
 }

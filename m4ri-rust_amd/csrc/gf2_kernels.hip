@@ -325,6 +325,8 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v3(const gf2k_mul_
   }
   const int tm = t % p.tiles_m;
   t /= p.tiles_m;
+  const int ks = t % p.ksplit;  // slice of the inner dimension (split-K): fills the chip when tiles are few
+  t /= p.ksplit;
   const int tn = t % p.tiles_n;
   const int bt = t / p.tiles_n;
   const u64 *__restrict__ A = p.A + (long long)bt * p.sA;
@@ -335,7 +337,9 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v3(const gf2k_mul_
   const int widthA = (p.l + 63) >> 6, widthB = (p.n + 63) >> 6;
   const u64 maskC = (p.n & 63) ? ((1ull << (p.n & 63)) - 1) : ~0ull;
   const int nw32 = (p.l + 31) >> 5;
-  const int nchunks = nw32 * 4;
+  const int jbeg = ks * p.kwords;                   // first 32-bit word of this slice
+  const int jend = min(nw32, jbeg + p.kwords);      // one past its last
+  const int ibeg = jbeg * 4, nchunks = jend * 4;    // chunk range [ibeg, nchunks)
   (void)widthA;
 
   const int g = lane >> 4, qd = lane & 15;
@@ -413,15 +417,15 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v3(const gf2k_mul_
   // ---- prologue: rows of chunk 0 -> table 0, rows of chunk 1 -> rrB, A column 0 ----
   u32 rrA[8], rrB[8];
   {
-    const __amdgpu_buffer_rsrc_t rs0 = rsrcB_for(0), rs1 = rsrcB_for(1);
+    const __amdgpu_buffer_rsrc_t rs0 = rsrcB_for(ibeg), rs1 = rsrcB_for(ibeg + 1);
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
-      rrA[b] = loadBrow(std::false_type{}, rs0, 0, b);
-      rrB[b] = loadBrow(std::false_type{}, rs1, 1, b);
+      rrA[b] = loadBrow(std::false_type{}, rs0, ibeg, b);
+      rrB[b] = loadBrow(std::false_type{}, rs1, ibeg + 1, b);
     }
   }
-  loadA_all(0);
-  if (nw32 == 1) {
+  loadA_all(jbeg);
+  if (jbeg == nw32 - 1) {
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) aw[s] &= tailA;
   }
@@ -512,9 +516,9 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v3(const gf2k_mul_
 
   // two separate loops (not one loop with a branch): the register allocator otherwise spills the
   // accumulators around the merge point
-  int i = 0;
+  int i = ibeg;
 #pragma unroll 1
-  for (; (i + 6) * 8 <= p.l; i += 4) {  // chunks i+2 .. i+5 lie wholly inside the inner dimension
+  for (; i < nchunks && (i + 6) * 8 <= p.l; i += 4) {  // chunks i+2 .. i+5 lie wholly inside the inner dimension
     chunk_iter(i + 0, std::integral_constant<int, 0>{}, std::true_type{}, rrB, rrA);
     chunk_iter(i + 1, std::integral_constant<int, 1>{}, std::true_type{}, rrA, rrB);
     chunk_iter(i + 2, std::integral_constant<int, 2>{}, std::true_type{}, rrB, rrA);
@@ -547,7 +551,10 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v3(const gf2k_mul_
       u64 v1 = (u64)acc[s][2] | ((u64)acc[s][3] << 32);
       if (wc == widthB - 1) v0 &= maskC;
       if (wc + 1 == widthB - 1) v1 &= maskC;
-      if (wc + 1 < widthB) {
+      if (p.ksplit > 1) {  // partial sums of the slices meet in C (zeroed by the launcher unless accumulating)
+        if (v0) atomicXor(reinterpret_cast<unsigned long long *>(dst), (unsigned long long)v0);
+        if (wc + 1 < widthB && v1) atomicXor(reinterpret_cast<unsigned long long *>(dst + 1), (unsigned long long)v1);
+      } else if (wc + 1 < widthB) {
         if (p.accumulate) {
           const uint4 old = *reinterpret_cast<const uint4 *>(dst);
           v0 ^= (u64)old.x | ((u64)old.y << 32);
@@ -921,6 +928,118 @@ __global__ __launch_bounds__(256) void gf2_strassen_merge_kernel(u64 *__restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// Two Strassen levels in one pass.  A source operand is cut into 4 x 4 sub-blocks S[r][c]; the 49 operands of
+// the level below the next are out[7*q1 + q2] = combo_q2(combo_q1(S)).  Each source word is read once and each
+// destination word written once: 16 + 49 block units of traffic instead of (4 + 7) + 7*(4 + 7)/4 * ... two passes
+// (121 units in the same unit).  The merge is the mirror image: 49 products -> 16 sub-blocks of the parent.
+// ---------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ void strassen_combo(const uint4 (&x)[4], uint4 (&o)[7], int side) {
+  // x = {X11, X12, X21, X22}; same combinations as gf2_strassen_split_kernel
+  if (side == 0) {
+    o[0] = xor4(x[0], x[3]);
+    o[1] = xor4(x[2], x[3]);
+    o[2] = x[0];
+    o[3] = x[3];
+    o[4] = xor4(x[0], x[1]);
+    o[5] = xor4(x[2], x[0]);
+    o[6] = xor4(x[1], x[3]);
+  } else {
+    o[0] = xor4(x[0], x[3]);
+    o[1] = x[0];
+    o[2] = xor4(x[1], x[3]);
+    o[3] = xor4(x[2], x[0]);
+    o[4] = x[3];
+    o[5] = xor4(x[0], x[1]);
+    o[6] = xor4(x[2], x[3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void gf2_strassen_split2_kernel(u64 *__restrict__ dst, long long ldd, long long dstStride,
+                                                                  const u64 *__restrict__ src, long long lds_,
+                                                                  long long srcStride, int h, int w, int side) {
+  // h, w: rows / words of one OUTPUT operand (a quarter of the source in each dimension)
+  const int b = blockIdx.z;
+  const u64 *X = src + (long long)b * srcStride;
+  u64 *Y = dst + (long long)b * 49 * dstStride;
+  const int pairs = w >> 1;
+  const long long total = (long long)h * pairs;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(idx / pairs), c = (int)(idx % pairs) * 2;
+    // level-1 combination applied to each of the four inner positions (ir, ic)
+    uint4 l1[4][7];
+#pragma unroll
+    for (int ip = 0; ip < 4; ++ip) {
+      const int ir = ip >> 1, ic = ip & 1;
+      uint4 x[4];
+#pragma unroll
+      for (int op = 0; op < 4; ++op) {
+        const int orow = op >> 1, ocol = op & 1;
+        x[op] = *reinterpret_cast<const uint4 *>(X + (long long)(r + (2 * orow + ir) * h) * lds_ + (2 * ocol + ic) * w + c);
+      }
+      strassen_combo(x, l1[ip], side);
+    }
+#pragma unroll
+    for (int q1 = 0; q1 < 7; ++q1) {
+      const uint4 x[4] = {l1[0][q1], l1[1][q1], l1[2][q1], l1[3][q1]};
+      uint4 o[7];
+      strassen_combo(x, o, side);
+#pragma unroll
+      for (int q2 = 0; q2 < 7; ++q2)
+        *reinterpret_cast<uint4 *>(Y + (long long)(7 * q1 + q2) * dstStride + (long long)r * ldd + c) = o[q2];
+    }
+  }
+}
+
+__device__ __forceinline__ void strassen_fold(const uint4 (&m)[7], uint4 (&c)[4]) {
+  // c = {C11, C12, C21, C22}
+  c[0] = xor4(xor4(m[0], m[3]), xor4(m[4], m[6]));
+  c[1] = xor4(m[2], m[4]);
+  c[2] = xor4(m[1], m[3]);
+  c[3] = xor4(xor4(m[0], m[1]), xor4(m[2], m[5]));
+}
+
+__global__ __launch_bounds__(256) void gf2_strassen_merge2_kernel(u64 *__restrict__ dst, long long ldd, long long dstStride,
+                                                                  const u64 *__restrict__ src, long long lds_,
+                                                                  long long srcStride, int h, int w, int accumulate) {
+  // h, w: rows / words of one INPUT product (a quarter of the destination in each dimension)
+  const int b = blockIdx.z;
+  const u64 *M = src + (long long)b * 49 * srcStride;
+  u64 *Cq = dst + (long long)b * dstStride;
+  const int pairs = w >> 1;
+  const long long total = (long long)h * pairs;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(idx / pairs), c = (int)(idx % pairs) * 2;
+    uint4 inner[7][4];  // inner[q1] = the four quadrants of level-1 product q1
+#pragma unroll
+    for (int q1 = 0; q1 < 7; ++q1) {
+      uint4 m[7];
+#pragma unroll
+      for (int q2 = 0; q2 < 7; ++q2)
+        m[q2] = *reinterpret_cast<const uint4 *>(M + (long long)(7 * q1 + q2) * srcStride + (long long)r * lds_ + c);
+      strassen_fold(m, inner[q1]);
+    }
+#pragma unroll
+    for (int ip = 0; ip < 4; ++ip) {
+      const int ir = ip >> 1, ic = ip & 1;
+      const uint4 m[7] = {inner[0][ip], inner[1][ip], inner[2][ip], inner[3][ip], inner[4][ip], inner[5][ip], inner[6][ip]};
+      uint4 o[4];
+      strassen_fold(m, o);
+#pragma unroll
+      for (int op = 0; op < 4; ++op) {
+        const int orow = op >> 1, ocol = op & 1;
+        uint4 *pd = reinterpret_cast<uint4 *>(Cq + (long long)(r + (2 * orow + ir) * h) * ldd + (2 * ocol + ic) * w + c);
+        uint4 v = o[op];
+        if (accumulate) v = xor4(v, *pd);
+        *pd = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers (internal C ABI used by m4ri_hip_api.cpp)
 // ---------------------------------------------------------------------------------------------
 
@@ -953,7 +1072,18 @@ extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {
   const int R = gf2k_m4rm_rows_per_tile(cfg);
   a.tiles_m = (a.m + R - 1) / R;
   a.tiles_n = (a.n + 2047) / 2048;
-  const long long nwg = (long long)a.tiles_m * a.tiles_n * a.batch;
+  const int nw32 = (a.l + 31) / 32;
+  if (cfg == 0 || cfg == 1 || a.ksplit < 1) a.ksplit = 1;  // first-generation kernels have no split-K
+  if (a.ksplit > nw32) a.ksplit = nw32 > 0 ? nw32 : 1;
+  a.kwords = (nw32 + a.ksplit - 1) / a.ksplit;
+  a.ksplit = a.kwords > 0 ? (nw32 + a.kwords - 1) / a.kwords : 1;  // no empty slices
+  if (a.ksplit > 1 && !a.accumulate) {  // slices are combined with atomic XOR: start from zero
+    for (int b = 0; b < a.batch; ++b) {
+      hipError_t e = gf2k_xor2d(a.C + (long long)b * a.sC, a.ldc, nullptr, 0, nullptr, 0, a.m, (a.n + 63) / 64, stream);
+      if (e != hipSuccess) return e;
+    }
+  }
+  const long long nwg = (long long)a.tiles_m * a.tiles_n * a.batch * a.ksplit;
   if (nwg > 0x7fffffffLL) return hipErrorInvalidValue;
   switch (cfg) {
     case 0: return launch_tile_kernel(&gf2_m4rm_kernel<8, 128>, 512, a, nwg, stream);
@@ -1072,6 +1202,27 @@ extern "C" hipError_t gf2k_strassen_split(u64 *dst, long long ldd, long long dst
   int gx = grid_for(total, 256, (4096 + batch - 1) / batch);
   hipLaunchKernelGGL(gf2_strassen_split_kernel, dim3(gx, 1, batch), dim3(256), 0, stream, dst, ldd, dstStride, src, lds_,
                      srcStride, h, w, side);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t gf2k_strassen_split2(u64 *dst, long long ldd, long long dstStride, const u64 *src, long long lds_,
+                                           long long srcStride, int h, int w, int side, int batch, hipStream_t stream) {
+  if (h <= 0 || w <= 0 || batch <= 0) return hipSuccess;
+  const long long total = (long long)h * (w / 2);
+  int gx = grid_for(total, 256, (4096 + batch - 1) / batch);
+  hipLaunchKernelGGL(gf2_strassen_split2_kernel, dim3(gx, 1, batch), dim3(256), 0, stream, dst, ldd, dstStride, src, lds_,
+                     srcStride, h, w, side);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t gf2k_strassen_merge2(u64 *dst, long long ldd, long long dstStride, const u64 *src, long long lds_,
+                                           long long srcStride, int h, int w, int accumulate, int batch,
+                                           hipStream_t stream) {
+  if (h <= 0 || w <= 0 || batch <= 0) return hipSuccess;
+  const long long total = (long long)h * (w / 2);
+  int gx = grid_for(total, 256, (4096 + batch - 1) / batch);
+  hipLaunchKernelGGL(gf2_strassen_merge2_kernel, dim3(gx, 1, batch), dim3(256), 0, stream, dst, ldd, dstStride, src, lds_,
+                     srcStride, h, w, accumulate);
   return hipGetLastError();
 }
 

@@ -13,6 +13,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -305,51 +306,103 @@ static int env_int(const char *name, int dflt) {
   return e ? std::atoi(e) : dflt;
 }
 
-// number of Strassen levels: `req` > 0 explicit; 0 automatic.  Automatic = keep splitting while the
-// eighth of the leaf work a level saves outweighs the two streaming passes it adds (split: 4 reads +
-// 7 writes per operand word on each side, merge: 7 reads + 4 writes).  `leaf_min` bounds the leaf
-// dimensions from below (mzd_mul's cutoff argument, strassen.rs:8-18).
+// ---- launch geometry of the tile kernel (shared by the launcher and the level chooser) ----
+// kernel variants (gf2_kernels.hip): 7 = v3 1024x2048 tile (8 waves), 20 = v3 256x2048 tile (4 waves);
+// M4RI_HIP_M4RM_CFG overrides (0/1 = first-generation kernels, kept for A/B runs)
+static int m4rm_cfg_for(int m, int n, int batch) {
+  (void)n;
+  (void)batch;
+  static const int forced = env_int("M4RI_HIP_M4RM_CFG", -1);
+  if (forced >= 0) return forced;
+  return m <= 256 ? 20 : 7;
+}
+
+// split-K factor: when a product has too few tiles to fill 256 CUs, the inner dimension is cut into slices of
+// at least 8 x 32 bits; the slices' partial sums are combined with atomic XOR
+static int m4rm_ksplit_for(int m, int l, int n, int batch) {
+  static const int forced = env_int("M4RI_HIP_M4RM_KSPLIT", 0);
+  if (forced > 0) return forced;
+  const int R = m <= 256 ? 256 : 1024;
+  const long long wg = (long long)((m + R - 1) / R) * ((n + 2047) / 2048) * batch;
+  if (wg >= 192) return 1;
+  const int nw32 = (l + 31) / 32;
+  long long ks = (512 + wg - 1) / wg;
+  if (ks > nw32 / 8) ks = nw32 / 8;
+  return ks < 1 ? 1 : (int)ks;
+}
+
+// modelled duration of one (batched) tile-kernel launch: rounds of 256 workgroups, each `chunks` table steps
+static double m4rm_time_model(int m, int l, int n, int batch) {
+  const int R = m <= 256 ? 256 : 1024;
+  const double cyc_per_chunk = R == 1024 ? 2350.0 : 1300.0;  // measured, 2.4 GHz
+  const int ks = m4rm_ksplit_for(m, l, n, batch);
+  const double wg = (double)((m + R - 1) / R) * ((n + 2047) / 2048) * batch * ks;
+  const double chunks = std::ceil((l + 31) / 32 / (double)ks) * 4.0;
+  const double rounds = std::ceil(wg / 256.0);
+  return rounds * (chunks * cyc_per_chunk + 6000.0) / 2.4e9 + 3e-6;
+}
+
+// Levels whose operands are materialised in the arena: the passes fuse two Strassen levels at a time
+// (gf2_strassen_split2 / merge2), an odd level count starts with one single-level pass.
+static std::vector<int> strassen_materialised(int L) {
+  std::vector<int> v;
+  int lv = 0;
+  if (L & 1) v.push_back(lv = 1);
+  while (lv < L) v.push_back(lv += 2);
+  return v;
+}
+
+static size_t pow7(int i) {
+  size_t p = 1;
+  while (i-- > 0) p *= 7;
+  return p;
+}
+
+// number of Strassen levels: `req` > 0 explicit; 0 automatic = the level count with the smallest modelled time
+//   t(L) = modelled time of the batched leaf launch (rounds of 256 workgroups x chunks x measured cycles per
+//          chunk, split-K included)  +  bytes moved by the split / merge passes / bw
+// (a pass over k fused levels reads 4^k and writes 7^k blocks per operand on the way down, the reverse on the way up).  `leaf_min` bounds the leaf dimensions from below
+// (mzd_mul's cutoff argument, strassen.rs:8-18).
 static int pick_levels(int m, int l, int n, int req, int leaf_min) {
-  static const int max_auto = env_int("M4RI_HIP_STRASSEN_MAX_LEVELS", 3);
-  static const double rate = (double)env_int("M4RI_HIP_M4RM_TBITMACS", 4200) * 1e12;  // kernel bit-MAC/s
-  static const double bw = (double)env_int("M4RI_HIP_STREAM_GBS", 4500) * 1e9;        // streaming B/s
+  static const int max_auto = env_int("M4RI_HIP_STRASSEN_MAX_LEVELS", 5);
+  static const double bw = (double)env_int("M4RI_HIP_STREAM_GBS", 4800) * 1e9;        // streaming B/s
   const int cap = req > 0 ? (req > 6 ? 6 : req) : max_auto;
-  int L = 0;
-  double count = 1;
-  while (L < cap) {
-    const int d = 1 << (L + 1);
-    if (m % d || l % (128 * d) || n % (128 * d)) break;  // leaf rows integral, leaf widths an even word count
-    if (req <= 0) {
-      const double mi = (double)(m >> L), li = (double)(l >> L), ni = (double)(n >> L);  // operands being split
-      if ((m >> (L + 1)) < (leaf_min < 1024 ? leaf_min : 1024) || (l >> (L + 1)) < leaf_min || (n >> (L + 1)) < leaf_min)
-        break;
-      const double saved = count * mi * li * ni / rate / 8.0;
-      const double extra = count * 2.75 * (mi * li + li * ni + mi * ni) / 8.0 / bw;
-      if (saved < 1.25 * extra) break;
+  int best = 0;
+  double best_t = 0;
+  for (int L = 0; L <= cap; ++L) {
+    if (L > 0) {
+      const int d = 1 << L;
+      if (m % d || l % (128 * d) || n % (128 * d)) break;  // leaf rows integral, leaf widths an even word count
+      if (req <= 0 && ((m >> L) < (leaf_min < 1024 ? leaf_min : 1024) || (l >> L) < leaf_min || (n >> L) < leaf_min)) break;
     }
-    count *= 7;
-    ++L;
+    if (req > 0) {
+      best = L;
+      continue;
+    }
+    double t = m4rm_time_model(m >> L, l >> L, n >> L, (int)pow7(L));
+    int prev = 0;
+    for (int i : strassen_materialised(L)) {
+      const int k = i - prev;
+      const double mi = (double)(m >> i), li = (double)(l >> i), ni = (double)(n >> i);
+      const double units = (double)pow7(prev) * ((k == 1 ? 4.0 : 16.0) + (k == 1 ? 7.0 : 49.0));
+      t += units * (mi * li + li * ni + mi * ni) / 8.0 / bw + 3 * 3e-6;  // three passes (A, B, C), a launch each
+      prev = i;
+    }
+    if (L == 0 || t < best_t) {
+      best = L;
+      best_t = t;
+    }
   }
-  return L;
+  return best;
 }
 
 static size_t strassen_ws_words(int m, int l, int n, int L) {
-  size_t total = 0, p7 = 1;
-  for (int i = 1; i <= L; ++i) {
-    p7 *= 7;
+  size_t total = 0;
+  for (int i : strassen_materialised(L)) {
     const size_t mi = (size_t)m >> i, li = (size_t)l >> i, ni = (size_t)n >> i;
-    total += p7 * (mi * (li / 64) + li * (ni / 64) + mi * (ni / 64));
+    total += pow7(i) * (mi * (li / 64) + li * (ni / 64) + mi * (ni / 64));
   }
   return total;
-}
-
-static int m4rm_cfg_for(int m, int n, int batch) {
-  // kernel variants (gf2_kernels.hip): 7 = v3 1024x2048 tile (8 waves), 20 = v3 256x2048 tile (4 waves);
-  // M4RI_HIP_M4RM_CFG overrides (0/1 = first-generation kernels, kept for A/B runs)
-  static const int forced = env_int("M4RI_HIP_M4RM_CFG", -1);
-  if (forced >= 0) return forced;
-  const long long big = (long long)((m + 1023) / 1024) * ((n + 2047) / 2048) * batch;
-  return (m <= 256 || (big < 128 && m > 256)) ? 20 : 7;
 }
 
 static int mul_m4rm_plain(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int accumulate, hipStream_t s) {
@@ -376,6 +429,7 @@ static int mul_m4rm_plain(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int
   a.n = n;
   a.batch = 1;
   a.accumulate = accumulate;
+  a.ksplit = m4rm_ksplit_for(m, l, n, 1);
   return launch_m4rm(a, m4rm_cfg_for(m, n, 1), s);
 }
 
@@ -388,10 +442,9 @@ static int mul_strassen(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int a
   if (int rc = stream_workspace(s, ws_bytes, &ws)) return rc;
   u64 *cur = static_cast<u64 *>(ws);
   std::vector<u64 *> Aop(L + 1), Bop(L + 1), Pop(L + 1);
-  size_t p7 = 1;
-  for (int i = 1; i <= L; ++i) {
-    p7 *= 7;
-    const size_t mi = (size_t)m >> i, li = (size_t)l >> i, ni = (size_t)n >> i;
+  const std::vector<int> mats = strassen_materialised(L);
+  for (int i : mats) {
+    const size_t mi = (size_t)m >> i, li = (size_t)l >> i, ni = (size_t)n >> i, p7 = pow7(i);
     Aop[i] = cur;
     cur += p7 * mi * (li / 64);
     Bop[i] = cur;
@@ -402,18 +455,23 @@ static int mul_strassen(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int a
   int rc = 0;
   auto run = [&]() -> int {
     // operand trees: level i holds 7^i operands of (m/2^i x l/2^i) and (l/2^i x n/2^i)
-    int batch = 1;
-    for (int i = 1; i <= L; ++i) {
-      const int mi = m >> i, li = l >> i, ni = n >> i;
-      const u64 *srcA = (i == 1) ? A->data : Aop[i - 1];
-      const long long ldsA = (i == 1) ? A->ld : (long long)((l >> (i - 1)) / 64);
-      const long long strA = (i == 1) ? 0 : (long long)(m >> (i - 1)) * ldsA;
-      HIP_TRY(gf2k_strassen_split(Aop[i], li / 64, (long long)mi * (li / 64), srcA, ldsA, strA, mi, li / 64, 0, batch, s));
-      const u64 *srcB = (i == 1) ? B->data : Bop[i - 1];
-      const long long ldsB = (i == 1) ? B->ld : (long long)((n >> (i - 1)) / 64);
-      const long long strB = (i == 1) ? 0 : (long long)(l >> (i - 1)) * ldsB;
-      HIP_TRY(gf2k_strassen_split(Bop[i], ni / 64, (long long)li * (ni / 64), srcB, ldsB, strB, li, ni / 64, 1, batch, s));
-      batch *= 7;
+    int prev = 0;
+    for (int i : mats) {
+      const int mi = m >> i, li = l >> i, ni = n >> i, batch = (int)pow7(prev);
+      const u64 *srcA = prev ? Aop[prev] : A->data;
+      const long long ldsA = prev ? (long long)((l >> prev) / 64) : A->ld;
+      const long long strA = prev ? (long long)(m >> prev) * ldsA : 0;
+      const u64 *srcB = prev ? Bop[prev] : B->data;
+      const long long ldsB = prev ? (long long)((n >> prev) / 64) : B->ld;
+      const long long strB = prev ? (long long)(l >> prev) * ldsB : 0;
+      if (i - prev == 1) {
+        HIP_TRY(gf2k_strassen_split(Aop[i], li / 64, (long long)mi * (li / 64), srcA, ldsA, strA, mi, li / 64, 0, batch, s));
+        HIP_TRY(gf2k_strassen_split(Bop[i], ni / 64, (long long)li * (ni / 64), srcB, ldsB, strB, li, ni / 64, 1, batch, s));
+      } else {
+        HIP_TRY(gf2k_strassen_split2(Aop[i], li / 64, (long long)mi * (li / 64), srcA, ldsA, strA, mi, li / 64, 0, batch, s));
+        HIP_TRY(gf2k_strassen_split2(Bop[i], ni / 64, (long long)li * (ni / 64), srcB, ldsB, strB, li, ni / 64, 1, batch, s));
+      }
+      prev = i;
     }
     // 7^L leaf products in one batched launch
     {
@@ -431,19 +489,23 @@ static int mul_strassen(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int a
       a.m = mi;
       a.l = li;
       a.n = ni;
-      a.batch = batch;
+      a.batch = (int)pow7(L);
       a.accumulate = 0;
-      if (int r = launch_m4rm(a, m4rm_cfg_for(mi, ni, batch), s)) return r;
+      a.ksplit = m4rm_ksplit_for(mi, li, ni, a.batch);
+      if (int r = launch_m4rm(a, m4rm_cfg_for(mi, ni, a.batch), s)) return r;
     }
     // fold the products back up
-    for (int i = L; i >= 1; --i) {
-      batch /= 7;
-      const int mi = m >> i, ni = n >> i;
-      u64 *dst = (i == 1) ? C->data : Pop[i - 1];
-      const long long ldd = (i == 1) ? C->ld : (long long)((n >> (i - 1)) / 64);
-      const long long strD = (i == 1) ? 0 : (long long)(m >> (i - 1)) * ldd;
-      HIP_TRY(gf2k_strassen_merge(dst, ldd, strD, Pop[i], ni / 64, (long long)mi * (ni / 64), mi, ni / 64,
-                                  (i == 1) ? accumulate : 0, batch, s));
+    for (int k = (int)mats.size() - 1; k >= 0; --k) {
+      const int i = mats[k], up = k ? mats[k - 1] : 0;  // products of level i -> level `up`
+      const int mi = m >> i, ni = n >> i, batch = (int)pow7(up);
+      u64 *dst = up ? Pop[up] : C->data;
+      const long long ldd = up ? (long long)((n >> up) / 64) : C->ld;
+      const long long strD = up ? (long long)(m >> up) * ldd : 0;
+      const int acc = up ? 0 : accumulate;
+      if (i - up == 1)
+        HIP_TRY(gf2k_strassen_merge(dst, ldd, strD, Pop[i], ni / 64, (long long)mi * (ni / 64), mi, ni / 64, acc, batch, s));
+      else
+        HIP_TRY(gf2k_strassen_merge2(dst, ldd, strD, Pop[i], ni / 64, (long long)mi * (ni / 64), mi, ni / 64, acc, batch, s));
     }
     return 0;
   };

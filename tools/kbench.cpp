@@ -21,7 +21,7 @@ int main(int argc, char **argv) {
   CK(gf2k_fill_random(B, ld, n * batch, n, 2, 0, 0, 0, 0));
   int *diff; CK(hipMalloc(&diff, 4));
   gf2k_mul_args a{};
-  a.A = A; a.B = B; a.lda = a.ldb = a.ldc = ld; a.sA = a.sB = a.sC = words; a.m = a.l = a.n = n; a.batch = batch;
+  a.A = A; a.B = B; a.lda = a.ldb = a.ldc = ld; a.sA = a.sB = a.sC = words; a.m = a.l = a.n = n; a.batch = batch; a.ksplit = getenv("KSPLIT") ? atoi(getenv("KSPLIT")) : 1;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   a.C = Cref;
   CK(gf2k_m4rm(a, 0, 0)); CK(hipDeviceSynchronize());
