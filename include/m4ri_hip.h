@@ -135,7 +135,7 @@ const char *gf2_last_error(void);           /* thread-local text of the last fai
 /* allocation helpers (hipMalloc / hipFree on the current device) */
 int gf2_dmat_alloc(gf2_dmat *M, int nrows, int ncols);
 void gf2_dmat_free(gf2_dmat *M);
-int gf2_dmat_upload(gf2_dmat *dst, mzd_t const *src, void *stream);   /* host mzd_t -> device */
+int gf2_dmat_upload(gf2_dmat *dst, mzd_t const *src, void *stream);   /* host mzd_t -> device; returns after the copy */
 int gf2_dmat_download(mzd_t *dst, gf2_dmat const *src, void *stream); /* device -> host mzd_t */
 int gf2_dmat_fill_random(gf2_dmat *M, uint64_t seed, void *stream);   /* splitmix64 stream, same as the oracle */
 /* same stream, but M holds rows [row0, row0 + M->nrows) of the full matrix (row-block shards) */

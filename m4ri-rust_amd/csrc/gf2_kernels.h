@@ -16,12 +16,18 @@ struct gf2k_mul_args {
   int kwords;               // 32-bit words of the inner dimension per slice (filled in by the launcher)
   int batch;
   int accumulate;  // 0: C = A*B, 1: C ^= A*B
+  const uint32_t *Bp;  // chunk-packed copy of B (kernel variants with BPACK), else unused
+  long long sBp;       // batch stride of Bp in 2 KiB blocks
+  int bp_nc;           // chunk blocks per tile column in Bp
 };
 
 extern "C" {
 int gf2k_m4rm_rows_per_tile(int cfg);
 hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream);
 hipError_t gf2k_dbg_sec(unsigned long long *out8);
+int gf2k_packB_chunks(int l);
+hipError_t gf2k_packB(uint32_t *Bp, long long bpStride, const uint64_t *B, long long ldb, long long bStride, int l, int n,
+                      int batch, hipStream_t stream);
 hipError_t gf2k_rowparity(const uint64_t *A, long long lda, const uint64_t *Bt, long long ldbt, uint64_t *C, long long ldc,
                           int m, int l, int n, int accumulate, hipStream_t stream);
 hipError_t gf2k_narrow(const uint64_t *A, long long lda, const uint64_t *B, long long ldb, uint64_t *C, long long ldc,

@@ -36,7 +36,7 @@ typedef uint32_t u32;
 static constexpr int kTileWords = 32;          // 2048 columns per tile = one 256-byte LDS bank row
 static constexpr int kTableBytes = 256 * 256;  // 2^8 entries x 256 B
 static constexpr int kStageBytes = 64 * 256;   // 64 rows of B x 256 B
-static constexpr int kLdsBytes = 2 * kTableBytes + kStageBytes;
+static constexpr int kLdsBytes = 2 * kTableBytes + kStageBytes;  // 144 KiB: also covers v4's rings (2 x 2 KiB + 2 x 4 KiB)
 
 __device__ __forceinline__ uint4 xor4(uint4 a, uint4 b) {
   return make_uint4(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w);
@@ -291,7 +291,11 @@ constexpr int v3_wait_count(int st, int G, int STEPS, int wps) {
 
 __device__ unsigned long long gf2_dbg_sec[16];  // diagnostic builds only (DBG != 0): per-section cycle sums
 
-template <int WAVES, int RPW, int G, int DBG = 0, int PRIO = 0>
+// BPACK: B is given in the chunk-packed layout written by gf2_packB_kernel / the packed Strassen split: for column
+// tile tn and chunk c one 2 KiB block at ((tn * bp_nc + c) * 2048) bytes, lane-major: lane d holds its dword d of the
+// 8 rows in 32 consecutive bytes.  One wave then fetches a whole chunk with TWO 16-byte buffer loads per lane
+// (instead of eight 4-byte ones), rows and columns outside the matrix are stored as zeros (no guards, one loop).
+template <int WAVES, int RPW, int G, int DBG = 0, int PRIO = 0, int BPACK = 0>
 __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v3(const gf2k_mul_args p) {
   unsigned long long sec[4] = {0, 0, 0, 0};
   auto stamp = [&]() __attribute__((always_inline)) -> unsigned long long {
@@ -376,6 +380,18 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v3(const gf2k_mul_
   auto rsrcB_for = [&](int c) __attribute__((always_inline)) {
     return __builtin_amdgcn_make_buffer_rsrc((void *)(B + (long long)c * 8 * p.ldb + w0), (short)0, (int)(8u * ldbB), 0x00020000);
   };
+  // packed operand: descriptor over this tile column's run of 2 KiB chunk blocks
+  const __amdgpu_buffer_rsrc_t rsrcBp = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)(reinterpret_cast<const char *>(p.Bp) + ((long long)bt * p.sBp + (long long)tn * p.bp_nc) * 2048), (short)0,
+      (int)((u32)p.bp_nc * 2048u), 0x00020000);
+  const u32 voffBp = (u32)lane * 32u;
+  auto loadBpacked = [&](int c, int half, u32 *dst4) __attribute__((always_inline)) {
+    const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rsrcBp, voffBp + (u32)half * 16u, c * 2048, 0);
+    dst4[0] = x.x;
+    dst4[1] = x.y;
+    dst4[2] = x.z;
+    dst4[3] = x.w;
+  };
   // FAST: all 8 rows exist.  Otherwise rows past the inner dimension read as zero (wave-uniform test).
   auto loadBrow = [&](auto fast, const __amdgpu_buffer_rsrc_t &rs, int c, int b) __attribute__((always_inline)) -> u32 {
     if constexpr (decltype(fast)::value) {
@@ -417,11 +433,18 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v3(const gf2k_mul_
   // ---- prologue: rows of chunk 0 -> table 0, rows of chunk 1 -> rrB, A column 0 ----
   u32 rrA[8], rrB[8];
   {
-    const __amdgpu_buffer_rsrc_t rs0 = rsrcB_for(ibeg), rs1 = rsrcB_for(ibeg + 1);
+    if constexpr (BPACK) {
+      loadBpacked(ibeg, 0, rrA);
+      loadBpacked(ibeg, 1, rrA + 4);
+      loadBpacked(ibeg + 1, 0, rrB);
+      loadBpacked(ibeg + 1, 1, rrB + 4);
+    } else {
+      const __amdgpu_buffer_rsrc_t rs0 = rsrcB_for(ibeg), rs1 = rsrcB_for(ibeg + 1);
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      rrA[b] = loadBrow(std::false_type{}, rs0, ibeg, b);
-      rrB[b] = loadBrow(std::false_type{}, rs1, ibeg + 1, b);
+      for (int b = 0; b < 8; ++b) {
+        rrA[b] = loadBrow(std::false_type{}, rs0, ibeg, b);
+        rrB[b] = loadBrow(std::false_type{}, rs1, ibeg + 1, b);
+      }
     }
   }
   loadA_all(jbeg);
@@ -442,7 +465,7 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v3(const gf2k_mul_
     const u32 lo = (C4 & 1) ? laneoff1 : laneoff0;
     using tnext = std::integral_constant<u32, (C4 & 1) ? 0u : (u32)kTableBytes>;
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-    if constexpr (DBG) t0 = stamp();
+    if constexpr (DBG == 1) t0 = stamp();
     build_begin(rows, tnext::value);
     const __amdgpu_buffer_rsrc_t rsN = rsrcB_for(i + 2);
     const int jn = (i >> 2) + 1;
@@ -472,7 +495,7 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v3(const gf2k_mul_
       // otherwise pads with s_nop between an inline-asm result and its first VALU use
       static_for<WPS>([&](auto ktag) __attribute__((always_inline)) {
         constexpr int e = st * WPS + decltype(ktag)::value;
-        if constexpr (e < EPW && e > 0 && decltype(ktag)::value == 0) cur32 ^= rows[__builtin_ctz(e | 256)];
+        if constexpr (e < EPW && e > 0 && decltype(ktag)::value == 0 && DBG != 4 && DBG != 5) cur32 ^= rows[__builtin_ctz(e | 256)];
       });
       // XOR in place through asm: opaque to LLVM (no reassociation of the four chunks' XOR chains into a
       // tree that keeps every table row alive) and pinned to the accumulator's own register
@@ -489,23 +512,27 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v3(const gf2k_mul_
           build_write(std::integral_constant<int, e>{}, tnext{});
         }
       });
-      if constexpr (st < 8) next[st] = loadBrow(fast, rsN, i + 2, st);
-      if constexpr (C4 == 3) {  // aw[st] was consumed G steps ago: fetch the next column's word in place
+      if constexpr (BPACK) {
+        if constexpr (st < 2) loadBpacked(i + 2, st, next + 4 * st);
+      } else if constexpr (st < 8 && DBG != 3 && DBG != 5 && DBG != 6) {
+        next[st] = loadBrow(fast, rsN, i + 2, st);
+      }
+      if constexpr (C4 == 3 && DBG != 3 && DBG != 5 && DBG != 7) {  // aw[st] was consumed G steps ago: fetch the next column's word in place
         aw[st] = __builtin_amdgcn_raw_buffer_load_b32(rsrcA, voA, jn * 4, 0);
         voA += 4u * ldaB;
       }
       __builtin_amdgcn_sched_barrier(0);
     });
-    if constexpr (DBG) t1 = stamp();
+    if constexpr (DBG == 1) t1 = stamp();
     if constexpr (C4 == 3) {
       if (jn == nw32 - 1 && tailA != 0xffffffffu) {
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) aw[s] &= tailA;
       }
     }
-    if constexpr (DBG) t2 = stamp();
-    __syncthreads();
-    if constexpr (DBG) {
+    if constexpr (DBG == 1) t2 = stamp();
+    if constexpr (DBG != 2 && DBG != 5) __syncthreads();  // DBG >= 2: timing-only ablations (wrong results)
+    if constexpr (DBG == 1) {
       t3 = stamp();
       sec[0] += t1 - t0;  // steps (lookups + build + interleaved loads)
       sec[1] += t2 - t1;  // tail mask
@@ -518,7 +545,7 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v3(const gf2k_mul_
   // accumulators around the merge point
   int i = ibeg;
 #pragma unroll 1
-  for (; i < nchunks && (i + 6) * 8 <= p.l; i += 4) {  // chunks i+2 .. i+5 lie wholly inside the inner dimension
+  for (; i < nchunks && (BPACK || (i + 6) * 8 <= p.l); i += 4) {  // chunks i+2 .. i+5 lie wholly inside the inner dimension
     chunk_iter(i + 0, std::integral_constant<int, 0>{}, std::true_type{}, rrB, rrA);
     chunk_iter(i + 1, std::integral_constant<int, 1>{}, std::true_type{}, rrA, rrB);
     chunk_iter(i + 2, std::integral_constant<int, 2>{}, std::true_type{}, rrB, rrA);
@@ -532,7 +559,7 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v3(const gf2k_mul_
     chunk_iter(i + 3, std::integral_constant<int, 3>{}, std::false_type{}, rrA, rrB);
   }
 
-  if constexpr (DBG) {
+  if constexpr (DBG == 1) {
     if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == WAVES - 1)) {
       const int o = wave ? 4 : 0;
       gf2_dbg_sec[o + 0] = sec[0];
@@ -1040,6 +1067,40 @@ __global__ __launch_bounds__(256) void gf2_strassen_merge2_kernel(u64 *__restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// B (l x n, row-major) -> chunk-packed layout of the tile kernel (see gf2_m4rm_kernel_v3, BPACK).
+// thread <-> (chunk c, column tile tn, lane d): reads dword d of rows 8c..8c+7 (a wave reads 256 contiguous bytes of
+// each row), writes its 32 bytes (a wave writes one whole 2 KiB block).  Rows >= l, columns >= n and the nc - ceil(l/8)
+// padding chunks are written as zeros.  blockIdx.z = batch.
+// ---------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void gf2_packB_kernel(u32 *__restrict__ Bp, long long bpStride, const u64 *__restrict__ B,
+                                                        long long ldb, long long bStride, int l, int n, int nc, int tiles_n) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int tn = blockIdx.y;
+  if (c >= nc) return;
+  const u32 *B32 = reinterpret_cast<const u32 *>(B + (long long)blockIdx.z * bStride);
+  const int ndw = ((n + 63) >> 6) * 2;  // dwords per row that exist
+  const int dcol = tn * 64 + lane;
+  const u32 tail = (n & 31) ? ((1u << (n & 31)) - 1u) : 0xffffffffu;
+  u32 v[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int row = c * 8 + r;
+    u32 x = 0;
+    if (row < l && dcol < ndw) {
+      x = B32[(long long)row * ldb * 2 + dcol];
+      if (dcol == ((n + 31) >> 5) - 1) x &= tail;
+      if (dcol > ((n + 31) >> 5) - 1) x = 0;
+    }
+    v[r] = x;
+  }
+  uint4 *dst = reinterpret_cast<uint4 *>(Bp + ((long long)blockIdx.z * bpStride + ((long long)tn * nc + c) * 512) + lane * 8);
+  dst[0] = make_uint4(v[0], v[1], v[2], v[3]);
+  dst[1] = make_uint4(v[4], v[5], v[6], v[7]);
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers (internal C ABI used by m4ri_hip_api.cpp)
 // ---------------------------------------------------------------------------------------------
 
@@ -1090,6 +1151,13 @@ extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {
     case 1: return launch_tile_kernel(&gf2_m4rm_kernel<4, 64>, 256, a, nwg, stream);
     case 7: return launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4>, 512, a, nwg, stream);
     case 20: return launch_tile_kernel(&gf2_m4rm_kernel_v3<4, 64, 4>, 256, a, nwg, stream);
+    case 50: return launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 0, 0, 1>, 512, a, nwg, stream);  // packed B
+    case 40: return launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 2>, 512, a, nwg, stream);  // no barriers (timing only)
+    case 41: return launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 3>, 512, a, nwg, stream);  // no loads in the loop
+    case 42: return launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 4>, 512, a, nwg, stream);  // no build xor chain
+    case 44: return launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 6>, 512, a, nwg, stream);  // no B loads in the loop
+    case 45: return launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 7>, 512, a, nwg, stream);  // no A loads in the loop
+    case 43: return launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 5>, 512, a, nwg, stream);  // none of the three
     case 9: return launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 6, 1>, 512, a, nwg, stream);  // section stamps
     default: return hipErrorInvalidValue;
   }
@@ -1097,6 +1165,20 @@ extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {
 
 extern "C" hipError_t gf2k_dbg_sec(unsigned long long *out8) {
   return hipMemcpyFromSymbol(out8, HIP_SYMBOL(gf2_dbg_sec), 8 * sizeof(unsigned long long));
+}
+
+// chunks per tile column of a packed operand with inner dimension l (4 padding chunks: the kernel prefetches two
+// chunks past the last 32-bit word)
+extern "C" int gf2k_packB_chunks(int l) { return ((l + 31) / 32) * 4 + 4; }
+
+// bpStride: dwords between batch elements of Bp (>= tiles_n * gf2k_packB_chunks(l) * 512)
+extern "C" hipError_t gf2k_packB(uint32_t *Bp, long long bpStride, const u64 *B, long long ldb, long long bStride, int l,
+                                 int n, int batch, hipStream_t stream) {
+  if (l <= 0 || n <= 0 || batch <= 0) return hipSuccess;
+  const int nc = gf2k_packB_chunks(l), tiles_n = (n + 2047) / 2048;
+  hipLaunchKernelGGL(gf2_packB_kernel, dim3((nc + 3) / 4, tiles_n, batch), dim3(256), 0, stream, Bp, bpStride, B, ldb,
+                     bStride, l, n, nc, tiles_n);
+  return hipGetLastError();
 }
 
 extern "C" hipError_t gf2k_rowparity(const u64 *A, long long lda, const u64 *Bt, long long ldbt, u64 *C, long long ldc,

@@ -698,12 +698,10 @@ extern "C" int gf2_strassen_levels(int m, int l, int n, int algo, int param) {
 }
 
 // host rows -> device. Our mzd_t are single-block with a constant rowstride (mzd_host.cpp), windows included.
-extern "C" int gf2_dmat_upload(gf2_dmat *dst, mzd_t const *src, void *stream) {
-  if (int rc = require_device()) return rc;
+// Asynchronous form (internal): `src` must stay untouched until the stream has passed the copy.
+static int upload_async(gf2_dmat *dst, mzd_t const *src, hipStream_t s) {
   if (dst->nrows != src->nrows || dst->ncols != src->ncols) return fail_msg("gf2_dmat_upload: dimension mismatch");
   if (src->nrows == 0 || src->ncols == 0) return 0;
-  hipStream_t s;
-  if (int rc = get_stream(stream, &s)) return rc;
   const size_t wbytes = (size_t)src->width * sizeof(word);
   if (dst->ld == src->rowstride)
     HIP_TRY(hipMemcpyAsync(dst->data, src->rows[0], ((size_t)(src->nrows - 1) * src->rowstride + src->width) * sizeof(word),
@@ -711,6 +709,17 @@ extern "C" int gf2_dmat_upload(gf2_dmat *dst, mzd_t const *src, void *stream) {
   else
     HIP_TRY(hipMemcpy2DAsync(dst->data, (size_t)dst->ld * sizeof(u64), src->rows[0], (size_t)src->rowstride * sizeof(word),
                              wbytes, src->nrows, hipMemcpyHostToDevice, s));
+  return 0;
+}
+
+// public form: returns once the host rows have been consumed (the caller may free or modify `src` right away;
+// pinned blocks make the copy itself truly asynchronous, so this has to wait for it)
+extern "C" int gf2_dmat_upload(gf2_dmat *dst, mzd_t const *src, void *stream) {
+  if (int rc = require_device()) return rc;
+  hipStream_t s;
+  if (int rc = get_stream(stream, &s)) return rc;
+  if (int rc = upload_async(dst, src, s)) return rc;
+  HIP_TRY(hipStreamSynchronize(s));
   return 0;
 }
 
@@ -766,7 +775,7 @@ int to_device(DMatOwner &o, const mzd_t *M, hipStream_t s, bool copy) {
   void *p = nullptr;
   if (int rc = dev_alloc(&p, (size_t)(M->nrows ? M->nrows : 1) * o.d.ld * sizeof(u64))) return rc;
   o.d.data = static_cast<u64 *>(p);
-  if (copy) return gf2_dmat_upload(&o.d, M, s);
+  if (copy) return upload_async(&o.d, M, s);  // host_mul synchronises before it returns
   return 0;
 }
 
@@ -781,7 +790,7 @@ mzd_t *host_mul(mzd_t *C, const mzd_t *A, const mzd_t *B, int accumulate, int al
     return nullptr;
   };
   if (require_device()) return bail("no device");
-  if (!C) C = mzd_init(A->nrows, B->ncols);
+  if (!C) C = (A->nrows == 0 || B->ncols == 0) ? mzd_init(A->nrows, B->ncols) : gf2_mzd_init_uncleared(A->nrows, B->ncols);
   if (A->nrows == 0 || B->ncols == 0) return C;
   hipStream_t s;
   if (get_private_stream(&s)) {

@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 
 #include "../../include/m4ri_hip.h"
 #include "api_internal.h"
@@ -37,32 +39,73 @@ static size_t pin_threshold() {
   return t;
 }
 
-static void *block_alloc(size_t bytes, uint8_t *kind) {
+// Pinned blocks are expensive to create (hipHostMalloc pins pages: ~100 ms for 512 MiB), so freed ones are kept in a
+// small size-keyed pool and handed out again (M4RI keeps a similar cache of its own blocks, m4ri_mmc).
+namespace {
+std::mutex g_pin_mu;
+std::multimap<size_t, void *> g_pin_free;
+size_t g_pin_cached = 0;
+size_t pin_cache_limit() {
+  static size_t t = [] {
+    const char *e = std::getenv("M4RI_HIP_PIN_CACHE_BYTES");
+    return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)8 << 30;
+  }();
+  return t;
+}
+}  // namespace
+
+static void *block_alloc(size_t bytes, uint8_t *kind, bool zero) {
   *kind = kAllocMalloc;
   if (bytes >= pin_threshold() && gf2_device_count() > 0) {
     void *p = nullptr;
-    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess && p) {
-      std::memset(p, 0, bytes);
+    {
+      std::lock_guard<std::mutex> lk(g_pin_mu);
+      auto it = g_pin_free.find(bytes);
+      if (it != g_pin_free.end()) {
+        p = it->second;
+        g_pin_cached -= bytes;
+        g_pin_free.erase(it);
+      }
+    }
+    if (!p && hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      p = nullptr;
+    }
+    if (p) {
+      if (zero) std::memset(p, 0, bytes);
       *kind = kAllocPinned;
       return p;
     }
-    (void)hipGetLastError();
   }
   void *p = nullptr;
   if (posix_memalign(&p, 64, bytes ? bytes : 64) != 0) gf2_die("out of memory");
-  std::memset(p, 0, bytes);
+  if (zero) std::memset(p, 0, bytes);
   return p;
 }
 
-static void block_free(void *p, uint8_t kind) {
+static void block_free(void *p, uint8_t kind, size_t bytes) {
   if (!p) return;
-  if (kind == kAllocPinned)
+  if (kind == kAllocPinned) {
+    {
+      std::lock_guard<std::mutex> lk(g_pin_mu);
+      if (g_pin_cached + bytes <= pin_cache_limit()) {
+        g_pin_free.emplace(bytes, p);
+        g_pin_cached += bytes;
+        return;
+      }
+    }
     (void)hipHostFree(p);
-  else
+  } else {
     std::free(p);
+  }
 }
 
-extern "C" mzd_t *mzd_init(rci_t r, rci_t c) {
+static mzd_t *mzd_init_impl(rci_t r, rci_t c, bool zero);
+extern "C" mzd_t *mzd_init(rci_t r, rci_t c) { return mzd_init_impl(r, c, true); }
+// product destinations are overwritten entirely: no need to clear half a gigabyte first
+mzd_t *gf2_mzd_init_uncleared(rci_t r, rci_t c) { return mzd_init_impl(r, c, false); }
+
+static mzd_t *mzd_init_impl(rci_t r, rci_t c, bool zero) {
   if (r < 0 || c < 0) gf2_die("mzd_init: negative dimension");
   mzd_t *A = nullptr;
   if (posix_memalign(reinterpret_cast<void **>(&A), 64, sizeof(mzd_t)) != 0) gf2_die("out of memory");
@@ -83,7 +126,7 @@ extern "C" mzd_t *mzd_init(rci_t r, rci_t c) {
     mzd_block_t *blocks = static_cast<mzd_block_t *>(std::calloc(2, sizeof(mzd_block_t)));  // [1] = terminator
     if (!blocks) gf2_die("out of memory");
     uint8_t kind;
-    blocks[0].begin = static_cast<word *>(block_alloc(bytes, &kind));
+    blocks[0].begin = static_cast<word *>(block_alloc(bytes, &kind, zero));
     blocks[0].size = bytes;
     blocks[0].end = blocks[0].begin + (size_t)r * A->rowstride;
     A->padding[0] = kind;
@@ -105,7 +148,7 @@ extern "C" void mzd_free(mzd_t *A) {
   if (!A) return;
   std::free(A->rows);
   if (owns_blocks(A)) {
-    block_free(A->blocks[0].begin, A->padding[0]);
+    block_free(A->blocks[0].begin, A->padding[0], A->blocks[0].size);
     std::free(A->blocks);
   }
   std::free(A);

@@ -261,3 +261,65 @@ def test_dev_properties_full_size(dev):
     from m4ri_rust_amd import BinMatrix
     I = dev.DMat.from_host(BinMatrix.identity(n))
     assert dev.equal(dev.mul(A, I), A) and dev.equal(dev.mul(I, A, algo="m4rm"), A)
+
+
+# ---- re-entrancy: BinMatrix is Send + Sync (binary_matrix.rs:38-39) -------------------------------
+
+def test_concurrent_host_threads(pkg):
+    """Several host threads multiply shared inputs at once through the C ABI (ctypes drops the GIL)."""
+    import threading
+    shapes = [(300, 500, 700), (1025, 2049, 513), (64, 4096, 64), (2048, 2048, 2048)]
+    mats = []
+    for (m, l, n) in shapes:
+        a, b = g.random_words(m, l, 31), g.random_words(l, n, 32)
+        mats.append((pkg.BinMatrix.from_words(a, l), pkg.BinMatrix.from_words(b, n), g.o_mul_m4rm(a, b, m, l, n)))
+    L = pkg._lib.lib()
+    errors = []
+
+    def worker(k):
+        try:
+            for it in range(6):
+                A, B, ref = mats[(k + it) % len(mats)]
+                fn = (L.mzd_mul, L.mzd_mul_m4rm)[it & 1]
+                c = fn(None, A.mzd, B.mzd, 0)
+                assert c, "NULL product"
+                out = pkg.BinMatrix(c)
+                if not np.array_equal(out.to_words(), ref):
+                    errors.append((k, it))
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
+def test_degenerate_shapes(pkg, dev):
+    """Empty inner dimension gives the zero matrix; one-row / one-column products; C == A aliasing is not used."""
+    L = pkg._lib.lib()
+    # l = 0 through the device API (mzd_init allows 0 columns)
+    A0, B0 = dev.DMat(5, 0), dev.DMat(0, 70)
+    C = dev.DMat.random(5, 70, 9)
+    dev.mul(A0, B0, C=C, algo="m4rm")
+    assert not dev.DMat.to_words(C).any()
+    for (m, l, n) in [(1, 1, 1), (1, 64, 1), (1, 5000, 1), (2, 3, 100000 // 8)]:
+        a, b = g.random_words(m, l, 3), g.random_words(l, n, 4)
+        ref = g.o_mul_m4rm(a, b, m, l, n)
+        for strat in ("strassen", "m4rm", "naive"):
+            assert np.array_equal(_host_mul(pkg, a, b, m, l, n, strat), ref), (m, l, n, strat)
+
+
+def test_split_k_and_small_tile_paths(dev):
+    """Shapes that exercise split-K (few tiles, long inner dimension) and the 256-row tile kernel."""
+    for (m, l, n) in [(2048, 16384, 2048), (200, 9000, 3000), (1100, 20000, 100), (256, 32768, 4096)]:
+        a, b = g.random_words(m, l, 5), g.random_words(l, n, 6)
+        ref = g.o_mul_fast(a, b, m, l, n) if (m % 128 == 0 and l % 128 == 0 and n % 128 == 0) else g.o_mul_m4rm(a, b, m, l, n, k=8)
+        A, B = dev.DMat.from_words(a, l), dev.DMat.from_words(b, n)
+        assert np.array_equal(dev.mul(A, B, algo="m4rm").to_words(), ref), (m, l, n)
+        C0 = dev.DMat.random(m, n, 7)
+        c0 = C0.to_words()
+        dev.mul(A, B, C=C0, accumulate=True, algo="m4rm")
+        assert np.array_equal(C0.to_words(), c0 ^ ref), (m, l, n, "accumulate")

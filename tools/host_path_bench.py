@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""End-to-end time of the drop-in entry point on host mzd_t (upload A, B + product + download C), pinned blocks.
+Development tool: the PCIe-inclusive rate quoted in DESIGN.md comes from here."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import m4ri_rust_amd as pkg
+from m4ri_rust_amd import device
+device.require_gpu()
+L = pkg._lib.lib()
+for n in (4096, 16384, 32768, 65536):
+    A, B = pkg.BinMatrix.random(n, n), pkg.BinMatrix.random(n, n)
+    c = L.mzd_mul(None, A.mzd, B.mzd, 0); L.mzd_free(c)
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        c = L.mzd_mul(None, A.mzd, B.mzd, 0)
+        L.mzd_free(c)
+    dt = (time.perf_counter() - t0) / reps
+    Cp = pkg.BinMatrix.zero(n, n)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        L.mzd_mul(Cp.mzd, A.mzd, B.mzd, 0)
+    dt2 = (time.perf_counter() - t0) / reps
+    print(f"n={n}: mzd_mul(NULL,..) {dt*1e3:.1f} ms  preallocated C {dt2*1e3:.1f} ms  -> {2*n**3/dt2/1e12:.1f} Tbit-ops/s end to end; bytes moved {3*n*n/8/1e6:.0f} MB")

@@ -22,6 +22,12 @@ int main(int argc, char **argv) {
   int *diff; CK(hipMalloc(&diff, 4));
   gf2k_mul_args a{};
   a.A = A; a.B = B; a.lda = a.ldb = a.ldc = ld; a.sA = a.sB = a.sC = words; a.m = a.l = a.n = n; a.batch = batch; a.ksplit = getenv("KSPLIT") ? atoi(getenv("KSPLIT")) : 1;
+  // chunk-packed copy of B for the BPACK kernel variants
+  const int nc = gf2k_packB_chunks(n), tiles_n = (n + 2047) / 2048;
+  const long long bpBlocks = (long long)tiles_n * nc;
+  uint32_t *Bp; CK(hipMalloc(&Bp, (size_t)bpBlocks * 2048 * batch));
+  CK(gf2k_packB(Bp, bpBlocks * 512, B, ld, words, n, n, batch, 0));
+  a.Bp = Bp; a.sBp = bpBlocks; a.bp_nc = nc;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   a.C = Cref;
   CK(gf2k_m4rm(a, 0, 0)); CK(hipDeviceSynchronize());
