@@ -417,6 +417,9 @@ static int mul_m4rm_plain(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int
     HIP_TRY(gf2k_va(A->data, A->ld, B->data, B->ld, C->data, C->ld, m, l, n, s));
     return 0;
   }
+  // buffer descriptors of the tile kernel carry 32-bit byte counts: one tile of A rows must stay below 4 GiB
+  if ((long long)A->ld * 8 * 1024 >= (1ll << 32) || (long long)B->ld * 8 * 8 >= (1ll << 32))
+    return fail_msg("gf2_mul_dev: row stride too large for the tile kernel (more than ~33 million columns)");
   gf2k_mul_args a{};
   a.A = A->data;
   a.B = B->data;
@@ -436,6 +439,9 @@ static int mul_m4rm_plain(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int
 static int mul_strassen(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int accumulate, int L, hipStream_t s,
                         bool sync_free) {
   const int m = A->nrows, l = A->ncols, n = B->ncols;
+  // the level passes use 16-byte accesses: row strides must be even and the bases 16-byte aligned
+  if ((A->ld | B->ld | C->ld) & 1) L = 0;
+  if ((reinterpret_cast<uintptr_t>(A->data) | reinterpret_cast<uintptr_t>(B->data) | reinterpret_cast<uintptr_t>(C->data)) & 15) L = 0;
   if (L <= 0) return mul_m4rm_plain(C, A, B, accumulate, s);
   const size_t ws_bytes = strassen_ws_words(m, l, n, L) * sizeof(u64);
   void *ws = nullptr;

@@ -106,6 +106,27 @@ __global__ __launch_bounds__(1024) void k(unsigned long long *out, u32 *sink, in
       asm volatile("s_waitcnt lgkmcnt(4)\nv_xor_b32 %0, %0, %10\nv_xor_b32 %1, %1, %10\nv_xor_b32 %2, %2, %10\nv_xor_b32 %3, %3, %10\nv_mov_b32_sdwa %11, %10 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0\nds_read_b128 %4, %11\nv_xor_b32 %0, %0, %10\nv_xor_b32 %1, %1, %10\nv_xor_b32 %2, %2, %10\nv_xor_b32 %3, %3, %10\nv_mov_b32_sdwa %11, %10 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1\nds_read_b128 %5, %11\ns_waitcnt lgkmcnt(4)\nv_xor_b32 %0, %0, %10\nv_xor_b32 %1, %1, %10\nv_xor_b32 %2, %2, %10\nv_xor_b32 %3, %3, %10\nv_mov_b32_sdwa %11, %10 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\nds_read_b128 %6, %11\nv_xor_b32 %0, %0, %10\nv_xor_b32 %1, %1, %10\nv_xor_b32 %2, %2, %10\nv_xor_b32 %3, %3, %10\nv_mov_b32_sdwa %11, %10 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3\nds_read_b128 %7, %11\ns_waitcnt lgkmcnt(4)\nv_xor_b32 %0, %0, %10\nv_xor_b32 %1, %1, %10\nv_xor_b32 %2, %2, %10\nv_xor_b32 %3, %3, %10\nv_mov_b32_sdwa %11, %10 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0\nds_read_b128 %8, %11\nv_xor_b32 %0, %0, %10\nv_xor_b32 %1, %1, %10\nv_xor_b32 %2, %2, %10\nv_xor_b32 %3, %3, %10\nv_mov_b32_sdwa %11, %10 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1\nds_read_b128 %9, %11\ns_waitcnt lgkmcnt(4)\nv_xor_b32 %0, %0, %10\nv_xor_b32 %1, %1, %10\nv_xor_b32 %2, %2, %10\nv_xor_b32 %3, %3, %10\nv_mov_b32_sdwa %11, %10 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\nds_read_b128 %4, %11\nv_xor_b32 %0, %0, %10\nv_xor_b32 %1, %1, %10\nv_xor_b32 %2, %2, %10\nv_xor_b32 %3, %3, %10\nv_mov_b32_sdwa %11, %10 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3\nds_read_b128 %5, %11\ns_waitcnt lgkmcnt(4)\nv_xor_b32 %0, %0, %10\nv_xor_b32 %1, %1, %10\nv_xor_b32 %2, %2, %10\nv_xor_b32 %3, %3, %10\nv_mov_b32_sdwa %11, %10 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0\nds_read_b128 %6, %11\nv_xor_b32 %0, %0, %10\nv_xor_b32 %1, %1, %10\nv_xor_b32 %2, %2, %10\nv_xor_b32 %3, %3, %10\nv_mov_b32_sdwa %11, %10 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1\nds_read_b128 %7, %11\ns_waitcnt lgkmcnt(4)\nv_xor_b32 %0, %0, %10\nv_xor_b32 %1, %1, %10\nv_xor_b32 %2, %2, %10\nv_xor_b32 %3, %3, %10\nv_mov_b32_sdwa %11, %10 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\nds_read_b128 %8, %11\nv_xor_b32 %0, %0, %10\nv_xor_b32 %1, %1, %10\nv_xor_b32 %2, %2, %10\nv_xor_b32 %3, %3, %10\nv_mov_b32_sdwa %11, %10 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3\nds_read_b128 %9, %11"
           : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(a[8]), "+v"(t0)
           : "v"(a[9]) : "memory");
+    } else if constexpr (MODE == 15 || MODE == 16 || MODE == 17) {
+      // 56 v_xor with 8 loads interleaved (one per 7 xor): MODE 15 dword/lane coalesced, 16 dwordx4/lane, 17 no loads (8 more xor)
+      const unsigned *gp = (const unsigned *)sink + 1024 + (threadIdx.x & 63) * (MODE == 16 ? 4 : 1);
+      u32 l0, l1, l2, l3, l4, l5, l6, l7;
+      u32x4 w0, w1;
+      (void)w0; (void)w1; (void)l0;
+#define X7 "v_xor_b32 %0, %0, %4\n v_xor_b32 %1, %1, %4\n v_xor_b32 %2, %2, %4\n v_xor_b32 %3, %3, %4\n v_xor_b32 %0, %0, %4\n v_xor_b32 %1, %1, %4\n v_xor_b32 %2, %2, %4\n"
+      if constexpr (MODE == 15) {
+        asm volatile(X7 "global_load_dword %5, %13, off\n" X7 "global_load_dword %6, %13, off offset:256\n" X7 "global_load_dword %7, %13, off offset:512\n" X7 "global_load_dword %8, %13, off offset:768\n"
+                     X7 "global_load_dword %9, %13, off offset:1024\n" X7 "global_load_dword %10, %13, off offset:1280\n" X7 "global_load_dword %11, %13, off offset:1536\n" X7 "global_load_dword %12, %13, off offset:1792\n s_waitcnt vmcnt(0)\n"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[8]), "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3), "=&v"(l4), "=&v"(l5), "=&v"(l6), "=&v"(l7)
+                     : "v"(gp) : "memory");
+        a[9] ^= l0 ^ l1 ^ l2 ^ l3 ^ l4 ^ l5 ^ l6 ^ l7;
+      } else if constexpr (MODE == 16) {
+        asm volatile(X7 X7 X7 X7 "global_load_dwordx4 %5, %7, off\n" X7 X7 X7 X7 "global_load_dwordx4 %6, %7, off offset:1024\n s_waitcnt vmcnt(0)\n"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[8]), "=&v"(w0), "=&v"(w1) : "v"(gp) : "memory");
+        a[9] ^= w0.x ^ w1.y;
+      } else {
+        asm volatile(X7 X7 X7 X7 X7 X7 X7 X7 "v_xor_b32 %0, %0, %4\n v_xor_b32 %1, %1, %4\n v_xor_b32 %2, %2, %4\n v_xor_b32 %3, %3, %4\n v_xor_b32 %0, %0, %4\n v_xor_b32 %1, %1, %4\n v_xor_b32 %2, %2, %4\n v_xor_b32 %3, %3, %4\n"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[8]) :: "memory");
+      }
     }
   }
   unsigned long long c1 = __builtin_amdgcn_s_memtime();
@@ -120,7 +141,7 @@ __global__ __launch_bounds__(1024) void k(unsigned long long *out, u32 *sink, in
 template <int MODE>
 void run(const char *name, int ninstr, int threads) {
   unsigned long long *out; u32 *sink;
-  CK(hipMalloc(&out, 8)); CK(hipMalloc(&sink, 4));
+  CK(hipMalloc(&out, 8)); CK(hipMalloc(&sink, 1 << 20)); CK(hipMemset(sink, 0, 1 << 20));
   const int iters = 2000;
   hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(threads), 65536, 0, out, sink, iters);
   CK(hipDeviceSynchronize());
@@ -151,6 +172,9 @@ int main() {
     run<14>("12 lookups sdwa, wait/2 (78)", 78, threads);
     run<12>("12 lookups + 12 addtid (96)", 96, threads);
     run<13>("12 lookups + 12 addtid wait/2 (90)", 90, threads);
+    run<17>("64 v_xor (ref)", 64, threads);
+    run<15>("56 v_xor + 8 global_load_dword", 64, threads);
+    run<16>("56 v_xor + 2 global_load_dwordx4", 58, threads);
   }
   return 0;
 }
