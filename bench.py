@@ -34,12 +34,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=65536, help="matrix dimension (BASELINE metric: 65536)")
+    ap.add_argument("--dim", "--n", dest="n", type=int, default=65536, help="matrix dimension (BASELINE metric: 65536)")
     ap.add_argument("--algo", default="auto", choices=["auto", "m4rm", "strassen"])
     ap.add_argument("--levels", type=int, default=0, help="Strassen levels (0 = automatic)")
     ap.add_argument("--cpu-n", type=int, default=32768, help="dimension of the CPU-baseline sample product")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--panels", type=int, default=4, help="column panels of B per step when N > 1 (RCCL/compute overlap)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--check", action="store_true", help="spot-check rows of C against the oracle after timing")
     args = ap.parse_args()
 
@@ -55,9 +56,10 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the multiply path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # rehearsal mode: more ranks than GPUs (e.g. 2 ranks on a 1-GPU box with --backend gloo) share device 0
+    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     import __graft_entry__ as ge
     if rank == 0:
@@ -144,6 +146,16 @@ def main():
     bitops = 2.0 * n * n * n * args.steps
     ms_per_step = dt * 1e3 / args.steps
 
+    sharded_ok = None
+    if args.check and world > 1:
+        # rank 0 recomputes every C panel from the full seeded A on its own GPU and compares with what was gathered
+        A_full = device.DMat.random(n, n, 1, stream)
+        sharded_ok = True
+        for pnl in range(P):
+            ref = device.mul(A_full, Bp[pnl], algo=args.algo, param=args.levels, stream=stream)
+            sharded_ok = sharded_ok and device.equal(ref, device.DMat.from_torch(Cfull_t[pnl], ncp), stream)
+        del A_full
+
     # dominant kernel: the (batched) M4RM tile kernel. Algorithmic bytes of ONE launch = what that
     # launch's products read and write once: batch * (m*l + l*n + m*n)/8 with the leaf dims.
     ncols_launch = n // P  # columns of B one launch sees (a column panel when N > 1)
@@ -203,6 +215,8 @@ def main():
         },
         "hbm_equiv_GBps_whole_step": 3.0 * n * n / 8.0 / (ms_per_step * 1e-3) / 1e9,
     }
+    if sharded_ok is not None:
+        out["sharded_result_matches_single_gpu"] = bool(sharded_ok)
 
     if world == 1 and not args.no_cpu:
         import numpy as np
