@@ -32,6 +32,8 @@ hipError_t gf2k_rowparity(const uint64_t *A, long long lda, const uint64_t *Bt, 
                           int m, int l, int n, int accumulate, hipStream_t stream);
 hipError_t gf2k_narrow(const uint64_t *A, long long lda, const uint64_t *B, long long ldb, uint64_t *C, long long ldc,
                        int m, int l, int n, int accumulate, hipStream_t stream);
+hipError_t gf2k_tallskinny(const uint64_t *A, long long lda, const uint64_t *B, long long ldb, uint64_t *C, long long ldc,
+                           int m, int l, int n, int accumulate, hipStream_t stream);
 hipError_t gf2k_va(const uint64_t *A, long long lda, const uint64_t *B, long long ldb, uint64_t *C, long long ldc, int m,
                    int l, int n, hipStream_t stream);
 hipError_t gf2k_xor2d(uint64_t *C, long long ldc, const uint64_t *A, long long lda, const uint64_t *B, long long ldb,

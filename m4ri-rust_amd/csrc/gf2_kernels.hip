@@ -740,6 +740,102 @@ __global__ __launch_bounds__(256) void gf2_narrow_kernel(const u64 *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
+// tall-skinny kernel: C (m x n) (+)= A (m x l) * B (l x n) with n <= 256 and m large -- a BATCH of LPN-style
+// matrix x vector products (BASELINE config 5: A is 2^20 x 256, B holds the vectors as columns).
+// Four-Russians with the roles the shape dictates: B is tiny, so EVERY 8-bit chunk of the inner dimension gets its
+// 256-entry table of n-bit rows (NW words each) in LDS, as many chunks at a time as fit in 128 KiB; each lane owns
+// RPT rows of A, whose words it reads exactly once with 16-byte loads, and XORs the table entries selected by the
+// bytes of its rows into NW 64-bit accumulators per row.  One workgroup = 256 lanes x RPT rows; tables are rebuilt
+// per workgroup (256*l/8 entries against 256*RPT*l/8 lookups).
+// ---------------------------------------------------------------------------------------------
+
+template <int NW, int RPT, int NT>
+__global__ __launch_bounds__(NT) void gf2_tallskinny_kernel(const u64 *__restrict__ A, long long lda, const u64 *__restrict__ B,
+                                                             long long ldb, u64 *__restrict__ C, long long ldc, int m, int l,
+                                                             int n, int accumulate) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  constexpr int kEntryBytes = 8 * NW;
+  constexpr int kChunksPerGroup = (128 * 1024) / (256 * kEntryBytes);  // 64 / NW chunks = 512 / NW bits of l per group
+  constexpr int kWordsPerGroup = kChunksPerGroup / 8;
+  const int tid = threadIdx.x;
+  const int wl = (l + 63) >> 6, wn = (n + 63) >> 6;
+  const u64 maskL = (l & 63) ? ((1ull << (l & 63)) - 1) : ~0ull;
+  const long long row_base = (long long)blockIdx.x * (NT * RPT);
+  u64 acc[RPT][NW];
+#pragma unroll
+  for (int r = 0; r < RPT; ++r)
+#pragma unroll
+    for (int w = 0; w < NW; ++w) acc[r][w] = 0;
+
+  for (int w0 = 0; w0 < wl; w0 += kWordsPerGroup) {  // group of 64-bit words of the inner dimension
+    const int gw = min(kWordsPerGroup, wl - w0);
+    __syncthreads();  // previous group's lookups are done
+    // stage the group's rows of B (gw*64 rows x NW words, a few KiB) behind the tables, coalesced
+    u64 *bst = reinterpret_cast<u64 *>(lds + 128 * 1024);
+    for (int idx = tid; idx < gw * 64 * NW; idx += NT) {
+      const int rr_ = idx / NW, w = idx % NW;
+      const int brow = w0 * 64 + rr_;
+      bst[idx] = (brow < l && w < wn) ? B[(long long)brow * ldb + w] : 0;
+    }
+    __syncthreads();
+    // build: thread e writes entry e of every chunk table of the group (rows come from LDS as broadcast reads)
+    const int ent_id = tid & 255;
+    for (int c = tid >> 8; c < gw * 8; c += NT / 256) {
+      u64 ent[NW];
+#pragma unroll
+      for (int w = 0; w < NW; ++w) ent[w] = 0;
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const u64 sel = 0ull - (u64)((ent_id >> b) & 1);
+#pragma unroll
+        for (int w = 0; w < NW; ++w) ent[w] ^= bst[(c * 8 + b) * NW + w] & sel;
+      }
+      u64 *dst = reinterpret_cast<u64 *>(lds + (size_t)c * 256 * kEntryBytes + (size_t)ent_id * kEntryBytes);
+#pragma unroll
+      for (int w = 0; w < NW; ++w) dst[w] = ent[w];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      const long long row = row_base + (long long)r * NT + tid;
+      if (row < m) {
+        const u64 *ar = A + row * lda + w0;
+#pragma unroll
+        for (int wq = 0; wq < kWordsPerGroup; ++wq) {
+          if (wq < gw) {
+            u64 aw = ar[wq];
+            if (w0 + wq == wl - 1) aw &= maskL;
+#pragma unroll
+            for (int by = 0; by < 8; ++by) {
+              const unsigned e = (unsigned)(aw >> (8 * by)) & 0xffu;
+              const u64 *tp = reinterpret_cast<const u64 *>(lds + (size_t)(wq * 8 + by) * 256 * kEntryBytes + (size_t)e * kEntryBytes);
+#pragma unroll
+              for (int w = 0; w < NW; ++w) acc[r][w] ^= tp[w];
+            }
+          }
+        }
+      }
+    }
+  }
+  const u64 maskC = (n & 63) ? ((1ull << (n & 63)) - 1) : ~0ull;
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) {
+    const long long row = row_base + (long long)r * NT + tid;
+    if (row < m) {
+#pragma unroll
+      for (int w = 0; w < NW; ++w)
+        if (w < wn) {
+          u64 v = acc[r][w];
+          if (w == wn - 1) v &= maskC;
+          u64 *d = C + row * ldc + w;
+          if (accumulate) v ^= *d;
+          *d = v;
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // v*A kernel: C (m x n) (+)= A (m x l) * B (l x n) for a handful of rows m <= 8 (_mzd_mul_va,
 // mzd.rs:175-181 and `&v * &A`, binary_matrix.rs:552-563).  Streams B once; the inner dimension
 // is split over blockIdx.y and partial sums are combined with 64-bit atomic XOR.
@@ -1226,6 +1322,33 @@ extern "C" hipError_t gf2k_narrow(const u64 *A, long long lda, const u64 *B, lon
     hipLaunchKernelGGL((gf2_narrow_kernel<8>), grid, block, lds, stream, A, lda, B, ldb, C, ldc, m, l, n, accumulate);
   else
     hipLaunchKernelGGL((gf2_narrow_kernel<0>), grid, block, lds, stream, A, lda, B, ldb, C, ldc, m, l, n, accumulate);
+  return hipGetLastError();
+}
+
+// n <= 256; returns hipErrorInvalidValue otherwise
+extern "C" hipError_t gf2k_tallskinny(const u64 *A, long long lda, const u64 *B, long long ldb, u64 *C, long long ldc, int m,
+                                      int l, int n, int accumulate, hipStream_t stream) {
+  if (m <= 0 || n <= 0) return hipSuccess;
+  if (n > 256 || l <= 0) return hipErrorInvalidValue;
+  const int nw = (n + 63) / 64;
+  constexpr int RPT = 4, NT = 1024;
+  const unsigned grid = (unsigned)(((long long)m + NT * RPT - 1) / (NT * RPT));
+  const size_t lds = 128 * 1024 + 8 * 64 * 8;  // tables + staged rows of B (8 words x 64 rows x NW/NW ... = 4 KiB)
+  hipError_t e;
+#define GF2_TS_LAUNCH(NWV)                                                                                             \
+  e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gf2_tallskinny_kernel<NWV, RPT, NT>),                            \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                       \
+  if (e != hipSuccess) return e;                                                                                       \
+  hipLaunchKernelGGL((gf2_tallskinny_kernel<NWV, RPT, NT>), dim3(grid), dim3(NT), lds, stream, A, lda, B, ldb, C, ldc, m, l, n, \
+                     accumulate)
+  if (nw == 1) {
+    GF2_TS_LAUNCH(1);
+  } else if (nw == 2) {
+    GF2_TS_LAUNCH(2);
+  } else {
+    GF2_TS_LAUNCH(4);
+  }
+#undef GF2_TS_LAUNCH
   return hipGetLastError();
 }
 

@@ -412,6 +412,10 @@ static int mul_m4rm_plain(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int
     if (!accumulate) HIP_TRY(gf2k_xor2d(C->data, C->ld, nullptr, 0, nullptr, 0, m, words_of(n), s));
     return 0;
   }
+  if (n <= 256 && m >= 2048 && (n > 64 || l > 64)) {  // tall and skinny: tables over ALL of B, A streamed once
+    HIP_TRY(gf2k_tallskinny(A->data, A->ld, B->data, B->ld, C->data, C->ld, m, l, n, accumulate, s));
+    return 0;
+  }
   if (m <= 8) {  // a handful of rows: stream B once (v*A path, binary_matrix.rs:552-563)
     if (!accumulate) HIP_TRY(gf2k_xor2d(C->data, C->ld, nullptr, 0, nullptr, 0, m, words_of(n), s));
     HIP_TRY(gf2k_va(A->data, A->ld, B->data, B->ld, C->data, C->ld, m, l, n, s));
@@ -528,6 +532,7 @@ static int mul_naive_dev(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int 
   const int m = A->nrows, l = A->ncols, n = B->ncols;
   if (n > 64 || l == 0) return mul_m4rm_plain(C, A, B, accumulate, s);
   if (m == 0 || n == 0) return 0;
+  if (n > 8 && m >= 2048) return mul_m4rm_plain(C, A, B, accumulate, s);  // batch of vectors: table kernel (see there)
   if ((size_t)n * words_of(l) * 8 <= 65536) {  // one launch: B is transposed into LDS by every block
     hipError_t e1 = gf2k_narrow(A->data, A->ld, B->data, B->ld, C->data, C->ld, m, l, n, accumulate, s);
     if (e1 != hipSuccess) return fail(e1, "gf2k_narrow");
