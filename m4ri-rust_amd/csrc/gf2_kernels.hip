@@ -503,9 +503,7 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v3(const gf2k_mul_
       asm("v_xor_b32 %0, %1, %0" : "+v"(acc[st][1]) : "v"(tv[st % G].y));
       asm("v_xor_b32 %0, %1, %0" : "+v"(acc[st][2]) : "v"(tv[st % G].z));
       asm("v_xor_b32 %0, %1, %0" : "+v"(acc[st][3]) : "v"(tv[st % G].w));
-      if constexpr (PRIO != 4) {
-        if constexpr (st + G < STEPS) issue(st + G, tv[st % G]);
-      }
+      if constexpr (st + G < STEPS) issue(st + G, tv[st % G]);
       static_for<WPS>([&](auto ktag) __attribute__((always_inline)) {
         constexpr int k = decltype(ktag)::value;
         constexpr int e = st * WPS + k;
@@ -514,9 +512,6 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v3(const gf2k_mul_
           build_write(std::integral_constant<int, e>{}, tnext{});
         }
       });
-      if constexpr (PRIO == 4) {  // experiment: table write ahead of the read in each step
-        if constexpr (st + G < STEPS) issue(st + G, tv[st % G]);
-      }
       if constexpr (BPACK) {
         if constexpr (st < 2) loadBpacked(i + 2, st, next + 4 * st);
       } else if constexpr (st < 8 && DBG != 3 && DBG != 5 && DBG != 6) {

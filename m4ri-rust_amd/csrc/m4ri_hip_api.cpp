@@ -154,18 +154,6 @@ int get_stream(void *user, hipStream_t *out) {
   return 0;
 }
 
-// scratch buffer that returns to the pool when it goes out of scope; the caller must have
-// synchronised (or ordered on the same stream) every kernel that uses it before that.
-struct Scratch {
-  void *p = nullptr;
-  size_t bytes = 0;
-  int alloc(size_t b) {
-    bytes = b;
-    return dev_alloc(&p, b);
-  }
-  ~Scratch() { dev_free(p, bytes); }
-};
-
 // deferred frees for asynchronous device-API calls: buffers used by work queued on a stream are
 // handed back to the pool only after an event recorded behind that work has completed.
 struct Deferred {
