@@ -323,3 +323,23 @@ def test_split_k_and_small_tile_paths(dev):
         c0 = C0.to_words()
         dev.mul(A, B, C=C0, accumulate=True, algo="m4rm")
         assert np.array_equal(C0.to_words(), c0 ^ ref), (m, l, n, "accumulate")
+
+
+def test_dev_full_size_65536(dev):
+    """BASELINE's metric size on one GPU: Strassen (4 fused levels) over M4RM == plain M4RM == oracle on sampled rows."""
+    n = 65536
+    A, B = dev.DMat.random(n, n, 1), dev.DMat.random(n, n, 2)
+    P_auto = dev.mul(A, B)
+    P_m4rm = dev.mul(A, B, algo="m4rm")
+    assert dev.equal(P_auto, P_m4rm)
+    del P_m4rm
+    # rows of C from the oracle's vector-matrix product: c_i = a_i * B (reads all of B, cheap for a few rows)
+    rows = [0, 12345, 65535]
+    w = n // 64
+    b = g.random_words(n, n, 2)
+    t = np.arange(w, dtype=np.uint64)
+    c = P_auto.to_words()
+    for r in rows:
+        a_r = g.splitmix64(1, np.uint64(r * w) + t).reshape(1, w)
+        ref = g.o_mul_m4rm(np.ascontiguousarray(a_r), b, 1, n, n)
+        assert np.array_equal(c[r:r + 1], ref), r
