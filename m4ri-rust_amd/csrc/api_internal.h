@@ -3,3 +3,7 @@
 [[noreturn]] void gf2_die(const char *msg);
 #include "../../include/m4ri_hip.h"
 mzd_t *gf2_mzd_init_uncleared(rci_t r, rci_t c);  // mzd_init without the memset (callers overwrite every word)
+// GPU-backed transpose of a host matrix (upload, 64x64-block kernel, download); 0 on success.  Used by mzd_transpose
+// for large matrices; the caller falls back to the host routine if it fails (this is not the multiply path).
+int gf2_host_transpose_gpu(mzd_t *dst, mzd_t const *src);
+int gf2_device_count(void);

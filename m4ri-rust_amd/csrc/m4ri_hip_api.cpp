@@ -814,6 +814,22 @@ mzd_t *host_mul(mzd_t *C, const mzd_t *A, const mzd_t *B, int accumulate, int al
 }
 }  // namespace
 
+int gf2_host_transpose_gpu(mzd_t *dst, mzd_t const *src) {
+  if (require_device()) return -1;
+  hipStream_t s;
+  if (get_private_stream(&s)) return -1;
+  DMatOwner dS, dD;
+  int rc = to_device(dS, src, s, true);
+  if (!rc) rc = to_device(dD, dst, s, false);
+  if (!rc) {
+    hipError_t e = gf2k_transpose(dD.d.data, dD.d.ld, dS.d.data, dS.d.ld, src->nrows, src->ncols, s);
+    if (e != hipSuccess) rc = fail(e, "gf2k_transpose");
+  }
+  if (!rc) rc = gf2_dmat_download(dst, &dD.d, s);
+  if (rc) (void)hipStreamSynchronize(s);
+  return rc;
+}
+
 // Strassen levels from M4RI's cutoff argument: recursion continues while the halved dimension stays
 // >= cutoff (strassen.rs:8-18: "Minimal dimension for Strassen recursion"); 0 = library default.
 static int levels_from_cutoff(const mzd_t *A, const mzd_t *B, int cutoff) {

@@ -266,10 +266,19 @@ static inline void transpose64(word x[64]) {
 }
 
 extern "C" mzd_t *mzd_transpose(mzd_t *DST, mzd_t const *A) {
-  if (!DST)
-    DST = mzd_init(A->ncols, A->nrows);
-  else if (DST->nrows != A->ncols || DST->ncols != A->nrows)
-    gf2_die("mzd_transpose: Wrong size for return matrix.");
+  if (DST && (DST->nrows != A->ncols || DST->ncols != A->nrows)) gf2_die("mzd_transpose: Wrong size for return matrix.");
+  // large matrices: PCIe both ways plus the device kernel is ~100x faster than the host loop below
+  static const long long gpu_min_bits = [] {
+    const char *e = std::getenv("M4RI_HIP_TRANSPOSE_GPU_MIN_BITS");
+    return e ? std::atoll(e) : (1ll << 24);
+  }();
+  const bool big = A->nrows > 0 && A->ncols > 0 && (long long)A->nrows * A->ncols >= gpu_min_bits && gf2_device_count() > 0;
+  if (big && !(DST && (DST->flags & mzd_flag_windowed_zerooffset))) {
+    mzd_t *D = DST ? DST : gf2_mzd_init_uncleared(A->ncols, A->nrows);  // every word is overwritten by the download
+    if (gf2_host_transpose_gpu(D, A) == 0) return D;
+    if (!DST) mzd_free(D);
+  }
+  if (!DST) DST = mzd_init(A->ncols, A->nrows);
   if (A->nrows == 0 || A->ncols == 0) return DST;
   word blk[64];
   for (rci_t bi = 0; bi < A->nrows; bi += 64) {

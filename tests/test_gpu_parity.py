@@ -343,3 +343,14 @@ def test_dev_full_size_65536(dev):
         a_r = g.splitmix64(1, np.uint64(r * w) + t).reshape(1, w)
         ref = g.o_mul_m4rm(np.ascontiguousarray(a_r), b, 1, n, n)
         assert np.array_equal(c[r:r + 1], ref), r
+
+
+def test_host_transpose_large_uses_device_and_matches(pkg):
+    """mzd_transpose on big host matrices goes through the device kernel; same bits as the oracle / host routine."""
+    for (r, c) in [(4096, 4100), (5000, 4096), (8192, 8192)]:
+        w = g.random_words(r, c, 41)
+        m = pkg.BinMatrix.from_words(w, c)
+        t = m.transposed()
+        assert t.nrows() == c and t.ncols() == r
+        assert np.array_equal(t.to_words(), g.o_transpose(w, r, c)), (r, c)
+        assert t.transposed() == m

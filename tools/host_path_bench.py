@@ -23,3 +23,10 @@ for n in (4096, 16384, 32768, 65536):
         L.mzd_mul(Cp.mzd, A.mzd, B.mzd, 0)
     dt2 = (time.perf_counter() - t0) / reps
     print(f"n={n}: mzd_mul(NULL,..) {dt*1e3:.1f} ms  preallocated C {dt2*1e3:.1f} ms  -> {2*n**3/dt2/1e12:.1f} Tbit-ops/s end to end; bytes moved {3*n*n/8/1e6:.0f} MB")
+
+import time as _t
+for n in (16384, 65536):
+    A = pkg.BinMatrix.random(n, n)
+    T = A.transposed()
+    t0 = _t.perf_counter(); T = A.transposed(); dt = _t.perf_counter() - t0
+    print(f"n={n}: mzd_transpose end to end {dt*1e3:.1f} ms")
