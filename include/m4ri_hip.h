@@ -160,6 +160,11 @@ int gf2_strassen_levels(int m, int l, int n, int algo, int param);
  * the library keeps one cached arena per device and grows it on demand. */
 size_t gf2_mul_workspace_bytes(int m, int l, int n, int algo, int param);
 
+/* compact binary file format for host matrices ("GF2M", version, nrows, ncols, dense little-endian rows);
+ * 0 / non-NULL on success.  (the reference only serialises to JSON, binary_matrix.rs:10-35) */
+int gf2_mzd_save(const char *path, mzd_t const *M);
+mzd_t *gf2_mzd_load(const char *path);
+
 /* kernel timing for bench.py's roofline object: HIP events recorded on the launch stream
  * around every launch of the dominant multiply kernel while enabled. */
 void gf2_prof_enable(int on);

@@ -93,6 +93,8 @@ _PROTOS = {
     "gf2_transpose_dev": (_I, [DMatP, DMatP, ctypes.c_void_p]),
     "gf2_equal_dev": (_I, [DMatP, DMatP, ctypes.POINTER(_I), ctypes.c_void_p]),
     "gf2_mul_workspace_bytes": (ctypes.c_size_t, [_I, _I, _I, _I, _I]),
+    "gf2_mzd_save": (_I, [ctypes.c_char_p, MzdP]),
+    "gf2_mzd_load": (MzdP, [ctypes.c_char_p]),
     "gf2_prof_enable": (None, [_I]),
     "gf2_prof_read": (_I, [ctypes.POINTER(_I), ctypes.POINTER(ctypes.c_double), _I]),
 }

@@ -392,3 +392,46 @@ extern "C" int m4ri_opt_k(int a, int b, int c) {
   if (k > 16) k = 16;
   return k;
 }
+
+// ---- compact binary wire format (the reference only has one-way serde JSON,
+// m4ri-rust/src/friendly/binary_matrix.rs:10-35) ----
+// file = "GF2M" | u32 version (1) | i32 nrows | i32 ncols | nrows * ceil(ncols/64) little-endian 64-bit words, rows dense,
+// excess bits zero.
+extern "C" int gf2_mzd_save(const char *path, mzd_t const *M) {
+  FILE *f = std::fopen(path, "wb");
+  if (!f) return -1;
+  const uint32_t ver = 1;
+  int ok = std::fwrite("GF2M", 1, 4, f) == 4 && std::fwrite(&ver, 4, 1, f) == 1 && std::fwrite(&M->nrows, 4, 1, f) == 1 &&
+           std::fwrite(&M->ncols, 4, 1, f) == 1;
+  for (rci_t i = 0; ok && i < M->nrows; ++i) {
+    if (M->width > 1) ok = std::fwrite(M->rows[i], sizeof(word), (size_t)M->width - 1, f) == (size_t)M->width - 1;
+    if (ok && M->width) {
+      const word last = M->rows[i][M->width - 1] & M->high_bitmask;
+      ok = std::fwrite(&last, sizeof(word), 1, f) == 1;
+    }
+  }
+  return (std::fclose(f) == 0 && ok) ? 0 : -1;
+}
+
+extern "C" mzd_t *gf2_mzd_load(const char *path) {
+  FILE *f = std::fopen(path, "rb");
+  if (!f) return nullptr;
+  char magic[4];
+  uint32_t ver = 0;
+  rci_t r = 0, c = 0;
+  mzd_t *M = nullptr;
+  if (std::fread(magic, 1, 4, f) == 4 && std::memcmp(magic, "GF2M", 4) == 0 && std::fread(&ver, 4, 1, f) == 1 && ver == 1 &&
+      std::fread(&r, 4, 1, f) == 1 && std::fread(&c, 4, 1, f) == 1 && r >= 0 && c >= 0) {
+    M = mzd_init(r, c);
+    for (rci_t i = 0; M && i < r; ++i) {
+      if (M->width && std::fread(M->rows[i], sizeof(word), (size_t)M->width, f) != (size_t)M->width) {
+        mzd_free(M);
+        M = nullptr;
+      } else if (M->width) {
+        M->rows[i][M->width - 1] &= M->high_bitmask;
+      }
+    }
+  }
+  std::fclose(f);
+  return M;
+}

@@ -204,3 +204,15 @@ def test_product_code_never_touches_the_oracle():
                 assert "gf2_oracle" not in txt and "libgf2oracle" not in txt and "gf2util" not in txt, f
     out = subprocess.check_output(["ldd", os.path.join(ROOT, "m4ri-rust_amd", "lib", "libm4ri_hip.so")], text=True)
     assert "oracle" not in out
+
+
+def test_binary_file_roundtrip(pkg, tmp_path):
+    L = pkg._lib.lib()
+    for (r, c) in [(1, 1), (7, 64), (33, 130), (100, 1000)]:
+        m = pkg.BinMatrix.from_words(g.random_words(r, c, 3), c)
+        path = str(tmp_path / ("m_%d_%d.gf2" % (r, c))).encode()
+        assert L.gf2_mzd_save(path, m.mzd) == 0
+        back = L.gf2_mzd_load(path)
+        assert back and pkg.BinMatrix(back) == m
+        assert os.path.getsize(path) == 16 + r * g.width(c) * 8
+    assert not L.gf2_mzd_load(str(tmp_path / "missing.gf2").encode())
