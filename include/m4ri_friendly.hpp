@@ -152,6 +152,9 @@ class BinMatrix {
   BinMatrix transposed() const { return BinMatrix(mzd_transpose(nullptr, mzd_)); }  // binary_matrix.rs:272-279
   BinMatrix augmented(const BinMatrix &o) const { return BinMatrix(mzd_concat(nullptr, mzd_, o.mzd_)); }
   BinMatrix stacked(const BinMatrix &o) const { return BinMatrix(mzd_stack(nullptr, mzd_, o.mzd_)); }
+  size_t echelonize() { return (size_t)mzd_echelonize(mzd_, 0); }  // binary_matrix.rs:254-261
+  size_t rank() const { return BinMatrix(*this).echelonize(); }    // binary_matrix.rs:246-252
+  BinMatrix inverted() const { return BinMatrix(mzd_inv_m4ri(nullptr, mzd_, 0)); }  // :263-268, NULL -> "Can't be NULL"
   uint32_t count_ones() const {  // binary_matrix.rs:172-189
     if (!(nrows() == 1 || ncols() == 1)) throw Panic("only works on single row or single column matrices");
     uint32_t c = 0;
@@ -205,6 +208,8 @@ class BinMatrix {
 
 inline BinMatrix BinVector::as_matrix() const { return BinMatrix::new_({*this}); }
 inline BinMatrix BinVector::as_column_matrix() const { return as_matrix().transposed(); }
+// Solve A X = B, B modified in place; true if it succeeded (binary_matrix.rs:575-586; `a` is consumed there)
+inline bool solve_left(BinMatrix a, BinMatrix &b) { return mzd_solve_left(a.raw(), b.raw(), 0, 1) == 0; }
 // impl Mul<&BinMatrix> for &BinVector: v^T * A (binary_matrix.rs:552-563)
 inline BinVector operator*(const BinVector &v, const BinMatrix &a) { return (v.as_matrix() * a).as_vector(); }
 

@@ -113,6 +113,23 @@ mzd_t *_mzd_mul_naive(mzd_t *C, mzd_t const *A, mzd_t const *Bt, int clear);
 /* C (+)= v*A, v a 1 x l row. mzd.rs:175-181 */
 mzd_t *_mzd_mul_va(mzd_t *C, mzd_t const *v, mzd_t const *A, int clear);
 
+/* -- elimination: blocked Gauss-Jordan on the device, trailing updates through the
+ *    multiply kernel.  Each call uploads the matrix, works device-resident, and downloads the result. -- */
+/* (Reduced) row echelon form in place; full != 0 -> reduced form (unique), full == 0 -> an upper echelon form with
+ * the same pivot columns and row space (row contents then depend on the algorithm, as between M4RI's own variants).
+ * Returns the rank.  echelonform.rs:9-16; caller binary_matrix.rs:258-261 (BinMatrix::echelonize, rank :250-252) */
+rci_t mzd_echelonize(mzd_t *A, int full);
+/* same contract; k (table size of the CPU algorithm) is accepted and ignored. echelonform.rs:29-37 */
+rci_t mzd_echelonize_m4ri(mzd_t *A, int full, int k);
+/* same contract. echelonform.rs:18-27 */
+rci_t mzd_echelonize_pluq(mzd_t *A, int full);
+/* dst = src^-1 (dst NULL -> allocated); NULL if src is singular. brilliantrussian.rs:201-208; caller binary_matrix.rs:265-268 */
+mzd_t *mzd_inv_m4ri(mzd_t *dst, mzd_t const *src, int k);
+/* Solve A X = B.  A is m x n, B has >= max(m, n) rows and holds the right-hand side in its first m rows; on return its
+ * first n rows hold X (free variables 0) and the remaining rows are 0; A is overwritten (by its reduced echelon form).
+ * Returns 0, or -1 if inconsistency_check != 0 and the system has no solution. solve.rs:12-29; caller binary_matrix.rs:582-586 */
+int mzd_solve_left(mzd_t *A, mzd_t *B, int cutoff, int inconsistency_check);
+
 /* ===================================================================================== */
 /* 2. Device-resident API                                                                 */
 /* ===================================================================================== */
@@ -153,6 +170,13 @@ int gf2_mul_nt_dev(gf2_dmat *C, gf2_dmat const *A, gf2_dmat const *Bt, int accum
 int gf2_add_dev(gf2_dmat *C, gf2_dmat const *A, gf2_dmat const *B, void *stream);
 int gf2_transpose_dev(gf2_dmat *D, gf2_dmat const *S, void *stream);
 int gf2_equal_dev(gf2_dmat const *A, gf2_dmat const *B, int *equal, void *stream);
+
+/* In-place echelon form of the first ncols_limit columns (0 = all) of a device matrix; the remaining columns follow
+ * the row operations (augmented systems).  *rank receives the rank, pivot_cols (host, may be NULL, >= min(rows, limit)
+ * ints) the pivot columns.  Synchronous. */
+int gf2_echelonize_dev(gf2_dmat *A, int full, int ncols_limit, int *rank, int *pivot_cols, void *stream);
+/* Ainv = A^-1 for square A; *singular = 1 (Ainv untouched) if A has no inverse.  Synchronous. */
+int gf2_inverse_dev(gf2_dmat *Ainv, gf2_dmat const *A, int *singular, void *stream);
 
 /* Strassen levels the library will use for this shape (0 = plain M4RM) */
 int gf2_strassen_levels(int m, int l, int n, int algo, int param);

@@ -69,6 +69,11 @@ _PROTOS = {
     "mzd_row_swap": (None, [MzdP, _I, _I]),
     "mzd_copy_row": (None, [MzdP, _I, MzdP, _I]),
     "m4ri_opt_k": (_I, [_I, _I, _I]),
+    "mzd_echelonize": (_I, [MzdP, _I]),
+    "mzd_echelonize_m4ri": (_I, [MzdP, _I, _I]),
+    "mzd_echelonize_pluq": (_I, [MzdP, _I]),
+    "mzd_inv_m4ri": (MzdP, [MzdP, MzdP, _I]),
+    "mzd_solve_left": (_I, [MzdP, MzdP, _I, _I]),
     "mzd_mul_m4rm": (MzdP, [MzdP, MzdP, MzdP, _I]),
     "mzd_addmul_m4rm": (MzdP, [MzdP, MzdP, MzdP, _I]),
     "mzd_mul": (MzdP, [MzdP, MzdP, MzdP, _I]),
@@ -92,6 +97,8 @@ _PROTOS = {
     "gf2_add_dev": (_I, [DMatP, DMatP, DMatP, ctypes.c_void_p]),
     "gf2_transpose_dev": (_I, [DMatP, DMatP, ctypes.c_void_p]),
     "gf2_equal_dev": (_I, [DMatP, DMatP, ctypes.POINTER(_I), ctypes.c_void_p]),
+    "gf2_echelonize_dev": (_I, [DMatP, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.c_void_p]),
+    "gf2_inverse_dev": (_I, [DMatP, DMatP, ctypes.POINTER(_I), ctypes.c_void_p]),
     "gf2_mul_workspace_bytes": (ctypes.c_size_t, [_I, _I, _I, _I, _I]),
     "gf2_mzd_save": (_I, [ctypes.c_char_p, MzdP]),
     "gf2_mzd_load": (MzdP, [ctypes.c_char_p]),

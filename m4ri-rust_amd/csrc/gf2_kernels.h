@@ -21,7 +21,32 @@ struct gf2k_mul_args {
   int bp_nc;           // chunk blocks per tile column in Bp
 };
 
+// Device-side record of a blocked elimination (gf2_elim.hip): the kernels of a step read their ranges from it, so a
+// whole column block is enqueued without host round trips.
+struct gf2k_elim_state {
+  int r0;     // rank when the current column block started
+  int r_cur;  // rank so far: rows [0, r_cur) hold the pivots found, in pivot-column order
+  int np;     // pivots found by the current step (one 64-bit word of columns)
+  int nmoves;
+  int jbase;  // r_cur - r0 before the current step: index of its first pivot inside the block
+  int pad_;
+  unsigned long long pcmask;   // pivot columns of the current word
+  int piv_row[64];             // row that holds pivot k (k in pivot-column order)
+  int piv_col[64];             // its bit position inside the word
+  unsigned long long trk[64];  // reduced pivot row k = XOR of the rows piv_row[k'] for k' in trk[k]
+  int mv_src[128], mv_dst[128], mv_piv[128];  // row moves of the step (mv_piv >= 0: the source is pivot mv_piv)
+};
+
 extern "C" {
+hipError_t gf2k_elim_begin_block(gf2k_elim_state *st, hipStream_t s);
+hipError_t gf2k_elim_step(uint64_t *A, long long lda, int m, long long aw, long long c0w, int sw, int j, uint64_t colmask,
+                          int full, uint64_t *U, long long ldu, int uw, gf2k_elim_state *st, int *pivcols, uint64_t *ptab,
+                          uint64_t *tmp, long long tld, hipStream_t s);
+hipError_t gf2k_elim_toggle(uint64_t *U, long long ldu, int max_rank, gf2k_elim_state *st, hipStream_t s);
+hipError_t gf2k_set_diag(uint64_t *M, long long ld, int n, long long col0, hipStream_t s);
+hipError_t gf2k_scatter_rows(uint64_t *X, long long ldx, const uint64_t *R, long long ldr, int words, const int *pivcols,
+                             int rank, hipStream_t s);
+hipError_t gf2k_any_nonzero(const uint64_t *M, long long ld, int row_lo, int rows, int words, int *flag, hipStream_t s);
 int gf2k_m4rm_rows_per_tile(int cfg);
 hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream);
 hipError_t gf2k_dbg_sec(unsigned long long *out8);

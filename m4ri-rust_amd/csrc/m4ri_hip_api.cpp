@@ -899,3 +899,262 @@ extern "C" mzd_t *_mzd_mul_va(mzd_t *C, mzd_t const *v, mzd_t const *A, int clea
   if (!C) gf2_die("_mzd_mul_va: C must be preallocated.");
   return host_mul(C, v, A, clear == 0, GF2_ALGO_M4RM, 0, "_mzd_mul_va");
 }
+
+// ---------------------------------------------------------------------------------------------
+// elimination: echelon forms, inverse, linear systems (kernels in gf2_elim.hip)
+//   mzd_echelonize / _m4ri / _pluq   m4ri-sys/src/echelonform.rs:16-37, caller binary_matrix.rs:258-261
+//   mzd_inv_m4ri                     m4ri-sys/src/brilliantrussian.rs:201-208, caller binary_matrix.rs:265-268
+//   mzd_solve_left                   m4ri-sys/src/solve.rs:12-29, caller binary_matrix.rs:582-586
+// ---------------------------------------------------------------------------------------------
+
+namespace {
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  int alloc(size_t b) {
+    bytes = b ? b : 8;
+    return dev_alloc(&p, bytes);
+  }
+  ~DevBuf() { dev_free(p, bytes); }
+  template <class T>
+  T *as() const { return static_cast<T *>(p); }
+};
+
+// In-place echelon form of the first `col_limit` columns of A (0 = all); row operations act on whole rows, so the
+// columns beyond the limit carry an augmented right-hand side along.  full != 0: reduced row echelon form (unique);
+// full == 0: pivot rows are only cleared below their column block.  Synchronous.  pivcols_dev (optional) receives a
+// device array of the pivot columns that stays valid until `keep` is destroyed.
+int echelonize_dev(gf2_dmat *A, int full, int col_limit, int *rank_out, int *pivcols_host, DevBuf *pivcols_keep,
+                   hipStream_t s) {
+  const int m = A->nrows, ncols = A->ncols;
+  const int limit = (col_limit > 0 && col_limit < ncols) ? col_limit : ncols;
+  *rank_out = 0;
+  if (m == 0 || limit == 0) return 0;
+  const int kbw_env = env_int("M4RI_HIP_ELIM_BLOCK_WORDS", 32);  // read per call: tests shrink it
+  const int KBW = kbw_env < 1 ? 1 : (kbw_env > 32 ? 32 : kbw_env);
+  const long long aw = words_of(ncols), lw = words_of(limit), lda = A->ld;
+  const int uw = KBW;
+  const int max_rank = m < limit ? m : limit;
+  const long long pld = (aw + 1) & ~1ll, tld = aw + uw;
+  const int prow_max = m < KBW * 64 ? m : KBW * 64;
+
+  DevBuf st, pivs, U, ptab, tmp, P;
+  DevBuf &pv = pivcols_keep ? *pivcols_keep : pivs;
+  if (int rc = st.alloc(sizeof(gf2k_elim_state))) return rc;
+  if (int rc = pv.alloc((size_t)(max_rank + 64) * sizeof(int))) return rc;
+  if (int rc = U.alloc((size_t)m * uw * sizeof(u64))) return rc;
+  if (int rc = ptab.alloc(64 * 64 * sizeof(u64))) return rc;
+  if (int rc = tmp.alloc((size_t)128 * tld * sizeof(u64))) return rc;
+  if (int rc = P.alloc((size_t)prow_max * pld * sizeof(u64))) return rc;
+  gf2k_elim_state *dst = st.as<gf2k_elim_state>();
+  HIP_TRY(hipMemsetAsync(dst, 0, sizeof(gf2k_elim_state), s));
+
+  int r_cur = 0;
+  for (long long c0w = 0; c0w < lw && r_cur < m; c0w += KBW) {
+    const int sw = (int)(lw - c0w < KBW ? lw - c0w : KBW);
+    HIP_TRY(hipMemsetAsync(U.p, 0, (size_t)m * uw * sizeof(u64), s));
+    HIP_TRY(gf2k_elim_begin_block(dst, s));
+    for (int j = 0; j < sw; ++j) {
+      const bool last = (c0w + j == lw - 1) && (limit & 63);
+      const u64 colmask = last ? ((1ull << (limit & 63)) - 1) : ~0ull;
+      HIP_TRY(gf2k_elim_step(A->data, lda, m, aw, c0w, sw, j, colmask, full, U.as<u64>(), uw, uw, dst, pv.as<int>(),
+                             ptab.as<u64>(), tmp.as<u64>(), tld, s));
+    }
+    HIP_TRY(gf2k_elim_toggle(U.as<u64>(), uw, prow_max, dst, s));
+    int head[2] = {0, 0};  // r0, r_cur
+    HIP_TRY(hipMemcpyAsync(head, dst, sizeof(head), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const int r0 = head[0], rp = head[1] - head[0];
+    r_cur = head[1];
+    const long long cR = c0w + sw;
+    if (rp > 0 && cR < aw) {
+      // everything right of the block in one product: A[rows, right] ^= U'[rows, 0:rp] * (pivot rows of the block)
+      const int rows_lo = full ? 0 : r0;
+      const int nright = ncols - (int)(cR * 64);
+      HIP_TRY(hipMemcpy2DAsync(P.p, (size_t)pld * sizeof(u64), A->data + (long long)r0 * lda + cR, (size_t)lda * sizeof(u64),
+                               (size_t)(aw - cR) * sizeof(u64), rp, hipMemcpyDeviceToDevice, s));
+      gf2_dmat Cw{A->data + (long long)rows_lo * lda + cR, lda, m - rows_lo, nright};
+      gf2_dmat Uw{U.as<u64>() + (long long)rows_lo * uw, uw, m - rows_lo, rp};
+      gf2_dmat Pw{P.as<u64>(), pld, rp, nright};
+      if (int rc = mul_m4rm_plain(&Cw, &Uw, &Pw, 1, s)) return rc;
+    }
+  }
+  *rank_out = r_cur;
+  if (pivcols_host && r_cur > 0)
+    HIP_TRY(hipMemcpyAsync(pivcols_host, pv.p, (size_t)r_cur * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+}  // namespace
+
+extern "C" int gf2_echelonize_dev(gf2_dmat *A, int full, int ncols_limit, int *rank, int *pivot_cols, void *stream) {
+  if (int rc = require_device()) return rc;
+  if (!A || !A->data || !rank) return fail_msg("gf2_echelonize_dev: null argument");
+  if (A->ld < words_of(A->ncols)) return fail_msg("gf2_echelonize_dev: row stride smaller than row width");
+  hipStream_t s;
+  if (int rc = get_stream(stream, &s)) return rc;
+  std::lock_guard<std::mutex> lk(g_enqueue_mu);
+  return echelonize_dev(A, full, ncols_limit, rank, pivot_cols, nullptr, s);
+}
+
+// [ A | 0-pad to a word boundary | I ] -> reduced echelon form of the left part; singular unless rank == n
+static int inverse_dev(gf2_dmat *Ainv, const u64 *Adata, long long lda, bool a_on_host, int n, int *singular, hipStream_t s) {
+  const int nw = words_of(n);
+  gf2_dmat T{nullptr, dev_ld_for(nw * 64 + n), n, nw * 64 + n};
+  DevBuf tb;
+  if (int rc = tb.alloc((size_t)n * T.ld * sizeof(u64))) return rc;
+  T.data = tb.as<u64>();
+  HIP_TRY(hipMemsetAsync(T.data, 0, (size_t)n * T.ld * sizeof(u64), s));
+  HIP_TRY(hipMemcpy2DAsync(T.data, (size_t)T.ld * sizeof(u64), Adata, (size_t)lda * sizeof(u64), (size_t)nw * sizeof(u64), n,
+                           a_on_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s));
+  HIP_TRY(gf2k_set_diag(T.data, T.ld, n, (long long)nw * 64, s));
+  int rank = 0;
+  if (int rc = echelonize_dev(&T, 1, n, &rank, nullptr, nullptr, s)) return rc;
+  *singular = rank < n;
+  if (rank == n) {
+    HIP_TRY(hipMemcpy2DAsync(Ainv->data, (size_t)Ainv->ld * sizeof(u64), T.data + nw, (size_t)T.ld * sizeof(u64),
+                             (size_t)nw * sizeof(u64), n, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  return 0;
+}
+
+extern "C" int gf2_inverse_dev(gf2_dmat *Ainv, gf2_dmat const *A, int *singular, void *stream) {
+  if (int rc = require_device()) return rc;
+  if (!Ainv || !A || !singular || !A->data || !Ainv->data) return fail_msg("gf2_inverse_dev: null argument");
+  if (A->nrows != A->ncols || Ainv->nrows != A->nrows || Ainv->ncols != A->ncols)
+    return fail_msg("gf2_inverse_dev: matrices must be square and of equal size");
+  hipStream_t s;
+  if (int rc = get_stream(stream, &s)) return rc;
+  *singular = 0;
+  if (A->nrows == 0) return 0;
+  std::lock_guard<std::mutex> lk(g_enqueue_mu);
+  return inverse_dev(Ainv, A->data, A->ld, false, A->nrows, singular, s);
+}
+
+static int host_echelonize(mzd_t *A, int full, const char *name) {
+  if (A->nrows == 0 || A->ncols == 0) return 0;
+  auto bail = [&](const char *why) {
+    std::fprintf(stderr, "m4ri_hip: %s failed: %s (%s)\n", name, why, gf2_last_error());
+    std::abort();  // the M4RI signature has no error channel (returns the rank)
+    return 0;
+  };
+  if (require_device()) return bail("no device");
+  hipStream_t s;
+  if (get_private_stream(&s)) return bail("stream");
+  int rank = 0, rc;
+  {
+    DMatOwner dA;
+    rc = to_device(dA, A, s, true);
+    if (!rc) rc = echelonize_dev(&dA.d, full, 0, &rank, nullptr, nullptr, s);
+    if (!rc) rc = gf2_dmat_download(A, &dA.d, s);
+    if (rc) (void)hipStreamSynchronize(s);
+  }
+  if (rc) return bail("device elimination");
+  return rank;
+}
+
+extern "C" rci_t mzd_echelonize(mzd_t *A, int full) { return host_echelonize(A, full, "mzd_echelonize"); }
+extern "C" rci_t mzd_echelonize_m4ri(mzd_t *A, int full, int k) {
+  (void)k;  // table size hint of the CPU algorithm
+  return host_echelonize(A, full, "mzd_echelonize_m4ri");
+}
+extern "C" rci_t mzd_echelonize_pluq(mzd_t *A, int full) { return host_echelonize(A, full, "mzd_echelonize_pluq"); }
+
+extern "C" mzd_t *mzd_inv_m4ri(mzd_t *dst, mzd_t const *src, int k) {
+  (void)k;
+  if (src->nrows != src->ncols) gf2_die("mzd_inv_m4ri: matrix must be square.");
+  if (dst && (dst->nrows != src->nrows || dst->ncols != src->ncols)) gf2_die("mzd_inv_m4ri: dst has wrong dimensions.");
+  auto bail = [&](const char *why) -> mzd_t * {
+    std::fprintf(stderr, "m4ri_hip: mzd_inv_m4ri failed: %s (%s)\n", why, gf2_last_error());
+    return nullptr;
+  };
+  if (require_device()) return bail("no device");
+  const int n = src->nrows;
+  if (n == 0) return dst ? dst : mzd_init(0, 0);
+  hipStream_t s;
+  if (get_private_stream(&s)) return bail("stream");
+  int rc, singular = 0;
+  const bool allocated = dst == nullptr;
+  if (!dst) dst = gf2_mzd_init_uncleared(n, n);
+  {
+    DMatOwner dI;
+    rc = to_device(dI, dst, s, false);
+    if (!rc) rc = inverse_dev(&dI.d, src->rows[0], src->rowstride, true, n, &singular, s);
+    if (!rc && !singular) rc = gf2_dmat_download(dst, &dI.d, s);
+    if (rc) (void)hipStreamSynchronize(s);
+  }
+  if (rc || singular) {
+    if (allocated) mzd_free(dst);
+    if (rc) return bail("device elimination");
+    return nullptr;  // not invertible: no inverse to return (callers see NULL; BinMatrix::inverted panics "Can't be NULL")
+  }
+  return dst;
+}
+
+extern "C" int mzd_solve_left(mzd_t *A, mzd_t *B, int cutoff, int inconsistency_check) {
+  (void)cutoff;
+  if (A->ncols > B->nrows) gf2_die("mzd_solve_left: A ncols must be smaller than B nrows.");
+  if (A->nrows > B->nrows) gf2_die("mzd_solve_left: A nrows must be smaller than B nrows.");
+  const int m = A->nrows, n = A->ncols, kb = B->ncols;
+  if (m == 0 || n == 0 || kb == 0) return 0;
+  auto bail = [&](const char *why) {
+    std::fprintf(stderr, "m4ri_hip: mzd_solve_left failed: %s (%s)\n", why, gf2_last_error());
+    std::abort();  // -1 means "inconsistent" in this signature; a device failure is not that
+    return -1;
+  };
+  if (require_device()) return bail("no device");
+  hipStream_t s;
+  if (get_private_stream(&s)) return bail("stream");
+  const int nw = words_of(n), bw = words_of(kb);
+  int rc = 0, inconsistent = 0;
+  do {
+    // T = [ A | pad | B[0:m] ]
+    gf2_dmat T{nullptr, dev_ld_for(nw * 64 + kb), m, nw * 64 + kb};
+    DevBuf tb, xb, flag, pivs;
+    if ((rc = tb.alloc((size_t)m * T.ld * sizeof(u64)))) break;
+    T.data = tb.as<u64>();
+    hipError_t e = hipMemsetAsync(T.data, 0, (size_t)m * T.ld * sizeof(u64), s);
+    if (e == hipSuccess)
+      e = hipMemcpy2DAsync(T.data, (size_t)T.ld * sizeof(u64), A->rows[0], (size_t)A->rowstride * sizeof(word),
+                           (size_t)nw * sizeof(u64), m, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess)
+      e = hipMemcpy2DAsync(T.data + nw, (size_t)T.ld * sizeof(u64), B->rows[0], (size_t)B->rowstride * sizeof(word),
+                           (size_t)bw * sizeof(u64), m, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) {
+      rc = fail(e, "mzd_solve_left: upload");
+      break;
+    }
+    int rank = 0;
+    if ((rc = echelonize_dev(&T, 1, n, &rank, nullptr, &pivs, s))) break;
+    if (inconsistency_check && rank < m) {
+      if ((rc = flag.alloc(sizeof(int)))) break;
+      e = hipMemsetAsync(flag.p, 0, sizeof(int), s);
+      if (e == hipSuccess) e = gf2k_any_nonzero(T.data + nw, T.ld, rank, m, bw, flag.as<int>(), s);
+      if (e == hipSuccess) e = hipMemcpyAsync(&inconsistent, flag.p, sizeof(int), hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess) e = hipStreamSynchronize(s);
+      if (e != hipSuccess) {
+        rc = fail(e, "mzd_solve_left: consistency check");
+        break;
+      }
+    }
+    // X[pivot column k] = reduced right-hand side row k; free variables are 0; rows n.. of B are cleared
+    gf2_dmat X{nullptr, dev_ld_for(kb), B->nrows, kb};
+    if ((rc = xb.alloc((size_t)B->nrows * X.ld * sizeof(u64)))) break;
+    X.data = xb.as<u64>();
+    e = hipMemsetAsync(X.data, 0, (size_t)B->nrows * X.ld * sizeof(u64), s);
+    if (e == hipSuccess) e = gf2k_scatter_rows(X.data, X.ld, T.data + nw, T.ld, bw, pivs.as<int>(), rank, s);
+    if (e != hipSuccess) {
+      rc = fail(e, "mzd_solve_left: solution rows");
+      break;
+    }
+    if ((rc = gf2_dmat_download(B, &X, s))) break;
+    gf2_dmat Ared{T.data, T.ld, m, n};  // "A Input matrix (overwritten)": left holding its reduced echelon form
+    if ((rc = gf2_dmat_download(A, &Ared, s))) break;
+  } while (0);
+  if (rc) {
+    (void)hipStreamSynchronize(s);
+    return bail("device elimination");
+  }
+  return inconsistent ? -1 : 0;
+}

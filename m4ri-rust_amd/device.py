@@ -124,6 +124,25 @@ def equal(A, B, stream=None):
     return bool(out.value)
 
 
+def echelonize(A, full=True, ncols_limit=0, stream=None):
+    """In-place (reduced) row echelon form of the first ncols_limit columns (0 = all) -> (rank, pivot columns)."""
+    rank = ctypes.c_int(0)
+    cap = min(A.nrows, ncols_limit if 0 < ncols_limit < A.ncols else A.ncols)
+    piv = (ctypes.c_int * max(cap, 1))()
+    _lib.check(_lib.lib().gf2_echelonize_dev(ctypes.byref(A.s), int(bool(full)), int(ncols_limit), ctypes.byref(rank), piv,
+                                             stream), "gf2_echelonize_dev")
+    return rank.value, list(piv[:rank.value])
+
+
+def inverse(A, stream=None):
+    """A^-1 as a new DMat, or None if A is singular."""
+    out = DMat(A.nrows, A.ncols)
+    singular = ctypes.c_int(0)
+    _lib.check(_lib.lib().gf2_inverse_dev(ctypes.byref(out.s), ctypes.byref(A.s), ctypes.byref(singular), stream),
+               "gf2_inverse_dev")
+    return None if singular.value else out
+
+
 def prof_enable(on):
     _lib.lib().gf2_prof_enable(int(on))
 

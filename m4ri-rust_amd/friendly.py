@@ -329,11 +329,21 @@ class BinMatrix:
             return self.transposed().as_vector()
         return BinVector(self.to_words()[0], self.ncols())
 
-    # -- out of scope on this path (elimination, not multiply): SURVEY.md section 2 rows 8-11 --
+    # -- elimination --
     def rank(self):
-        raise NotImplementedError("rank/echelonize are outside the multiply hot path (SURVEY.md section 8)")
+        """binary_matrix.rs:246-252: echelonizes a clone and throws it away."""
+        return self.clone().echelonize()
 
-    echelonize = inverted = rank
+    def echelonize(self, full=False):
+        """In place; returns the rank (binary_matrix.rs:254-261, which passes full = false)."""
+        return int(_lib.lib().mzd_echelonize(self.mzd, 1 if full else 0))
+
+    def inverted(self):
+        """binary_matrix.rs:263-268: a NULL result (singular matrix) panics with "Can't be NULL"."""
+        ptr = _lib.lib().mzd_inv_m4ri(None, self.mzd, 0)
+        if not ptr:
+            raise PanicError("Can't be NULL")
+        return BinMatrix(ptr)
 
     # -- products --
     def mul_slice(self, other):
@@ -369,5 +379,8 @@ class BinMatrix:
         return "BinMatrix(%dx%d)" % (self.nrows(), self.ncols())
 
 
-def solve_left(_a, _b):
-    raise NotImplementedError("mzd_solve_left is outside the multiply hot path (SURVEY.md section 8f)")
+def solve_left(a, b):
+    """Solve A X = B; b is modified in place and holds X afterwards; True if it succeeded (binary_matrix.rs:575-586).
+
+    The reference consumes `a`; here it is left holding its reduced echelon form."""
+    return _lib.lib().mzd_solve_left(a.mzd, b.mzd, 0, 1) == 0

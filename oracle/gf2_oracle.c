@@ -393,3 +393,70 @@ static void fast_rec(u64 *C, int ldc, const u64 *A, int lda, const u64 *B, int l
 void oracle_mul_fast(u64 *C, int ldc, const u64 *A, int lda, const u64 *B, int ldb, int m, int l, int n) {
   fast_rec(C, ldc, A, lda, B, ldb, m, l, n);
 }
+
+/* ---- elimination -------------------------------------------------------------------------- */
+
+int oracle_echelonize(u64 *M, int ld, int nrows, int ncols, int limit, int full, int *pivcols) {
+  const int w = (ncols + 63) / 64;
+  if (limit <= 0 || limit > ncols) limit = ncols;
+  int r = 0;
+  for (int c = 0; c < limit && r < nrows; ++c) {
+    const int cw = c >> 6;
+    const u64 bit = 1ull << (c & 63);
+    int p = -1;
+    for (int i = r; i < nrows; ++i)
+      if (M[(size_t)i * ld + cw] & bit) {
+        p = i;
+        break;
+      }
+    if (p < 0) continue;
+    if (p != r)
+      for (int j = 0; j < w; ++j) {
+        const u64 t = M[(size_t)p * ld + j];
+        M[(size_t)p * ld + j] = M[(size_t)r * ld + j];
+        M[(size_t)r * ld + j] = t;
+      }
+    const u64 *pr = M + (size_t)r * ld;
+    for (int i = full ? 0 : r + 1; i < nrows; ++i)
+      if (i != r && (M[(size_t)i * ld + cw] & bit)) {
+        u64 *row = M + (size_t)i * ld;
+        for (int j = cw; j < w; ++j) row[j] ^= pr[j]; /* the pivot row is zero left of its pivot */
+      }
+    if (pivcols) pivcols[r] = c;
+    ++r;
+  }
+  return r;
+}
+
+int oracle_inverse(u64 *Ainv, int ldi, const u64 *A, int lda, int n) {
+  const int nw = (n + 63) / 64, tw = 2 * nw;
+  u64 *T = (u64 *)calloc((size_t)n * tw, sizeof(u64));
+  for (int i = 0; i < n; ++i) {
+    memcpy(T + (size_t)i * tw, A + (size_t)i * lda, (size_t)nw * sizeof(u64));
+    T[(size_t)i * tw + nw + (i >> 6)] |= 1ull << (i & 63);
+  }
+  const int rank = oracle_echelonize(T, tw, n, nw * 64 + n, n, 1, NULL);
+  if (rank == n)
+    for (int i = 0; i < n; ++i) memcpy(Ainv + (size_t)i * ldi, T + (size_t)i * tw + nw, (size_t)nw * sizeof(u64));
+  free(T);
+  return rank == n ? 0 : -1;
+}
+
+int oracle_solve_left(const u64 *A, int lda, int m, int n, u64 *B, int ldb, int brows, int k) {
+  const int nw = (n + 63) / 64, kw = (k + 63) / 64, tw = nw + kw;
+  u64 *T = (u64 *)calloc((size_t)m * tw, sizeof(u64));
+  int *piv = (int *)malloc(sizeof(int) * (size_t)(m < n ? m : n) + sizeof(int));
+  for (int i = 0; i < m; ++i) {
+    memcpy(T + (size_t)i * tw, A + (size_t)i * lda, (size_t)nw * sizeof(u64));
+    memcpy(T + (size_t)i * tw + nw, B + (size_t)i * ldb, (size_t)kw * sizeof(u64));
+  }
+  const int rank = oracle_echelonize(T, tw, m, nw * 64 + k, n, 1, piv);
+  int bad = 0;
+  for (int i = rank; i < m; ++i)
+    for (int j = 0; j < kw; ++j) bad |= T[(size_t)i * tw + nw + j] != 0;
+  for (int i = 0; i < brows; ++i) memset(B + (size_t)i * ldb, 0, (size_t)kw * sizeof(u64));
+  for (int r = 0; r < rank; ++r) memcpy(B + (size_t)piv[r] * ldb, T + (size_t)r * tw + nw, (size_t)kw * sizeof(u64));
+  free(T);
+  free(piv);
+  return bad ? -1 : 0;
+}

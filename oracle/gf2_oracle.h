@@ -80,6 +80,22 @@ void oracle_add(uint64_t *C, int ldc, const uint64_t *A, int lda, const uint64_t
 void oracle_mul_fast(uint64_t *C, int ldc, const uint64_t *A, int lda, const uint64_t *B, int ldb,
                      int m, int l, int n);
 
+/* ---- elimination ------------------------------------------------
+ * Textbook Gauss(-Jordan) over GF(2), the semantics documented at echelonform.rs:9-16: pivots are searched
+ * column by column, the first row at or below the current rank with a 1 is swapped up.  full != 0 clears the
+ * pivot column in every other row (reduced row echelon form: unique, so any correct implementation agrees bit for
+ * bit); full == 0 clears it below only (the row contents then depend on the algorithm, M4RI's variants differ
+ * among themselves; only rank, pivot columns and row space are comparable).
+ * Only the first `limit` columns (0 = all) are searched for pivots; the others follow the row operations.
+ * pivcols (may be NULL) receives the pivot columns.  Returns the rank.
+ * PARITY UNPINNED by the reference: it holds no test for rank/echelonize/inverted/solve_left. */
+int oracle_echelonize(uint64_t *M, int ld, int nrows, int ncols, int limit, int full, int *pivcols);
+/* mzd_inv_m4ri (brilliantrussian.rs:201-208): Ainv = A^-1, returns 0; returns -1 if A is singular. */
+int oracle_inverse(uint64_t *Ainv, int ldi, const uint64_t *A, int lda, int n);
+/* mzd_solve_left (solve.rs:12-29) for A (m x n), B (brows >= max(m,n) rows, k columns, right-hand side in the
+ * first m rows): B's first n rows become X with free variables 0, the rest 0.  Returns 0, or -1 if inconsistent. */
+int oracle_solve_left(const uint64_t *A, int lda, int m, int n, uint64_t *B, int ldb, int brows, int k);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,12 @@ def oracle():
         lib.oracle_add.argtypes = [_U64P, _I, _U64P, _I, _U64P, _I, _I, _I]
         lib.oracle_opt_k.argtypes = [_I, _I, _I]
         lib.oracle_opt_k.restype = _I
+        lib.oracle_echelonize.argtypes = [_U64P, _I, _I, _I, _I, _I, ctypes.POINTER(_I)]
+        lib.oracle_echelonize.restype = _I
+        lib.oracle_inverse.argtypes = [_U64P, _I, _U64P, _I, _I]
+        lib.oracle_inverse.restype = _I
+        lib.oracle_solve_left.argtypes = [_U64P, _I, _I, _I, _U64P, _I, _I, _I]
+        lib.oracle_solve_left.restype = _I
         for f in ("oracle_fill_random", "oracle_mul_bits", "oracle_mul_naive", "oracle_mul_fast",
                   "oracle_mul_naive_t", "oracle_mul_m4rm", "oracle_mul_strassen", "oracle_mul_va",
                   "oracle_transpose", "oracle_add"):
@@ -144,3 +150,27 @@ def o_transpose(a, nrows, ncols):
     d = np.zeros((ncols, width(nrows)), dtype=np.uint64)
     oracle().oracle_transpose(ptr(d), d.shape[1], ptr(a), a.shape[1], nrows, ncols)
     return d
+
+
+def o_echelonize(a, nrows, ncols, full=True, limit=0):
+    """-> (echelon form, rank, pivot columns) of a copy of `a` (oracle_echelonize)."""
+    m = np.ascontiguousarray(a).copy()
+    piv = (ctypes.c_int * (min(nrows, ncols) + 1))()
+    rank = oracle().oracle_echelonize(ptr(m), m.shape[1], nrows, ncols, limit, 1 if full else 0, piv)
+    return m, rank, list(piv[:rank])
+
+
+def o_inverse(a, n):
+    """-> inverse words, or None if singular."""
+    a = np.ascontiguousarray(a)
+    inv = np.zeros_like(a)
+    rc = oracle().oracle_inverse(ptr(inv), inv.shape[1], ptr(a), a.shape[1], n)
+    return inv if rc == 0 else None
+
+
+def o_solve_left(a, m, n, b, brows, k):
+    """-> (X as brows x width(k) words, consistent?)."""
+    a = np.ascontiguousarray(a)
+    x = np.ascontiguousarray(b).copy()
+    rc = oracle().oracle_solve_left(ptr(a), a.shape[1], m, n, ptr(x), x.shape[1], brows, k)
+    return x, rc == 0

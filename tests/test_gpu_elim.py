@@ -1,0 +1,243 @@
+"""GPU parity tests for the elimination entry points: mzd_echelonize*, mzd_inv_m4ri,
+mzd_solve_left and the device forms, through the C ABI, against the CPU oracle.  Reduced row echelon forms, inverses and
+solutions with free variables 0 are unique, so every comparison is bit-exact; the non-reduced form (full = 0) is
+checked through what is defined about it (rank, pivot columns, echelon shape, row space)."""
+import os
+
+import numpy as np
+import pytest
+
+import gf2util as g
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg(built):
+    import m4ri_rust_amd as p
+    from m4ri_rust_amd import device
+    device.require_gpu()
+    return p
+
+
+@pytest.fixture(scope="module")
+def dev(pkg):
+    from m4ri_rust_amd import device
+    return device
+
+
+@pytest.fixture(params=[32, 2], ids=["block2048", "block128"])
+def block_words(request):
+    """Column-block width of the elimination; the small setting puts many blocks into small matrices."""
+    old = os.environ.get("M4RI_HIP_ELIM_BLOCK_WORDS")
+    os.environ["M4RI_HIP_ELIM_BLOCK_WORDS"] = str(request.param)
+    yield request.param
+    if old is None:
+        del os.environ["M4RI_HIP_ELIM_BLOCK_WORDS"]
+    else:
+        os.environ["M4RI_HIP_ELIM_BLOCK_WORDS"] = old
+
+
+def _low_rank(m, n, r, seed):
+    return g.o_mul_naive(g.random_words(m, r, seed), g.random_words(r, n, seed + 1), m, r, n)
+
+
+def _host_rref(pkg, a, n, full=True):
+    M = pkg.BinMatrix.from_words(a, n)
+    rank = M.echelonize(full=full)
+    return M.to_words(), rank
+
+
+SHAPES = [(1, 1), (1, 200), (200, 1), (64, 64), (65, 63), (100, 100), (70, 130), (130, 70), (513, 1030), (1030, 513),
+          (1000, 1000), (2048, 2048), (300, 5000), (5000, 300), (3000, 2500)]
+
+
+@pytest.mark.parametrize("m,n", SHAPES)
+def test_rref_random(pkg, block_words, m, n):
+    a = g.random_words(m, n, 100 + m + n)
+    got, rank = _host_rref(pkg, a, n)
+    ref, orank, _ = g.o_echelonize(a, m, n, full=True)
+    assert rank == orank
+    assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("m,n,r", [(200, 300, 17), (1500, 1200, 64), (1500, 1200, 65), (2500, 3000, 700), (4096, 4096, 1)])
+def test_rref_rank_deficient(pkg, block_words, m, n, r):
+    a = _low_rank(m, n, r, 7 * r + m)
+    got, rank = _host_rref(pkg, a, n)
+    ref, orank, _ = g.o_echelonize(a, m, n, full=True)
+    assert rank == orank <= r
+    assert np.array_equal(got, ref)
+
+
+def test_rref_structured(pkg, block_words):
+    n = 700
+    ident = g.bits_to_words(np.eye(n, dtype=np.uint8))
+    got, rank = _host_rref(pkg, ident, n)
+    assert rank == n and np.array_equal(got, ident)
+    zero = np.zeros_like(ident)
+    got, rank = _host_rref(pkg, zero, n)
+    assert rank == 0 and not got.any()
+    # reversed identity: every pivot comes from the last active row
+    rev = g.bits_to_words(np.eye(n, dtype=np.uint8)[::-1].copy())
+    got, rank = _host_rref(pkg, rev, n)
+    assert rank == n and np.array_equal(got, ident)
+    # leading zero columns, duplicated rows, an all-ones block
+    bits = g.words_to_bits(g.random_words(900, 1000, 5), 1000)
+    bits[:, :130] = 0
+    bits[450:] = bits[:450]
+    bits[100:164, 500:564] = 1
+    a = g.bits_to_words(bits)
+    got, rank = _host_rref(pkg, a, 1000)
+    ref, orank, _ = g.o_echelonize(a, 900, 1000, full=True)
+    assert rank == orank and np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("m,n,r", [(100, 100, 100), (1200, 1500, 1500), (1500, 1200, 300), (3000, 2500, 2500)])
+def test_upper_echelon_form(pkg, block_words, m, n, r):
+    """full = 0 (what BinMatrix::echelonize passes, binary_matrix.rs:259)."""
+    a = _low_rank(m, n, r, 31) if r < min(m, n) else g.random_words(m, n, 32)
+    got, rank = _host_rref(pkg, a, n, full=False)
+    ref, orank, piv = g.o_echelonize(a, m, n, full=True)
+    assert rank == orank
+    bits = g.words_to_bits(got, n)
+    assert not bits[rank:].any()
+    first = np.argmax(bits[:rank], axis=1)  # leading 1 of each non-zero row
+    assert list(first) == piv  # same pivot columns, strictly increasing
+    for r_, c in enumerate(piv):
+        assert not bits[r_ + 1:, c].any()
+    assert np.array_equal(g.o_echelonize(got, m, n, full=True)[0], ref)  # same row space
+
+
+def test_rank_and_variants(pkg):
+    L = pkg._lib.lib()
+    a = _low_rank(777, 900, 123, 3)
+    A = pkg.BinMatrix.from_words(a, 900)
+    before = A.to_words().copy()
+    assert A.rank() == g.o_echelonize(a, 777, 900)[1]
+    assert np.array_equal(A.to_words(), before)  # rank() works on a clone (binary_matrix.rs:250-252)
+    ref, orank, _ = g.o_echelonize(a, 777, 900, full=True)
+    for fn, extra in ((L.mzd_echelonize_m4ri, (1, 0)), (L.mzd_echelonize_pluq, (1,))):
+        B = pkg.BinMatrix.from_words(a, 900)
+        assert fn(B.mzd, *extra) == orank
+        assert np.array_equal(B.to_words(), ref)
+
+
+def test_echelonize_window(pkg):
+    L = pkg._lib.lib()
+    big = pkg.BinMatrix.from_words(g.random_words(400, 600, 41), 600)
+    before = g.words_to_bits(big.to_words(), 600)
+    W = L.mzd_init_window(big.mzd, 30, 128, 330, 128 + 200)  # 300 x 200, ragged tail inside the parent
+    rank = L.mzd_echelonize(W, 1)
+    after = g.words_to_bits(big.to_words(), 600)
+    sub = g.bits_to_words(before[30:330, 128:328])
+    ref, orank, _ = g.o_echelonize(sub, 300, 200, full=True)
+    expect = before.copy()
+    expect[30:330, 128:328] = g.words_to_bits(ref, 200)
+    assert rank == orank and np.array_equal(after, expect)
+    L.mzd_free(W)
+
+
+def _invertible(n, seed):
+    """Product of a unit lower and a unit upper triangular random matrix."""
+    bits = g.words_to_bits(g.random_words(n, n, seed), n)
+    lo = np.tril(bits, -1) | np.eye(n, dtype=np.uint8)
+    up = np.triu(g.words_to_bits(g.random_words(n, n, seed + 1), n), 1) | np.eye(n, dtype=np.uint8)
+    return g.o_mul_naive(g.bits_to_words(lo), g.bits_to_words(up), n, n, n)
+
+
+@pytest.mark.parametrize("n", [1, 64, 100, 1000, 2049])
+def test_inverse(pkg, block_words, n):
+    a = _invertible(n, 50 + n)
+    A = pkg.BinMatrix.from_words(a, n)
+    inv = A.inverted()
+    assert np.array_equal(inv.to_words(), g.o_inverse(a, n))
+    assert (A * inv) == pkg.BinMatrix.identity(n)
+
+
+def test_inverse_singular(pkg):
+    a = _low_rank(300, 300, 299, 9)
+    with pytest.raises(pkg.PanicError, match="Can't be NULL"):
+        pkg.BinMatrix.from_words(a, 300).inverted()
+    L = pkg._lib.lib()
+    dst = pkg.BinMatrix.zero(300, 300)
+    assert not L.mzd_inv_m4ri(dst.mzd, pkg.BinMatrix.from_words(a, 300).mzd, 0)
+
+
+@pytest.mark.parametrize("m,n,k", [(100, 100, 1), (1200, 800, 70), (2048, 2048, 2048), (900, 900, 5000)])
+def test_solve_left(pkg, block_words, m, n, k):
+    a = g.random_words(m, n, 61)
+    x0 = g.random_words(n, k, 62)
+    b = g.o_mul_naive(a, x0, m, n, k)
+    A, B = pkg.BinMatrix.from_words(a, n), pkg.BinMatrix.from_words(b, k)
+    assert pkg.solve_left(A, B) is True
+    ref, ok = g.o_solve_left(a, m, n, b, m, k)
+    assert ok and np.array_equal(B.to_words(), ref)
+    assert np.array_equal(g.o_mul_naive(a, B.to_words()[:n], m, n, k), b)
+    assert np.array_equal(A.to_words(), g.o_echelonize(a, m, n, full=True)[0])  # "A ... (overwritten)"
+
+
+def test_solve_left_underdetermined_rows_and_inconsistent(pkg):
+    # rank-deficient A, more rows in B than in A: the extra rows are cleared, free variables are 0
+    m, n, k, brows = 500, 400, 90, 640
+    a = _low_rank(m, n, 150, 71)
+    x0 = g.random_words(n, k, 72)
+    b = np.zeros((brows, g.width(k)), dtype=np.uint64)
+    b[:m] = g.o_mul_naive(a, x0, m, n, k)
+    b[m:] = g.random_words(brows - m, k, 73)  # ignored by the solver
+    A, B = pkg.BinMatrix.from_words(a, n), pkg.BinMatrix.from_words(b, k)
+    assert pkg.solve_left(A, B) is True
+    ref, ok = g.o_solve_left(a, m, n, b, brows, k)
+    assert ok and np.array_equal(B.to_words(), ref)
+    assert np.array_equal(g.o_mul_naive(a, B.to_words()[:n], m, n, k), b[:m])
+    # inconsistent system
+    b2 = b.copy()
+    b2[:m] = g.random_words(m, k, 74)
+    A, B = pkg.BinMatrix.from_words(a, n), pkg.BinMatrix.from_words(b2, k)
+    assert pkg.solve_left(A, B) is False
+    assert g.o_solve_left(a, m, n, b2, brows, k)[1] is False
+    # without the check the call reports success (solve.rs:19-21: output then undefined)
+    L = pkg._lib.lib()
+    A, B = pkg.BinMatrix.from_words(a, n), pkg.BinMatrix.from_words(b2, k)
+    assert L.mzd_solve_left(A.mzd, B.mzd, 0, 0) == 0
+
+
+def test_device_echelonize_limit_and_pivots(pkg, dev, block_words):
+    m, n, extra = 1500, 1000, 700
+    a = _low_rank(m, n + extra, 600, 81)
+    D = dev.DMat.from_words(a, n + extra)
+    rank, piv = dev.echelonize(D, full=True, ncols_limit=n)
+    ref, orank, opiv = g.o_echelonize(a, m, n + extra, full=True, limit=n)
+    assert rank == orank and piv == opiv
+    assert np.array_equal(D.to_words(), ref)
+
+
+def test_device_inverse(pkg, dev):
+    n = 3000
+    a = _invertible(n, 91)
+    A = dev.DMat.from_words(a, n)
+    inv = dev.inverse(A)
+    assert inv is not None and np.array_equal(inv.to_words(), g.o_inverse(a, n))
+    assert dev.inverse(dev.DMat.from_words(_low_rank(500, 500, 20, 92), 500)) is None
+
+
+@pytest.mark.parametrize("n", [8192, 16384])
+def test_large_transformation_property(pkg, dev, n):
+    """[A | I] -> [R | E] with E*A = R, R the reduced echelon form: checked with the device product (no oracle at
+    this size), plus the shape of R."""
+    A = dev.DMat.random(n, n, 7)
+    T = dev.DMat(n, 2 * n)
+    aw = A.to_words()
+    t = np.zeros((n, 2 * n // 64), dtype=np.uint64)
+    t[:, : n // 64] = aw
+    t[:, n // 64:] = g.bits_to_words(np.eye(n, dtype=np.uint8))
+    T = dev.DMat.from_words(t, 2 * n)
+    rank, piv = dev.echelonize(T, full=True, ncols_limit=n)
+    out = T.to_words()
+    R, E = np.ascontiguousarray(out[:, : n // 64]), np.ascontiguousarray(out[:, n // 64:])
+    prod = dev.mul(dev.DMat.from_words(E, n), A, algo="m4rm").to_words()
+    assert np.array_equal(prod, R)
+    assert n - 70 < rank <= n and len(piv) == rank and piv == sorted(piv)
+    bits = g.words_to_bits(R, n)
+    sub = bits[:rank][:, piv]
+    assert np.array_equal(sub, np.eye(rank, dtype=np.uint8)) and not bits[rank:].any()

@@ -118,3 +118,72 @@ def test_opt_k_follows_documented_rule():
     lib = g.oracle()
     assert lib.oracle_opt_k(1000, 1024, 1000) == int(0.75 * 11)
     assert 1 <= lib.oracle_opt_k(1, 1, 1) <= 16
+
+
+# ---- elimination oracle -----------------------------------------
+
+def _py_rref(bits):
+    """Independent bit-level Gauss-Jordan on a list-of-lists (small cases only)."""
+    a = [list(map(int, r)) for r in bits]
+    m, n = len(a), len(a[0]) if a else 0
+    r, piv = 0, []
+    for c in range(n):
+        p = next((i for i in range(r, m) if a[i][c]), None)
+        if p is None:
+            continue
+        a[r], a[p] = a[p], a[r]
+        for i in range(m):
+            if i != r and a[i][c]:
+                a[i] = [x ^ y for x, y in zip(a[i], a[r])]
+        piv.append(c)
+        r += 1
+        if r == m:
+            break
+    return np.array(a, dtype=np.uint8).reshape(m, n), piv
+
+
+@pytest.mark.parametrize("m,n,seed", [(1, 1, 1), (5, 9, 2), (64, 64, 3), (70, 130, 4), (130, 70, 5), (100, 100, 6)])
+def test_oracle_rref_matches_bit_level(m, n, seed):
+    a = g.random_words(m, n, seed)
+    red, rank, piv = g.o_echelonize(a, m, n, full=True)
+    ref, rpiv = _py_rref(g.words_to_bits(a, n))
+    assert rank == len(rpiv) and piv == rpiv
+    assert np.array_equal(g.words_to_bits(red, n), ref)
+
+
+def test_oracle_rank_deficient_and_upper_form():
+    # rank <= 20 by construction: product of 90x20 and 20x150
+    x, y = g.random_words(90, 20, 7), g.random_words(20, 150, 8)
+    a = g.o_mul_naive(x, y, 90, 20, 150)
+    red, rank, piv = g.o_echelonize(a, 90, 150, full=True)
+    assert rank <= 20 and not red[rank:].any()
+    up, rank2, piv2 = g.o_echelonize(a, 90, 150, full=False)
+    assert rank2 == rank and piv2 == piv
+    bits = g.words_to_bits(up, 150)
+    for r, c in enumerate(piv2):  # echelon shape: first 1 of row r is at its pivot column, zeros below it
+        assert bits[r, c] == 1 and not bits[r, :c].any() and not bits[r + 1:, c].any()
+    # same row space: the reduced form of the upper form is the reduced form
+    assert np.array_equal(g.o_echelonize(up, 90, 150, full=True)[0], red)
+
+
+def test_oracle_inverse_and_solve():
+    n = 150
+    a = g.random_words(n, n, 11)
+    inv = g.o_inverse(a, n)
+    while inv is None:  # random matrices are invertible with probability ~0.29
+        a[0, 0] ^= np.uint64(1)
+        a = g.random_words(n, n, int(a[0, 0]) % 1000 + 12)
+        inv = g.o_inverse(a, n)
+    ident = g.o_mul_naive(a, inv, n, n, n)
+    assert np.array_equal(g.words_to_bits(ident, n), np.eye(n, dtype=np.uint8))
+    assert g.o_inverse(np.zeros_like(a), n) is None
+    # A X = B with a known solution
+    m, n, k = 120, 80, 33
+    a = g.random_words(m, n, 13)
+    x0 = g.random_words(n, k, 14)
+    b = np.zeros((m, g.width(k)), dtype=np.uint64)
+    b[:m] = g.o_mul_naive(a, x0, m, n, k)
+    x, ok = g.o_solve_left(a, m, n, b, m, k)
+    assert ok and np.array_equal(g.o_mul_naive(a, x[:n], m, n, k), b) and not x[n:].any()
+    b[m - 1, 0] ^= np.uint64(1)  # rank(A) = 80 < 120: a perturbed right-hand side is (almost surely) inconsistent
+    assert g.o_solve_left(a, m, n, b, m, k)[1] is False
