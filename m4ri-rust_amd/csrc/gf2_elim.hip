@@ -8,12 +8,13 @@
 //
 // Blocked Gauss-Jordan.  Columns are processed in blocks of up to 2048 (32 words).  Inside a block the columns of one
 // 64-bit word form a step:
-//   pivot   one workgroup scans the word of every active row (rows >= rank), keeps a GF(2) basis of at most 64 words
-//           in LDS (1024 candidates reduced against it per pass, insertion by ballot inside one wave), then
-//           back-substitutes so that the chosen rows are reduced on the pivot columns, sorts them by column and emits
-//           the row moves that bring them to rows [rank, rank+np);
-//   ptab    the np reduced pivot rows, restricted to the block's columns plus the block's tracking matrix U;
-//   update  every other row XORs the pivot rows its word selects (table in LDS, one wave per row, lane = word);
+//   pivot   one workgroup scans the word of the active rows (rows >= rank; 256 first, then 1024 per pass), keeps a fully
+//           reduced GF(2) basis of at most 64 words (candidates reduced against it with v_readlane broadcasts, insertion
+//           by ballot inside one wave), orders the chosen rows by pivot column, emits the row moves that bring them to
+//           rows [rank, rank+np), and writes the np reduced pivot rows restricted to the block's columns plus the
+//           block's tracking matrix U (staged through LDS);
+//   update  every other row XORs the pivot rows its word selects: Four Russians with 4-bit groups, 16 x 16 entries
+//           of 512 B in 128 KiB of LDS per workgroup, one wave per row, lane = word, 16 conflict-free lookups per row;
 //   gather / scatter   the <= 128 row moves (whole rows, so the columns right of the block travel with them).
 // U (rows x 2048 bits) records, for each row, which of the block's pivot rows (as they were when the block started)
 // have been added to it; when the block is finished, everything right of it is updated with ONE product
@@ -34,52 +35,87 @@ __device__ __forceinline__ u64 readfirst64(u64 v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// pivot search in one word column
+// pivot search in one word column + the reduced pivot rows over the block
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void gf2_elim_pivot_kernel(const u64 *__restrict__ A, long long lda, int m, long long wc,
-                                                              u64 colmask, gf2k_elim_state *st, int *pivcols) {
+__device__ __forceinline__ u64 rdlane64(u64 v, int lane) {  // lane must be wave-uniform
+  const int l = __builtin_amdgcn_readfirstlane(lane);
+  const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, l), hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), l);
+  return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ int rdlane32(int v, int lane) {
+  return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(lane));
+}
+
+__global__ __launch_bounds__(1024) void gf2_elim_pivot_kernel(const u64 *__restrict__ A, long long lda, int m, long long c0w,
+                                                              int sw, int j, u64 colmask, const u64 *__restrict__ U,
+                                                              long long ldu, int uw, gf2k_elim_state *st, int *pivcols,
+                                                              u64 *__restrict__ ptab) {
+  // basis vector k: b_word[k] is clear on the pivot column of every other vector (kept fully reduced), b_trk[k] says
+  // which of the chosen rows (by insertion index, as originally read) it is the XOR of
   __shared__ u64 b_word[64], b_trk[64];
   __shared__ int b_row[64], b_col[64];
   __shared__ int s_nb;
   __shared__ int s_nz[16];
+  __shared__ int f_pos[64];
+  __shared__ int s_flag[64];
+  __shared__ u64 stage[64 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r_cur = st->r_cur;
+  const int jbase = r_cur - st->r0;
+  const long long wc = c0w + j;
   if (tid == 0) s_nb = 0;
+  if (tid < 64) s_flag[tid] = 0;
   __syncthreads();
-  for (int base = r_cur; base < m; base += 1024) {
-    const int nb0 = s_nb;
-    if (nb0 == 64) break;
+  // the first pass looks at 256 rows only (one wave per SIMD: nearly always enough for 64 pivots, and the waves that
+  // re-reduce their candidates after the first wave's insertions do not compete for issue slots); then 1024 per pass
+  int csz = 256;
+  for (int base = r_cur; base < m; base += csz, csz = 1024) {
     const int i = base + tid;
-    u64 w = i < m ? (A[(long long)i * lda + wc] & colmask) : 0, t = 0;
-    // w: candidate reduced against the basis; t: which basis rows (as originally read) were added to it
-    for (int k = 0; k < nb0; ++k)
-      if ((w >> b_col[k]) & 1) {
-        w ^= b_word[k];
-        t ^= b_trk[k];
-      }
-    const u64 nzb = __ballot(w != 0);
-    if (lane == 0) s_nz[wave] = nzb != 0;
-    __syncthreads();
-    for (int wv = 0; wv < 16; ++wv) {
-      if (!s_nz[wv]) continue;  // uniform over the workgroup
-      if (wave == wv) {
-        int nbl = s_nb;
-        for (int k = nb0; k < nbl; ++k)  // vectors inserted by earlier waves of this pass
-          if ((w >> b_col[k]) & 1) {
-            w ^= b_word[k];
-            t ^= b_trk[k];
+    // w: candidate reduced against the basis; t: which chosen rows were added to it
+    u64 w = (tid < csz && i < m) ? (A[(long long)i * lda + wc] & colmask) : 0, t = 0;
+    int done = 0;  // basis vectors already applied to w
+    for (;;) {
+      const int nb = s_nb;
+      if (nb == 64) break;  // uniform over the workgroup
+      if (done < nb && __ballot(w != 0)) {  // basis vector `lane` in registers, broadcast by v_readlane
+        const u64 mw = b_word[lane], mt = b_trk[lane];
+        const int mc = b_col[lane];
+        for (int k = done; k < nb; ++k) {
+          const int c = rdlane32(mc, k);
+          const u64 pw = rdlane64(mw, k), pt = rdlane64(mt, k);
+          if ((w >> c) & 1) {
+            w ^= pw;
+            t ^= pt;
           }
-        u64 mask = __ballot(w != 0);
+        }
+      }
+      done = nb;
+      const u64 nzb = __ballot(w != 0);
+      if (lane == 0) s_nz[wave] = nzb != 0;
+      __syncthreads();
+      int fw = -1;
+      for (int wv = 15; wv >= 0; --wv)
+        if (s_nz[wv]) fw = wv;
+      if (fw < 0) break;
+      if (wave == fw) {  // this wave's candidates are reduced against the whole basis: insert the independent ones
+        u64 mw = lane < nb ? b_word[lane] : 0, mt = lane < nb ? b_trk[lane] : 0;
+        int mc = lane < nb ? b_col[lane] : 0, mrow = lane < nb ? b_row[lane] : 0;
+        int nbl = nb;
+        u64 mask = nzb;
         while (mask && nbl < 64) {
           const int p = __builtin_ctzll(mask);  // lowest row first
-          const u64 pw = shfl64(w, p);
-          const u64 pt = shfl64(t, p) | (1ull << nbl);
+          const u64 pw = rdlane64(w, p);
+          const u64 pt = rdlane64(t, p) | (1ull << nbl);
           const int c = __builtin_ctzll(pw);
-          if (lane == 0) {
-            b_word[nbl] = pw;
-            b_trk[nbl] = pt;
-            b_row[nbl] = base + wv * 64 + p;
-            b_col[nbl] = c;
+          if ((mw >> c) & 1) {  // keep the older vectors clear on the new pivot column
+            mw ^= pw;
+            mt ^= pt;
+          }
+          if (lane == nbl) {
+            mw = pw;
+            mt = pt;
+            mc = c;
+            mrow = base + fw * 64 + p;
           }
           if (lane == p) {
             w = 0;
@@ -90,112 +126,133 @@ __global__ __launch_bounds__(1024) void gf2_elim_pivot_kernel(const u64 *__restr
           ++nbl;
           mask = __ballot(w != 0);
         }
+        done = nbl;
+        if (lane < nbl) {
+          b_word[lane] = mw;
+          b_trk[lane] = mt;
+          b_col[lane] = mc;
+          b_row[lane] = mrow;
+        }
         if (lane == 0) s_nb = nbl;
       }
       __syncthreads();
     }
     __syncthreads();  // s_nz is rewritten by the next pass
+    if (s_nb == 64) break;
   }
   __syncthreads();
-  if (wave != 0) return;
-
   const int np = s_nb;
-  u64 bw = lane < np ? b_word[lane] : 0, bt = lane < np ? b_trk[lane] : 0;
-  const int c = lane < np ? b_col[lane] : 0, row = lane < np ? b_row[lane] : -1;
-  // vector k is already clear on the pivot columns of earlier vectors; clear the later ones (Gauss-Jordan)
-  for (int kk = np - 1; kk >= 1; --kk) {
-    const u64 pw = shfl64(bw, kk), pt = shfl64(bt, kk);
-    const int pc = __shfl(c, kk);
-    if (lane < kk && ((bw >> pc) & 1)) {
-      bw ^= pw;
-      bt ^= pt;
-    }
-  }
-  u64 pcmask = lane < np ? (1ull << c) : 0;
-  for (int o = 32; o; o >>= 1) pcmask |= shfl64(pcmask, lane ^ o);
-  const int pos = lane < np ? __popcll(pcmask & ((1ull << c) - 1)) : 64;  // order by pivot column
-  u64 nt = 0;
-  for (int k = 0; k < np; ++k) {
-    const int pk = __shfl(pos, k);
-    if ((bt >> k) & 1) nt |= 1ull << pk;
-  }
-  if (lane < np) {
-    st->piv_row[pos] = row;
-    st->piv_col[pos] = c;
-    st->trk[pos] = nt;
-    pivcols[r_cur + pos] = (int)(wc * 64 + c);
-    st->mv_src[pos] = row;
-    st->mv_dst[pos] = r_cur + pos;
-    st->mv_piv[pos] = pos;
-  }
-  // rows inside [r_cur, r_cur+np) that are not pivots trade places with the pivot rows coming from below
-  bool is_src = false;
-  for (int k = 0; k < np; ++k) is_src |= (__shfl(row, k) == r_cur + lane);
-  const bool displaced = lane < np && !is_src, vacated = lane < np && row >= r_cur + np;
-  const u64 dmask = __ballot(displaced), vmask = __ballot(vacated);
-  const int q = __popcll(dmask & ((1ull << lane) - 1));
-  u64 vm = vmask;
-  for (int i = 0; i < q && vm; ++i) vm &= vm - 1;
-  const int vk = vm ? __builtin_ctzll(vm) : 0;
-  const int vrow = __shfl(row, vk);
-  if (displaced) {
-    st->mv_src[np + q] = r_cur + lane;
-    st->mv_dst[np + q] = vrow;
-    st->mv_piv[np + q] = -1;
-  }
-  if (lane == 0) {
-    st->np = np;
-    st->nmoves = np + __popcll(dmask);
-    st->pcmask = pcmask;
-    st->jbase = r_cur - st->r0;
-    st->r_cur = r_cur + np;
-  }
-}
 
-// reduced pivot rows over the block's columns [c0w, c0w+sw) and the tracking words [0, uw): one wave per pivot
-__global__ __launch_bounds__(64) void gf2_elim_ptab_kernel(const u64 *__restrict__ A, long long lda, long long c0w, int sw,
-                                                           const u64 *__restrict__ U, long long ldu, int uw,
-                                                           const gf2k_elim_state *st, u64 *__restrict__ ptab) {
-  const int k = blockIdx.x, lane = threadIdx.x;
-  if (k >= st->np) return;
-  const int jbase = st->jbase;
-  if (lane >= sw + uw) return;
-  u64 acc = 0;
-  for (u64 t = st->trk[k]; t; t &= t - 1) {
-    const int k2 = __builtin_ctzll(t);
-    const long long r = st->piv_row[k2];
-    if (lane < sw) {
-      acc ^= A[r * lda + c0w + lane];
-    } else {
-      const int u = lane - sw, j = jbase + k2;  // row r becomes pivot j of the block: its own unit bit
-      acc ^= U[r * ldu + u] ^ ((j >> 6) == u ? 1ull << (j & 63) : 0);
+  // order the pivots by column: vector k goes to row r_cur + pos[k] and is pivot jbase + pos[k] of the block
+  u64 pcmask = 0;
+  int c = 0, row = -1, pos = 64;
+  if (wave == 0) {
+    if (lane < np) {
+      c = b_col[lane];
+      row = b_row[lane];
+      pcmask = 1ull << c;
+    }
+    for (int o = 32; o; o >>= 1) pcmask |= shfl64(pcmask, lane ^ o);
+    if (lane < np) {
+      pos = __popcll(pcmask & ((1ull << c) - 1));
+      f_pos[lane] = pos;
+      pivcols[r_cur + pos] = (int)(wc * 64 + c);
+      st->mv_src[pos] = row;
+      st->mv_dst[pos] = r_cur + pos;
+      st->mv_piv[pos] = pos;
+      if (row < r_cur + np) s_flag[row - r_cur] = 1;  // a pivot row that already sits inside [r_cur, r_cur+np)
     }
   }
-  ptab[k * 64 + lane] = acc;
+  __syncthreads();
+  if (wave == 0) {
+    // rows inside [r_cur, r_cur+np) that are not pivots trade places with the pivot rows coming from below
+    const bool displaced = lane < np && !s_flag[lane], vacated = lane < np && row >= r_cur + np;
+    const u64 dmask = __ballot(displaced), vmask = __ballot(vacated);
+    const int q = __popcll(dmask & ((1ull << lane) - 1));
+    u64 vm = vmask;
+    for (int i = 0; i < q && vm; ++i) vm &= vm - 1;
+    const int vk = vm ? __builtin_ctzll(vm) : 0;
+    const int vrow = __shfl(row, vk);
+    if (displaced) {
+      st->mv_src[np + q] = r_cur + lane;
+      st->mv_dst[np + q] = vrow;
+      st->mv_piv[np + q] = -1;
+    }
+    if (lane == 0) {
+      st->np = np;
+      st->nmoves = np + __popcll(dmask);
+      st->pcmask = pcmask;
+      st->jbase = jbase;
+      st->r_cur = r_cur + np;
+    }
+  }
+  // the chosen rows over the block's columns [c0w, c0w+sw) and the tracking words [0, uw), each with its own unit bit
+  for (int idx = tid; idx < np * 64; idx += 1024) {
+    const int k = idx >> 6, wd = idx & 63;
+    const long long r = b_row[k];
+    u64 v = 0;
+    if (wd < sw) {
+      v = A[r * lda + c0w + wd];
+    } else if (wd < sw + uw) {
+      const int u = wd - sw, jj = jbase + f_pos[k];
+      v = U[r * ldu + u] ^ ((jj >> 6) == u ? 1ull << (jj & 63) : 0);
+    }
+    stage[idx] = v;
+  }
+  __syncthreads();
+  // reduced pivot row = XOR of the staged rows selected by b_trk[k], stored at its column-ordered position
+  for (int idx = tid; idx < np * 64; idx += 1024) {
+    const int k = idx >> 6, wd = idx & 63;
+    u64 acc = 0;
+    for (u64 t = b_trk[k]; t; t &= t - 1) acc ^= stage[__builtin_ctzll(t) * 64 + wd];
+    ptab[f_pos[k] * 64 + wd] = acc;
+  }
 }
 
 // every row adds the pivot rows selected by its bits on the pivot columns (pivot rows themselves are rewritten by the
-// scatter afterwards, whatever lands in them here is discarded)
-__global__ __launch_bounds__(256) void gf2_elim_update_kernel(u64 *__restrict__ A, long long lda, int m, int full,
-                                                              long long c0w, int sw, int j, u64 *__restrict__ U,
-                                                              long long ldu, int uw, const gf2k_elim_state *st,
-                                                              const u64 *__restrict__ ptab) {
-  __shared__ u64 tab[64 * 64];
-  const int np = st->np;
-  if (np == 0) return;
-  const int tid = threadIdx.x, lane = tid & 63;
-  for (int i = tid; i < np * 64; i += 256) tab[i] = ptab[i];
-  __syncthreads();
+// scatter afterwards, whatever lands in them here is discarded).  Four Russians with 4-bit groups: for each nibble of
+// the 64-bit selector word a 16-entry table of XOR combinations, 16 x 16 entries of 512 B (one LDS bank row each:
+// lane = word, conflict-free) = 128 KiB, built once per workgroup; a row then costs 16 lookups.
+constexpr int kUpdLds = 16 * 16 * 64 * 8;
+__global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__ A, long long lda, int m, int full,
+                                                               long long c0w, int sw, int j, u64 *__restrict__ U,
+                                                               long long ldu, int uw, const gf2k_elim_state *st,
+                                                               const u64 *__restrict__ ptab) {
+  extern __shared__ __attribute__((aligned(16))) u64 tab[];  // [group 16][entry 16][word 64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int np = st->np, r0s = st->r0;
   const u64 pcmask = st->pcmask;
-  const int rows_lo = full ? 0 : st->r0;
+  if (np == 0) return;
+  // level 0/1: entry 0 and the single-bit entries (bit b of the word = pivot popcount(pcmask below b), or nothing)
+  for (int it = tid; it < 16 * 5 * 64; it += 1024) {
+    const int wd = it & 63, e5 = (it >> 6) % 5, g = (it >> 6) / 5;
+    u64 v = 0;
+    int e = 0;
+    if (e5) {
+      e = 1 << (e5 - 1);
+      const int b = g * 4 + (e5 - 1);
+      if ((pcmask >> b) & 1) v = ptab[__popcll(pcmask & ((1ull << b) - 1)) * 64 + wd];
+    }
+    tab[(g * 16 + e) * 64 + wd] = v;
+  }
+  __syncthreads();
+  // entries with 2, 3, 4 bits from the lower levels
+  for (int bits = 2; bits <= 4; ++bits) {
+    for (int it = tid; it < 16 * 16 * 64; it += 1024) {
+      const int wd = it & 63, e = (it >> 6) & 15, g = it >> 10;
+      if (__popc(e) == bits) tab[(g * 16 + e) * 64 + wd] = tab[(g * 16 + (e & (e - 1))) * 64 + wd] ^ tab[(g * 16 + (e & -e)) * 64 + wd];
+    }
+    __syncthreads();
+  }
+  const int rows_lo = full ? 0 : r0s;
   const long long wc = c0w + j;
   const int nS = sw - j;
   const bool isS = lane < nS, act = lane < nS + uw;
-  const int tword = isS ? j + lane : sw + (lane - nS);
+  const int tword = isS ? j + lane : (act ? sw + (lane - nS) : 0);
   u64 *const base = isS ? A + wc + lane : U + (lane - nS);
   const long long ld = isS ? lda : ldu;
-  const int gw = blockIdx.x * 4 + (tid >> 6), nw = gridDim.x * 4;
-  constexpr int RG = 4;
+  const int gw = blockIdx.x * 16 + wave, nw = gridDim.x * 16;
+  constexpr int RG = 8;
   for (long long r0 = rows_lo + (long long)gw * RG; r0 < m; r0 += (long long)nw * RG) {
     u64 sel[RG], old[RG];
 #pragma unroll
@@ -206,12 +263,14 @@ __global__ __launch_bounds__(256) void gf2_elim_update_kernel(u64 *__restrict__ 
     }
 #pragma unroll
     for (int q = 0; q < RG; ++q) {
-      u64 s = readfirst64(sel[q]), acc = 0;
+      const u64 s = readfirst64(sel[q]);
       if (!s) continue;
-      for (; s; s &= s - 1) {
-        const int b = __builtin_ctzll(s);
-        const int pos = __popcll(pcmask & ((1ull << b) - 1));
-        acc ^= tab[pos * 64 + (act ? tword : 0)];
+      const unsigned lo = (unsigned)s, hi = (unsigned)(s >> 32);
+      u64 acc = 0;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const unsigned idx = ((g < 8 ? lo : hi) >> (4 * (g & 7))) & 15u;
+        acc ^= tab[(g * 16 + idx) * 64 + tword];
       }
       if (act && r0 + q < m) base[(r0 + q) * ld] = old[q] ^ acc;
     }
@@ -309,13 +368,19 @@ extern "C" hipError_t gf2k_elim_step(u64 *A, long long lda, int m, long long aw,
                                      int full, u64 *U, long long ldu, int uw, gf2k_elim_state *st, int *pivcols, u64 *ptab,
                                      u64 *tmp, long long tld, hipStream_t s) {
   if (sw + uw > 64 || j >= sw) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(gf2_elim_pivot_kernel, dim3(1), dim3(1024), 0, s, A, lda, m, c0w + j, colmask, st, pivcols);
-  hipLaunchKernelGGL(gf2_elim_ptab_kernel, dim3(64), dim3(64), 0, s, A, lda, c0w, sw, U, ldu, uw, st, ptab);
-  const int groups = (m + 3) / 4;
-  int grid = (groups + 3) / 4;
-  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(gf2_elim_pivot_kernel, dim3(1), dim3(1024), 0, s, A, lda, m, c0w, sw, j, colmask, U, ldu, uw, st,
+                     pivcols, ptab);
+  // 8 rows per wave and pass, 16 waves per workgroup, one workgroup per CU (128 KiB of LDS tables each)
+  int grid = (m + 127) / 128;
+  if (grid > 256) grid = 256;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(gf2_elim_update_kernel, dim3(grid), dim3(256), 0, s, A, lda, m, full, c0w, sw, j, U, ldu, uw, st, ptab);
+  {  // per device, so not cached in a static (same as the tile kernel's launcher)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gf2_elim_update_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kUpdLds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(gf2_elim_update_kernel, dim3(grid), dim3(1024), kUpdLds, s, A, lda, m, full, c0w, sw, j, U, ldu, uw, st,
+                     ptab);
   hipLaunchKernelGGL(gf2_elim_gather_kernel, dim3(128), dim3(256), 0, s, A, lda, aw, c0w, sw, U, ldu, uw, st, ptab, tmp, tld);
   hipLaunchKernelGGL(gf2_elim_scatter_kernel, dim3(128), dim3(256), 0, s, A, lda, aw, c0w, U, ldu, uw, st, tmp, tld);
   return hipGetLastError();

@@ -31,9 +31,6 @@ struct gf2k_elim_state {
   int jbase;  // r_cur - r0 before the current step: index of its first pivot inside the block
   int pad_;
   unsigned long long pcmask;   // pivot columns of the current word
-  int piv_row[64];             // row that holds pivot k (k in pivot-column order)
-  int piv_col[64];             // its bit position inside the word
-  unsigned long long trk[64];  // reduced pivot row k = XOR of the rows piv_row[k'] for k' in trk[k]
   int mv_src[128], mv_dst[128], mv_piv[128];  // row moves of the step (mv_piv >= 0: the source is pivot mv_piv)
 };
 
