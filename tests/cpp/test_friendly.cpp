@@ -78,6 +78,34 @@ static int mul_tests() {
       CHECK((A * B).transposed() == (Bt * At));
     }
   }
+  mul_strategy() = MulStrategy::Strassen;
+  {  // elimination (binary_matrix.rs:246-268, 575-586): unit-triangular products are invertible
+    const size_t n = 300;
+    BinMatrix L = BinMatrix::identity(n), Um = BinMatrix::identity(n), R = BinMatrix::random(n, n);
+    for (size_t i = 0; i < n; ++i)
+      for (size_t j = 0; j < n; ++j)
+        if (i != j && R.bit(i, j)) {
+          mzd_t *t = (i > j ? L : Um).raw();
+          t->rows[i][j / 64] |= 1ull << (j % 64);
+        }
+    BinMatrix A = L * Um;
+    CHECK(A.rank() == n);
+    BinMatrix Ai = A.inverted();
+    CHECK((A * Ai) == BinMatrix::identity(n) && (Ai * A) == BinMatrix::identity(n));
+    BinMatrix X0 = BinMatrix::random(n, 40), B = A * X0;
+    CHECK(solve_left(A, B) && B == X0);
+    BinMatrix Z = BinMatrix::zero(n, n);
+    CHECK(Z.rank() == 0);
+    BinMatrix thin = BinMatrix::random(200, 17) * BinMatrix::random(17, 200);
+    CHECK(thin.rank() <= 17);
+    bool threw = false;
+    try {
+      (void)thin.inverted();
+    } catch (const Panic &) {
+      threw = true;
+    }
+    CHECK(threw);
+  }
   return 0;
 }
 
