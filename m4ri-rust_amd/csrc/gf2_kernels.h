@@ -19,6 +19,10 @@ struct gf2k_mul_args {
   const uint32_t *Bp;  // chunk-packed copy of B (kernel variants with BPACK), else unused
   long long sBp;       // batch stride of Bp in 2 KiB blocks
   int bp_nc;           // chunk blocks per tile column in Bp
+  // split-K without atomics: slice ks of batch item bt stores its partial product at P + (bt*ksplit + ks)*sP (dense,
+  // row stride ldp) and gf2k_m4rm combines the slices into C with a second kernel; nullptr: atomic XOR into C
+  uint64_t *P;
+  long long ldp, sP;
 };
 
 // Device-side record of a blocked elimination (gf2_elim.hip): the kernels of a step read their ranges from it, so a

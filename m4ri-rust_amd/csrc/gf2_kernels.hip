@@ -335,7 +335,12 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v3(const gf2k_mul_
   const int bt = t / p.tiles_n;
   const u64 *__restrict__ A = p.A + (long long)bt * p.sA;
   const u64 *__restrict__ B = p.B + (long long)bt * p.sB;
-  u64 *__restrict__ C = p.C + (long long)bt * p.sC;
+  // split-K: either every slice stores its partial product (combined by gf2_splitk_reduce_kernel) or all slices meet
+  // in C with atomic XOR
+  const bool part = p.P != nullptr && p.ksplit > 1;
+  u64 *__restrict__ C = part ? p.P + ((long long)bt * p.ksplit + ks) * p.sP : p.C + (long long)bt * p.sC;
+  const long long ldc = part ? p.ldp : p.ldc;
+  const bool accum = !part && p.accumulate;
 
   const int row0 = tm * R, w0 = tn * kTileWords;
   const int widthA = (p.l + 63) >> 6, widthB = (p.n + 63) >> 6;
@@ -573,25 +578,50 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v3(const gf2k_mul_
   for (int s = 0; s < STEPS; ++s) {
     const int row = myrow0 + 4 * s;
     if (row < p.m && wc < widthB) {
-      u64 *dst = C + (long long)row * p.ldc + wc;
+      u64 *dst = C + (long long)row * ldc + wc;
       u64 v0 = (u64)acc[s][0] | ((u64)acc[s][1] << 32);
       u64 v1 = (u64)acc[s][2] | ((u64)acc[s][3] << 32);
       if (wc == widthB - 1) v0 &= maskC;
       if (wc + 1 == widthB - 1) v1 &= maskC;
-      if (p.ksplit > 1) {  // partial sums of the slices meet in C (zeroed by the launcher unless accumulating)
+      if (p.ksplit > 1 && !part) {  // partial sums of the slices meet in C (zeroed by the launcher unless accumulating)
         if (v0) atomicXor(reinterpret_cast<unsigned long long *>(dst), (unsigned long long)v0);
         if (wc + 1 < widthB && v1) atomicXor(reinterpret_cast<unsigned long long *>(dst + 1), (unsigned long long)v1);
       } else if (wc + 1 < widthB) {
-        if (p.accumulate) {
+        if (accum) {
           const uint4 old = *reinterpret_cast<const uint4 *>(dst);
           v0 ^= (u64)old.x | ((u64)old.y << 32);
           v1 ^= (u64)old.z | ((u64)old.w << 32);
         }
         *reinterpret_cast<uint4 *>(dst) = make_uint4((u32)v0, (u32)(v0 >> 32), (u32)v1, (u32)(v1 >> 32));
       } else {
-        if (p.accumulate) v0 ^= dst[0];
+        if (accum) v0 ^= dst[0];
         dst[0] = v0;
       }
+    }
+  }
+}
+
+// C (+)= XOR of the ksplit partial products of a split-K launch (dense, row stride ldp, 16-byte accesses; ldp even)
+__global__ __launch_bounds__(256) void gf2_splitk_reduce_kernel(u64 *__restrict__ C, long long ldc, long long sC,
+                                                                const u64 *__restrict__ P, long long ldp, long long sP,
+                                                                int ksplit, int m, int words, int batch, int accumulate) {
+  const int pairs = (words + 1) >> 1;
+  const long long per = (long long)m * pairs, total = per * batch;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(idx / per);
+    const long long rem = idx - (long long)b * per;
+    const int r = (int)(rem / pairs), w = (int)(rem % pairs) * 2;
+    const u64 *src = P + (long long)b * ksplit * sP + (long long)r * ldp + w;
+    uint4 a = make_uint4(0, 0, 0, 0);
+    for (int s = 0; s < ksplit; ++s) a = xor4(a, *reinterpret_cast<const uint4 *>(src + (long long)s * sP));
+    u64 *dst = C + (long long)b * sC + (long long)r * ldc + w;
+    if (w + 1 < words) {
+      if (accumulate) a = xor4(a, *reinterpret_cast<const uint4 *>(dst));
+      *reinterpret_cast<uint4 *>(dst) = a;
+    } else {
+      u64 v = (u64)a.x | ((u64)a.y << 32);
+      if (accumulate) v ^= dst[0];
+      dst[0] = v;
     }
   }
 }
@@ -1234,7 +1264,8 @@ extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {
   if (a.ksplit > nw32) a.ksplit = nw32 > 0 ? nw32 : 1;
   a.kwords = (nw32 + a.ksplit - 1) / a.ksplit;
   a.ksplit = a.kwords > 0 ? (nw32 + a.kwords - 1) / a.kwords : 1;  // no empty slices
-  if (a.ksplit > 1 && !a.accumulate) {  // slices are combined with atomic XOR: start from zero
+  if (a.ksplit <= 1 || cfg == 0 || cfg == 1 || (a.ldp & 1)) a.P = nullptr;
+  if (a.ksplit > 1 && !a.accumulate && !a.P) {  // slices are combined with atomic XOR: start from zero
     for (int b = 0; b < a.batch; ++b) {
       hipError_t e = gf2k_xor2d(a.C + (long long)b * a.sC, a.ldc, nullptr, 0, nullptr, 0, a.m, (a.n + 63) / 64, stream);
       if (e != hipSuccess) return e;
@@ -1242,21 +1273,28 @@ extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {
   }
   const long long nwg = (long long)a.tiles_m * a.tiles_n * a.batch * a.ksplit;
   if (nwg > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipError_t e = hipErrorInvalidValue;
   switch (cfg) {
-    case 0: return launch_tile_kernel(&gf2_m4rm_kernel<8, 128>, 512, a, nwg, stream);
-    case 1: return launch_tile_kernel(&gf2_m4rm_kernel<4, 64>, 256, a, nwg, stream);
-    case 7: return launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4>, 512, a, nwg, stream);
-    case 20: return launch_tile_kernel(&gf2_m4rm_kernel_v3<4, 64, 4>, 256, a, nwg, stream);
-    case 50: return launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 0, 0, 1>, 512, a, nwg, stream);  // packed B
-    case 40: return launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 2>, 512, a, nwg, stream);  // no barriers (timing only)
-    case 41: return launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 3>, 512, a, nwg, stream);  // no loads in the loop
-    case 42: return launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 4>, 512, a, nwg, stream);  // no build xor chain
-    case 44: return launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 6>, 512, a, nwg, stream);  // no B loads in the loop
-    case 45: return launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 7>, 512, a, nwg, stream);  // no A loads in the loop
-    case 43: return launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 5>, 512, a, nwg, stream);  // none of the three
-    case 9: return launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 6, 1>, 512, a, nwg, stream);  // section stamps
+    case 0: e = launch_tile_kernel(&gf2_m4rm_kernel<8, 128>, 512, a, nwg, stream); break;
+    case 1: e = launch_tile_kernel(&gf2_m4rm_kernel<4, 64>, 256, a, nwg, stream); break;
+    case 7: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4>, 512, a, nwg, stream); break;
+    case 20: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<4, 64, 4>, 256, a, nwg, stream); break;
+    case 50: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 0, 0, 1>, 512, a, nwg, stream); break;  // packed B
+    case 40: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 2>, 512, a, nwg, stream); break;  // no barriers (timing only)
+    case 41: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 3>, 512, a, nwg, stream); break;  // no loads in the loop
+    case 42: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 4>, 512, a, nwg, stream); break;  // no build xor chain
+    case 44: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 6>, 512, a, nwg, stream); break;  // no B loads in the loop
+    case 45: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 7>, 512, a, nwg, stream); break;  // no A loads in the loop
+    case 43: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 5>, 512, a, nwg, stream); break;  // none of the three
+    case 9: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 6, 1>, 512, a, nwg, stream); break;  // section stamps
     default: return hipErrorInvalidValue;
   }
+  if (e != hipSuccess || !a.P) return e;
+  const int words = (a.n + 63) / 64;
+  const long long total = (long long)a.m * ((words + 1) / 2) * a.batch;
+  hipLaunchKernelGGL(gf2_splitk_reduce_kernel, dim3(grid_for(total)), dim3(256), 0, stream, a.C, a.ldc, a.sC, a.P, a.ldp, a.sP,
+                     a.ksplit, a.m, words, a.batch, a.accumulate);
+  return hipGetLastError();
 }
 
 extern "C" hipError_t gf2k_dbg_sec(unsigned long long *out8) {

@@ -18,6 +18,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/m4ri_hip.h"
@@ -197,13 +198,14 @@ struct StreamWs {
   size_t bytes = 0;
 };
 std::mutex g_ws_mu;
-std::map<std::pair<int, hipStream_t>, StreamWs> g_ws;
+std::map<std::tuple<int, hipStream_t, int>, StreamWs> g_ws;
 
-int stream_workspace(hipStream_t s, size_t bytes, void **out) {
+// slot 0: Strassen operand arena / transposed operand of the naive entry; slot 1: split-K partial products
+int stream_workspace(hipStream_t s, size_t bytes, void **out, int slot = 0) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lk(g_ws_mu);
-  StreamWs &w = g_ws[{dev, s}];
+  StreamWs &w = g_ws[std::make_tuple(dev, s, slot)];
   if (w.bytes < bytes) {
     if (w.p) {  // still referenced by queued work: hand it back once the stream has drained past this point
       if (free_after(s, w.p, w.bytes) != 0) {
@@ -315,7 +317,7 @@ static int m4rm_ksplit_for(int m, int l, int n, int batch) {
   if (wg >= 192) return 1;
   const int nw32 = (l + 31) / 32;
   long long ks = (512 + wg - 1) / wg;
-  if (ks > nw32 / 8) ks = nw32 / 8;
+  if (ks > nw32 / 4) ks = nw32 / 4;  // slices of at least 128 bits
   return ks < 1 ? 1 : (int)ks;
 }
 
@@ -425,6 +427,14 @@ static int mul_m4rm_plain(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int
   a.batch = 1;
   a.accumulate = accumulate;
   a.ksplit = m4rm_ksplit_for(m, l, n, 1);
+  if (a.ksplit > 1) {  // slices store partial products that a second kernel combines (atomic XOR costs about 3x as much)
+    static const long long cap = (long long)env_int("M4RI_HIP_SPLITK_WS_MIB", 512) << 20;
+    a.ldp = (words_of(n) + 1) & ~1ll;
+    a.sP = (long long)m * a.ldp;
+    const long long bytes = a.sP * a.ksplit * (long long)sizeof(u64);
+    void *ws = nullptr;
+    if (bytes <= cap && stream_workspace(s, (size_t)bytes, &ws, 1) == 0) a.P = static_cast<u64 *>(ws);
+  }
   return launch_m4rm(a, m4rm_cfg_for(m, n, 1), s);
 }
 
@@ -555,7 +565,7 @@ static std::mutex g_enqueue_mu;
 static int mul_dispatch(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int accumulate, int algo, int param,
                         hipStream_t s, bool sync_free) {
   std::unique_lock<std::mutex> lk(g_enqueue_mu, std::defer_lock);
-  if (algo != GF2_ALGO_M4RM && !sync_free) lk.lock();  // host-path calls own a private (thread-local) stream
+  if (!sync_free) lk.lock();  // host-path calls own a private (thread-local) stream
   switch (algo) {
     case GF2_ALGO_NAIVE:
       return mul_naive_dev(C, A, B, accumulate, s, sync_free);
