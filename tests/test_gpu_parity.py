@@ -354,3 +354,20 @@ def test_host_transpose_large_uses_device_and_matches(pkg):
         assert t.nrows() == c and t.ncols() == r
         assert np.array_equal(t.to_words(), g.o_transpose(w, r, c)), (r, c)
         assert t.transposed() == m
+
+
+@pytest.mark.parametrize("m,l,n", [(2048, 256, 64), (2048, 256, 65), (2500, 256, 128), (3000, 256, 256), (5000, 100, 1),
+                                   (4097, 300, 200), (2049, 1000, 129), (9000, 64, 255), (2300, 129, 130), (70000, 256, 37),
+                                   (2048, 8, 256), (6000, 513, 64)])
+def test_tall_skinny_shapes(pkg, dev, m, l, n):
+    """n <= 256 with many rows (batches of LPN-style products): both tall-skinny kernels (one lane per row for entries
+    up to 16 bytes, one quad per row above), all entry widths, ragged everything, with and without accumulation."""
+    a, b = g.random_words(m, l, 300 + n), g.random_words(l, n, 301 + l)
+    A, B = dev.DMat.from_words(a, l), dev.DMat.from_words(b, n)
+    ref = g.o_mul_m4rm(a, b, m, l, n)
+    C = dev.mul(A, B, algo="m4rm")
+    assert np.array_equal(C.to_words(), ref)
+    c0 = g.random_words(m, n, 302)
+    C = dev.DMat.from_words(c0, n)
+    dev.mul(A, B, C, accumulate=True, algo="auto")
+    assert np.array_equal(C.to_words(), ref ^ c0)
