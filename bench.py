@@ -39,7 +39,10 @@ def main():
     ap.add_argument("--levels", type=int, default=0, help="Strassen levels (0 = automatic)")
     ap.add_argument("--cpu-n", type=int, default=32768, help="dimension of the CPU-baseline sample product")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--panels", type=int, default=4, help="column panels of B per step when N > 1 (RCCL/compute overlap)")
+    ap.add_argument("--panels", type=int, default=0,
+                    help="column panels of B per step when N > 1 (RCCL/compute overlap); 0 = 2 panels on 2 GPUs, 4 above "
+                         "(measured per-rank products: thin panels cost Strassen efficiency, 32768x65536x32768 takes 13.0 ms "
+                         "but 4 x 32768x65536x16384 take 31 ms; from 4 GPUs on the transfer is the longer leg)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--check", action="store_true", help="spot-check rows of C against the oracle after timing")
     args = ap.parse_args()
@@ -86,7 +89,7 @@ def main():
     A_t = torch.empty((rows, ldw), dtype=torch.int64, device="cuda")
     A = device.DMat.from_torch(A_t, n)
     sharded.fill_row_block(A, seed=1, row0=rank * rows, stream=stream)
-    P = max(1, args.panels) if world > 1 else 1
+    P = (args.panels if args.panels > 0 else (2 if world == 2 else 4)) if world > 1 else 1
     assert ldw % (2 * P) == 0
     wp, ncp = ldw // P, n // P
     if world == 1:

@@ -7,7 +7,10 @@ import torch
 import m4ri_rust_amd  # noqa
 from m4ri_rust_amd import device, sharded
 
-shapes = [(8192, 8192, 8192), (16384, 16384, 16384), (32768, 32768, 32768), (8192, 65536, 16384), (8192, 65536, 65536), (65536, 65536, 65536)]
+shapes = [(8192, 8192, 8192), (16384, 16384, 16384), (32768, 32768, 32768), (8192, 65536, 16384), (16384, 65536, 16384),
+          (32768, 65536, 16384), (8192, 65536, 65536), (65536, 65536, 65536)]
+if len(sys.argv) > 1:
+    shapes = [tuple(int(x) for x in a.split('x')) for a in sys.argv[1:]]
 for (m, l, n) in shapes:
     A, B = device.DMat.random(m, l, 1), device.DMat.random(l, n, 2)
     C = device.DMat(m, n)
