@@ -163,7 +163,10 @@ def main():
     # launch's products read and write once: batch * (m*l + l*n + m*n)/8 with the leaf dims.
     ncols_launch = n // P  # columns of B one launch sees (a column panel when N > 1)
     levels = sharded.levels_used(rows, n, ncols_launch, args.algo, args.levels)
-    mi, li, ni, batch = rows >> levels, n >> levels, ncols_launch >> levels, 7 ** levels
+    # the library may cut the batch of 7^levels leaf products into several launches (chunks that overlap the Strassen passes)
+    products = (args.steps * P) or 1
+    lps = max(1, int(round(launches / products))) if launches else 1  # tile-kernel launches per product
+    mi, li, ni, batch = rows >> levels, n >> levels, ncols_launch >> levels, (7 ** levels) // lps
     alg_bytes_launch = batch * (mi * li + li * ni + mi * ni) / 8.0
     avg_kernel_ms = kernel_ms / max(launches, 1)
     achieved = alg_bytes_launch / (avg_kernel_ms * 1e-3) / 1e9 if launches else 0.0
@@ -176,7 +179,7 @@ def main():
             with open(tfile) as f:
                 tj = json.load(f)
             if tj.get("n") == n and tj.get("levels") == levels and tj.get("n_gpus") == world:
-                traffic = tj.get("hbm_bytes_per_launch")
+                traffic = tj.get("hbm_bytes_per_launch") * tj.get("launches_per_product", 1) / lps
         except Exception:
             traffic = None
     out = {
@@ -237,7 +240,7 @@ def main():
             blk = (n >> i) * (n >> i) / 8.0
             pass_bytes += 3 * units * blk  # A side, B side and the merge of C move the same number of blocks
             prev = i
-        pass_ms = max(ms_per_step - avg_kernel_ms, 1e-9)
+        pass_ms = max(ms_per_step - kernel_ms / args.steps, 1e-9)
         out["strassen_passes"] = {"bound": "hbm", "ms_per_step": pass_ms, "bytes_per_step": pass_bytes,
                                   "achieved": pass_bytes / (pass_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": pass_bytes / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -225,6 +225,30 @@ int stream_workspace(hipStream_t s, size_t bytes, void **out, int slot = 0) {
   return 0;
 }
 
+// Side stream + events for one main stream: the leaf products of a Strassen product run there, chunk by chunk, while
+// the main stream streams the operands of the next chunk / folds the previous chunk's products (HBM-bound passes under
+// an LDS-bound kernel).  Cached per (device, stream); never destroyed (a handful per process).
+struct SideStream {
+  hipStream_t s2 = nullptr;
+  std::vector<hipEvent_t> ev;
+};
+std::map<std::pair<int, hipStream_t>, SideStream> g_side;
+
+int side_stream(hipStream_t s, int nevents, SideStream **out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  SideStream &sd = g_side[{dev, s}];
+  if (!sd.s2) HIP_TRY(hipStreamCreateWithFlags(&sd.s2, hipStreamNonBlocking));
+  while ((int)sd.ev.size() < nevents) {
+    hipEvent_t e;
+    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    sd.ev.push_back(e);
+  }
+  *out = &sd;
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // kernel timing (bench.py roofline): events around the dominant multiply kernel
 // ---------------------------------------------------------------------------------------------
@@ -461,6 +485,18 @@ static int mul_strassen(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int a
     cur += p7 * mi * (ni / 64);
   }
   int rc = 0;
+  // Optional (M4RI_HIP_STRASSEN_OVERLAP=1, default off): the last materialised level is processed in chunks of parent
+  // nodes so that its passes overlap the leaf kernel -- chunk k's operands are split on `s`, its leaf products run on a
+  // side stream, and `s` folds them when they are done.  Measured at 65536^3, 4 levels: the passes disappear from the
+  // critical path (5.4 -> 2.0 ms exposed) but the leaf kernel, whose operand loads then compete with 5 TB/s of pass
+  // traffic, slows from 38.8 to 43.2 ms (raising its wave priority changes nothing): 45.2 ms against 44.3 ms serial.
+  const int last = mats.back(), lastprev = mats.size() > 1 ? mats[mats.size() - 2] : 0;
+  const int parents = (int)pow7(lastprev), cpp = (int)pow7(last - lastprev);  // children (leaves) per parent node
+  const int overlap_on = env_int("M4RI_HIP_STRASSEN_OVERLAP", 0);
+  const int nchunks = (overlap_on && parents >= 7) ? 7 : 1;
+  SideStream *side = nullptr;
+  if (nchunks > 1)
+    if (int r = side_stream(s, 2 * nchunks, &side)) return r;
   auto run = [&]() -> int {
     // operand trees: level i holds 7^i operands of (m/2^i x l/2^i) and (l/2^i x n/2^i)
     int prev = 0;
@@ -472,35 +508,48 @@ static int mul_strassen(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int a
       const u64 *srcB = prev ? Bop[prev] : B->data;
       const long long ldsB = prev ? (long long)((n >> prev) / 64) : B->ld;
       const long long strB = prev ? (long long)(l >> prev) * ldsB : 0;
-      if (i - prev == 1) {
-        HIP_TRY(gf2k_strassen_split(Aop[i], li / 64, (long long)mi * (li / 64), srcA, ldsA, strA, mi, li / 64, 0, batch, s));
-        HIP_TRY(gf2k_strassen_split(Bop[i], ni / 64, (long long)li * (ni / 64), srcB, ldsB, strB, li, ni / 64, 1, batch, s));
-      } else {
-        HIP_TRY(gf2k_strassen_split2(Aop[i], li / 64, (long long)mi * (li / 64), srcA, ldsA, strA, mi, li / 64, 0, batch, s));
-        HIP_TRY(gf2k_strassen_split2(Bop[i], ni / 64, (long long)li * (ni / 64), srcB, ldsB, strB, li, ni / 64, 1, batch, s));
+      const long long dA = (long long)mi * (li / 64), dB = (long long)li * (ni / 64);  // operand sizes at level i
+      const int per = (int)pow7(i - prev);
+      const int chunks = i == last ? nchunks : 1;
+      for (int c = 0; c < chunks; ++c) {
+        const int k0 = (int)((long long)batch * c / chunks), k1 = (int)((long long)batch * (c + 1) / chunks);
+        u64 *dAp = Aop[i] + (long long)k0 * per * dA, *dBp = Bop[i] + (long long)k0 * per * dB;
+        if (i - prev == 1) {
+          HIP_TRY(gf2k_strassen_split(dAp, li / 64, dA, srcA + k0 * strA, ldsA, strA, mi, li / 64, 0, k1 - k0, s));
+          HIP_TRY(gf2k_strassen_split(dBp, ni / 64, dB, srcB + k0 * strB, ldsB, strB, li, ni / 64, 1, k1 - k0, s));
+        } else {
+          HIP_TRY(gf2k_strassen_split2(dAp, li / 64, dA, srcA + k0 * strA, ldsA, strA, mi, li / 64, 0, k1 - k0, s));
+          HIP_TRY(gf2k_strassen_split2(dBp, ni / 64, dB, srcB + k0 * strB, ldsB, strB, li, ni / 64, 1, k1 - k0, s));
+        }
+        if (i == last) {  // leaf products of this chunk
+          const int mL = m >> L, lL = l >> L, nL = n >> L;
+          gf2k_mul_args a{};
+          a.lda = lL / 64;
+          a.ldb = nL / 64;
+          a.ldc = nL / 64;
+          a.sA = (long long)mL * a.lda;
+          a.sB = (long long)lL * a.ldb;
+          a.sC = (long long)mL * a.ldc;
+          a.A = Aop[L] + (long long)k0 * cpp * a.sA;
+          a.B = Bop[L] + (long long)k0 * cpp * a.sB;
+          a.C = Pop[L] + (long long)k0 * cpp * a.sC;
+          a.m = mL;
+          a.l = lL;
+          a.n = nL;
+          a.batch = (k1 - k0) * cpp;
+          a.accumulate = 0;
+          a.ksplit = m4rm_ksplit_for(mL, lL, nL, a.batch);
+          hipStream_t ls = s;
+          if (side) {
+            ls = side->s2;
+            HIP_TRY(hipEventRecord(side->ev[2 * c], s));
+            HIP_TRY(hipStreamWaitEvent(ls, side->ev[2 * c], 0));
+          }
+          if (int r = launch_m4rm(a, m4rm_cfg_for(mL, nL, a.batch), ls)) return r;
+          if (side) HIP_TRY(hipEventRecord(side->ev[2 * c + 1], ls));
+        }
       }
       prev = i;
-    }
-    // 7^L leaf products in one batched launch
-    {
-      const int mi = m >> L, li = l >> L, ni = n >> L;
-      gf2k_mul_args a{};
-      a.A = Aop[L];
-      a.B = Bop[L];
-      a.C = Pop[L];
-      a.lda = li / 64;
-      a.ldb = ni / 64;
-      a.ldc = ni / 64;
-      a.sA = (long long)mi * a.lda;
-      a.sB = (long long)li * a.ldb;
-      a.sC = (long long)mi * a.ldc;
-      a.m = mi;
-      a.l = li;
-      a.n = ni;
-      a.batch = (int)pow7(L);
-      a.accumulate = 0;
-      a.ksplit = m4rm_ksplit_for(mi, li, ni, a.batch);
-      if (int r = launch_m4rm(a, m4rm_cfg_for(mi, ni, a.batch), s)) return r;
     }
     // fold the products back up
     for (int k = (int)mats.size() - 1; k >= 0; --k) {
@@ -510,10 +559,18 @@ static int mul_strassen(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int a
       const long long ldd = up ? (long long)((n >> up) / 64) : C->ld;
       const long long strD = up ? (long long)(m >> up) * ldd : 0;
       const int acc = up ? 0 : accumulate;
-      if (i - up == 1)
-        HIP_TRY(gf2k_strassen_merge(dst, ldd, strD, Pop[i], ni / 64, (long long)mi * (ni / 64), mi, ni / 64, acc, batch, s));
-      else
-        HIP_TRY(gf2k_strassen_merge2(dst, ldd, strD, Pop[i], ni / 64, (long long)mi * (ni / 64), mi, ni / 64, acc, batch, s));
+      const long long dP = (long long)mi * (ni / 64);
+      const int per = (int)pow7(i - up);
+      const int chunks = i == last ? nchunks : 1;
+      for (int c = 0; c < chunks; ++c) {
+        const int k0 = (int)((long long)batch * c / chunks), k1 = (int)((long long)batch * (c + 1) / chunks);
+        if (i == last && side) HIP_TRY(hipStreamWaitEvent(s, side->ev[2 * c + 1], 0));
+        const u64 *src = Pop[i] + (long long)k0 * per * dP;
+        if (i - up == 1)
+          HIP_TRY(gf2k_strassen_merge(dst + k0 * strD, ldd, strD, src, ni / 64, dP, mi, ni / 64, acc, k1 - k0, s));
+        else
+          HIP_TRY(gf2k_strassen_merge2(dst + k0 * strD, ldd, strD, src, ni / 64, dP, mi, ni / 64, acc, k1 - k0, s));
+      }
     }
     return 0;
   };

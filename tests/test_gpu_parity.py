@@ -371,3 +371,18 @@ def test_tall_skinny_shapes(pkg, dev, m, l, n):
     C = dev.DMat.from_words(c0, n)
     dev.mul(A, B, C, accumulate=True, algo="auto")
     assert np.array_equal(C.to_words(), ref ^ c0)
+
+
+def test_strassen_overlap_switch(pkg, dev, monkeypatch):
+    """M4RI_HIP_STRASSEN_OVERLAP=1 runs the leaf products chunk by chunk on a side stream while the main stream streams
+    the operands of the next chunk (an experiment that is off by default): same bits either way."""
+    n = 8192
+    A, B = dev.DMat.random(n, n, 1), dev.DMat.random(n, n, 2)
+    ref = dev.mul(A, B, algo="m4rm")
+    for levels in (3, 4):
+        monkeypatch.setenv("M4RI_HIP_STRASSEN_OVERLAP", "1")
+        C1 = dev.mul(A, B, algo="strassen", param=levels)
+        C1b = dev.mul(A, B, algo="strassen", param=levels)  # back to back on the same streams
+        monkeypatch.setenv("M4RI_HIP_STRASSEN_OVERLAP", "0")
+        C0 = dev.mul(A, B, algo="strassen", param=levels)
+        assert dev.equal(C1, ref) and dev.equal(C1b, ref) and dev.equal(C0, ref)
