@@ -241,3 +241,27 @@ def test_large_transformation_property(pkg, dev, n):
     bits = g.words_to_bits(R, n)
     sub = bits[:rank][:, piv]
     assert np.array_equal(sub, np.eye(rank, dtype=np.uint8)) and not bits[rank:].any()
+
+
+def test_full_size_transformation_property(pkg, dev):
+    """65536 x 65536 (BASELINE's headline dimension), entirely on the device: [A | I] -> [R | E], then E*A == R with the
+    device product and device comparison; rank and pivot columns are checked on the host."""
+    import torch
+    n = 65536
+    w = n // 64
+    t = torch.zeros((n, 2 * w), dtype=torch.int64, device="cuda")
+    T = dev.DMat.from_torch(t, 2 * n)
+    A = dev.DMat.random(n, n, 11)
+    a_t = torch.zeros((n, w), dtype=torch.int64, device="cuda")
+    Acopy = dev.DMat.from_torch(a_t, n)
+    dev.add(A, dev.DMat.from_torch(torch.zeros((n, w), dtype=torch.int64, device="cuda"), n), Acopy)  # copy through XOR with 0
+    t[:, :w] = a_t
+    idx = torch.arange(n, device="cuda")
+    t[idx, w + idx // 64] = torch.bitwise_left_shift(torch.ones(n, dtype=torch.int64, device="cuda"), idx % 64)
+    torch.cuda.synchronize()
+    rank, piv = dev.echelonize(T, full=True, ncols_limit=n)
+    assert n - 70 < rank <= n and piv == sorted(piv) and len(set(piv)) == rank
+    R = dev.DMat.wrap(t.data_ptr(), n, n, 2 * w, keep=t)
+    E = dev.DMat.wrap(t.data_ptr() + 8 * w, n, n, 2 * w, keep=t)
+    prod = dev.mul(E, A, algo="auto")
+    assert dev.equal(prod, R)
