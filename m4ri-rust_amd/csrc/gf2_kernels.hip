@@ -878,7 +878,9 @@ __global__ __launch_bounds__(NT) void gf2_tallskinny_kernel(const u64 *__restric
 //     staging area, rotated ds_read_b32 per lane.
 // Known limit: the row stores sit between the ring's loads, and since stores may complete out of order with respect to
 // loads the compiler has to wait for vmcnt(0) before a ring entry is consumed -- the effective prefetch distance is one
-// half-block, not four.  Splitting the waves into loaders and computers would lift that.
+// half-block, not four.  Tried: a dedicated store wave (the compute waves' waits then become vmcnt(15..12), the whole ring
+// stays in flight) -- 44.7 us instead of 36.5: with two waves per SIMD the dependent LDS chains of a half-block
+// (staged dword -> byte -> table entry -> XOR) bound the step, and the per-step workgroup barrier adds to it.
 // ---------------------------------------------------------------------------------------------
 template <int CTRL>
 __device__ __forceinline__ u32 xor_dpp(u32 v) {
