@@ -265,3 +265,28 @@ def test_full_size_transformation_property(pkg, dev):
     E = dev.DMat.wrap(t.data_ptr() + 8 * w, n, n, 2 * w, keep=t)
     prod = dev.mul(E, A, algo="auto")
     assert dev.equal(prod, R)
+
+
+ELIM = sorted(__import__("glob").glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "elim", "*.npz")))
+
+
+@pytest.mark.parametrize("path", ELIM, ids=[os.path.basename(p)[:-4] for p in ELIM])
+def test_elimination_fixtures(pkg, path):
+    """The committed known answers (independent numpy elimination, tests/golden/make_golden_elim.py), through the C ABI."""
+    d = np.load(path)
+    name = os.path.basename(path)
+    if name.startswith("rref"):
+        m, n = (int(x) for x in d["shape"])
+        got, rank = _host_rref(pkg, d["a"], n)
+        assert rank == len(d["pivots"]) and np.array_equal(got, d["rref"])
+        assert pkg.BinMatrix.from_words(d["a"], n).rank() == rank
+    elif name.startswith("inverse"):
+        n = int(d["shape"][0])
+        assert np.array_equal(pkg.BinMatrix.from_words(d["a"], n).inverted().to_words(), d["inv"])
+    else:
+        m, n, k = (int(x) for x in d["shape"])
+        B = pkg.BinMatrix.from_words(d["b"], k)
+        assert pkg.solve_left(pkg.BinMatrix.from_words(d["a"], n), B) is True
+        assert np.array_equal(B.to_words(), d["x"])
+        B2 = pkg.BinMatrix.from_words(d["b_inconsistent"], k)
+        assert pkg.solve_left(pkg.BinMatrix.from_words(d["a"], n), B2) is (not bool(d["inconsistent"][0]))

@@ -187,3 +187,26 @@ def test_oracle_inverse_and_solve():
     assert ok and np.array_equal(g.o_mul_naive(a, x[:n], m, n, k), b) and not x[n:].any()
     b[m - 1, 0] ^= np.uint64(1)  # rank(A) = 80 < 120: a perturbed right-hand side is (almost surely) inconsistent
     assert g.o_solve_left(a, m, n, b, m, k)[1] is False
+
+
+# ---- committed elimination fixtures (tests/golden/elim, independent numpy elimination) ----------
+
+ELIM = sorted(glob.glob(os.path.join(GOLDEN, "elim", "*.npz")))
+
+
+@pytest.mark.parametrize("path", ELIM, ids=[os.path.basename(p)[:-4] for p in ELIM])
+def test_oracle_matches_elimination_fixtures(path):
+    d = np.load(path)
+    name = os.path.basename(path)
+    if name.startswith("rref"):
+        m, n = (int(x) for x in d["shape"])
+        red, rank, piv = g.o_echelonize(d["a"], m, n, full=True)
+        assert rank == len(d["pivots"]) and piv == list(d["pivots"]) and np.array_equal(red, d["rref"])
+    elif name.startswith("inverse"):
+        n = int(d["shape"][0])
+        assert np.array_equal(g.o_inverse(d["a"], n), d["inv"])
+    else:
+        m, n, k = (int(x) for x in d["shape"])
+        x, ok = g.o_solve_left(d["a"], m, n, d["b"], m, k)
+        assert ok and np.array_equal(x, d["x"])
+        assert g.o_solve_left(d["a"], m, n, d["b_inconsistent"], m, k)[1] == (not bool(d["inconsistent"][0]))
