@@ -8,14 +8,16 @@
 //
 // Blocked Gauss-Jordan.  Columns are processed in blocks of up to 2048 (32 words).  Inside a block the columns of one
 // 64-bit word form a step:
-//   pivot   one workgroup scans the word of the active rows (rows >= rank; 256 first, then 1024 per pass), keeps a fully
-//           reduced GF(2) basis of at most 64 words (candidates reduced against it with v_readlane broadcasts, insertion
-//           by ballot inside one wave), orders the chosen rows by pivot column, emits the row moves that bring them to
-//           rows [rank, rank+np), and writes the np reduced pivot rows restricted to the block's columns plus the
-//           block's tracking matrix U (staged through LDS);
+//   pivot   one workgroup scans the word of the rows that are not pivots of this block yet (256 first, then 1024 per
+//           pass), keeps a fully reduced GF(2) basis of at most 64 words (candidates reduced against it with v_readlane
+//           broadcasts, insertion by ballot inside one wave), orders the chosen rows by pivot column, flags them, and
+//           writes the np reduced pivot rows restricted to the block's columns plus the block's tracking matrix U
+//           (staged through LDS);
 //   update  every other row XORs the pivot rows its word selects: Four Russians with 4-bit groups, 16 x 16 entries
 //           of 512 B in 128 KiB of LDS per workgroup, one wave per row, lane = word, 16 conflict-free lookups per row;
-//   gather / scatter   the <= 128 row moves (whole rows, so the columns right of the block travel with them).
+//           the step's pivot rows are overwritten with their reduced form.
+// Rows stay where they are inside a block (a byte per row says "pivot of this step / of this block"); when the block is
+// finished one permutation (plan, gather, scatter of whole rows) brings block pivot j to row rank0 + j.
 // U (rows x 2048 bits) records, for each row, which of the block's pivot rows (as they were when the block started)
 // have been added to it; when the block is finished, everything right of it is updated with ONE product
 //   A[:, right] ^= U' * A[pivot rows of the block, right]
@@ -49,7 +51,8 @@ __device__ __forceinline__ int rdlane32(int v, int lane) {
 __global__ __launch_bounds__(1024) void gf2_elim_pivot_kernel(const u64 *__restrict__ A, long long lda, int m, long long c0w,
                                                               int sw, int j, u64 colmask, const u64 *__restrict__ U,
                                                               long long ldu, int uw, gf2k_elim_state *st, int *pivcols,
-                                                              u64 *__restrict__ ptab) {
+                                                              u64 *__restrict__ ptab, unsigned char *rowflag,
+                                                              int *__restrict__ blkpiv) {
   // basis vector k: b_word[k] is clear on the pivot column of every other vector (kept fully reduced), b_trk[k] says
   // which of the chosen rows (by insertion index, as originally read) it is the XOR of
   __shared__ u64 b_word[64], b_trk[64];
@@ -57,22 +60,28 @@ __global__ __launch_bounds__(1024) void gf2_elim_pivot_kernel(const u64 *__restr
   __shared__ int s_nb;
   __shared__ int s_nz[16];
   __shared__ int f_pos[64];
-  __shared__ int s_flag[64];
+  __shared__ unsigned char s_chosen[256];  // rows scan0 .. scan0+255 picked by this step
+  __shared__ int s_lead[4];
   __shared__ u64 stage[64 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r_cur = st->r_cur;
   const int jbase = r_cur - st->r0;
+  const int scan0 = st->scan;
   const long long wc = c0w + j;
   if (tid == 0) s_nb = 0;
-  if (tid < 64) s_flag[tid] = 0;
+  if (tid < 256) s_chosen[tid] = 0;
+  if (tid < st->np) rowflag[st->cur_row[tid]] = 255;  // the previous step's pivots become "pivot of this block"
+  unsigned char f0 = 1;                                // flag of row scan0 + tid before this step (first pass, tid < 256)
   __syncthreads();
   // the first pass looks at 256 rows only (one wave per SIMD: nearly always enough for 64 pivots, and the waves that
   // re-reduce their candidates after the first wave's insertions do not compete for issue slots); then 1024 per pass
   int csz = 256;
-  for (int base = r_cur; base < m; base += csz, csz = 1024) {
+  for (int base = scan0; base < m; base += csz, csz = 1024) {
     const int i = base + tid;
     // w: candidate reduced against the basis; t: which chosen rows were added to it
-    u64 w = (tid < csz && i < m) ? (A[(long long)i * lda + wc] & colmask) : 0, t = 0;
+    const unsigned char fl = (tid < csz && i < m) ? rowflag[i] : 1;  // pivots of this block are no candidates
+    if (base == scan0) f0 = fl;
+    u64 w = fl == 0 ? (A[(long long)i * lda + wc] & colmask) : 0, t = 0;
     int done = 0;  // basis vectors already applied to w
     for (;;) {
       const int nb = s_nb;
@@ -143,10 +152,10 @@ __global__ __launch_bounds__(1024) void gf2_elim_pivot_kernel(const u64 *__restr
   __syncthreads();
   const int np = s_nb;
 
-  // order the pivots by column: vector k goes to row r_cur + pos[k] and is pivot jbase + pos[k] of the block
-  u64 pcmask = 0;
-  int c = 0, row = -1, pos = 64;
+  // order the pivots by column: vector k is pivot jbase + pos[k] of the block
   if (wave == 0) {
+    u64 pcmask = 0;
+    int c = 0, row = -1;
     if (lane < np) {
       c = b_col[lane];
       row = b_row[lane];
@@ -154,37 +163,37 @@ __global__ __launch_bounds__(1024) void gf2_elim_pivot_kernel(const u64 *__restr
     }
     for (int o = 32; o; o >>= 1) pcmask |= shfl64(pcmask, lane ^ o);
     if (lane < np) {
-      pos = __popcll(pcmask & ((1ull << c) - 1));
+      const int pos = __popcll(pcmask & ((1ull << c) - 1));
       f_pos[lane] = pos;
       pivcols[r_cur + pos] = (int)(wc * 64 + c);
-      st->mv_src[pos] = row;
-      st->mv_dst[pos] = r_cur + pos;
-      st->mv_piv[pos] = pos;
-      if (row < r_cur + np) s_flag[row - r_cur] = 1;  // a pivot row that already sits inside [r_cur, r_cur+np)
-    }
-  }
-  __syncthreads();
-  if (wave == 0) {
-    // rows inside [r_cur, r_cur+np) that are not pivots trade places with the pivot rows coming from below
-    const bool displaced = lane < np && !s_flag[lane], vacated = lane < np && row >= r_cur + np;
-    const u64 dmask = __ballot(displaced), vmask = __ballot(vacated);
-    const int q = __popcll(dmask & ((1ull << lane) - 1));
-    u64 vm = vmask;
-    for (int i = 0; i < q && vm; ++i) vm &= vm - 1;
-    const int vk = vm ? __builtin_ctzll(vm) : 0;
-    const int vrow = __shfl(row, vk);
-    if (displaced) {
-      st->mv_src[np + q] = r_cur + lane;
-      st->mv_dst[np + q] = vrow;
-      st->mv_piv[np + q] = -1;
+      blkpiv[jbase + pos] = row;
+      st->cur_row[pos] = row;
+      rowflag[row] = (unsigned char)(1 + c);
+      if (row - scan0 < 256) s_chosen[row - scan0] = 1;
     }
     if (lane == 0) {
       st->np = np;
-      st->nmoves = np + __popcll(dmask);
       st->pcmask = pcmask;
       st->jbase = jbase;
       st->r_cur = r_cur + np;
     }
+  }
+  __syncthreads();
+  // the search of the next step starts behind the leading run of block pivots
+  if (tid < 256) {
+    const bool taken = f0 != 0 || s_chosen[tid];
+    const u64 mk = __ballot(taken);
+    if (lane == 0) s_lead[wave] = ~mk ? __builtin_ctzll(~mk) : 64;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int adv = 0;
+    for (int w2 = 0; w2 < 4; ++w2) {
+      adv += s_lead[w2];
+      if (s_lead[w2] < 64) break;
+    }
+    const int ns = scan0 + adv;
+    st->scan = ns < m ? ns : m;
   }
   // the chosen rows over the block's columns [c0w, c0w+sw) and the tracking words [0, uw), each with its own unit bit
   for (int idx = tid; idx < np * 64; idx += 1024) {
@@ -209,15 +218,16 @@ __global__ __launch_bounds__(1024) void gf2_elim_pivot_kernel(const u64 *__restr
   }
 }
 
-// every row adds the pivot rows selected by its bits on the pivot columns (pivot rows themselves are rewritten by the
-// scatter afterwards, whatever lands in them here is discarded).  Four Russians with 4-bit groups: for each nibble of
+// every row adds the pivot rows selected by its bits on the pivot columns; the step's own pivot rows (row flag) are
+// overwritten with their reduced form, which is the single-bit table entry of their pivot column.  Four Russians with 4-bit groups: for each nibble of
 // the 64-bit selector word a 16-entry table of XOR combinations, 16 x 16 entries of 512 B (one LDS bank row each:
 // lane = word, conflict-free) = 128 KiB, built once per workgroup; a row then costs 16 lookups.
 constexpr int kUpdLds = 16 * 16 * 64 * 8;
 __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__ A, long long lda, int m, int full,
                                                                long long c0w, int sw, int j, u64 *__restrict__ U,
                                                                long long ldu, int uw, const gf2k_elim_state *st,
-                                                               const u64 *__restrict__ ptab) {
+                                                               const u64 *__restrict__ ptab,
+                                                               const unsigned char *__restrict__ rowflag) {
   extern __shared__ __attribute__((aligned(16))) u64 tab[];  // [group 16][entry 16][word 64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int np = st->np, r0s = st->r0;
@@ -255,6 +265,8 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
   constexpr int RG = 8;
   for (long long r0 = rows_lo + (long long)gw * RG; r0 < m; r0 += (long long)nw * RG) {
     u64 sel[RG], old[RG];
+    const long long rf = r0 + (lane & 7);
+    const int flv = rf < m ? rowflag[rf] : 0;  // lanes 0..7: flags of the pass's rows
 #pragma unroll
     for (int q = 0; q < RG; ++q) {
       const long long r = r0 + q;
@@ -263,6 +275,12 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
     }
 #pragma unroll
     for (int q = 0; q < RG; ++q) {
+      const int fl = __builtin_amdgcn_readlane(flv, q);
+      if (fl >= 1 && fl <= 64) {  // pivot of this step with pivot column fl-1: the row becomes its reduced form
+        const int c = fl - 1;
+        if (act && r0 + q < m) base[(r0 + q) * ld] = tab[((c >> 2) * 16 + (1 << (c & 3))) * 64 + tword];
+        continue;
+      }
       const u64 s = readfirst64(sel[q]);
       if (!s) continue;
       const unsigned lo = (unsigned)s, hi = (unsigned)(s >> 32);
@@ -277,34 +295,88 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
   }
 }
 
-// row moves, two phases through a scratch buffer: pivot rows take their block columns and tracking words from ptab
+// ---- end of a block: block pivot j (row blkpiv[j]) goes to row r0 + j; the non-pivot rows that sit inside
+// [r0, r0 + rp) trade places with the pivot rows below that range ----
+__global__ __launch_bounds__(1024) void gf2_elim_plan_kernel(gf2k_elim_state *st, unsigned char *rowflag,
+                                                             const int *__restrict__ blkpiv, int *__restrict__ moves) {
+  __shared__ int s_wcnt[2][16], s_run[2];
+  __shared__ int s_vac[GF2K_ELIM_BLOCK_PIVOTS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0 = st->r0, rp = st->r_cur - r0;
+  int *mv_src = moves, *mv_dst = moves + 2 * GF2K_ELIM_BLOCK_PIVOTS;
+  // two elements per thread: t = tid and tid + 1024 (rp <= 2048)
+  int prow[2], dpos[2], vpos[2];
+  bool isdisp[2], isvac[2];
+  for (int h = 0; h < 2; ++h) {
+    const int t = tid + h * 1024;
+    prow[h] = t < rp ? blkpiv[t] : -1;
+    isvac[h] = t < rp && prow[h] >= r0 + rp;     // block pivot t comes from below the target range
+    isdisp[h] = t < rp && rowflag[r0 + t] == 0;  // target slot r0 + t holds an ordinary row
+  }
+  if (tid < 2) s_run[tid] = 0;
+  __syncthreads();
+  for (int h = 0; h < 2; ++h) {  // ranks in increasing t: ballot inside a wave, wave counts through LDS
+    const u64 dm = __ballot(isdisp[h]), vm = __ballot(isvac[h]);
+    if (lane == 0) {
+      s_wcnt[0][wave] = __popcll(dm);
+      s_wcnt[1][wave] = __popcll(vm);
+    }
+    __syncthreads();
+    int doff = s_run[0], voff = s_run[1];
+    for (int w = 0; w < wave; ++w) {
+      doff += s_wcnt[0][w];
+      voff += s_wcnt[1][w];
+    }
+    dpos[h] = doff + __popcll(dm & ((1ull << lane) - 1));
+    vpos[h] = voff + __popcll(vm & ((1ull << lane) - 1));
+    __syncthreads();
+    if (tid == 0)
+      for (int w = 0; w < 16; ++w) {
+        s_run[0] += s_wcnt[0][w];
+        s_run[1] += s_wcnt[1][w];
+      }
+    __syncthreads();
+  }
+  for (int h = 0; h < 2; ++h)
+    if (isvac[h]) s_vac[vpos[h]] = prow[h];
+  __syncthreads();  // all flags have been read, all vacated rows are listed
+  for (int h = 0; h < 2; ++h) {
+    const int t = tid + h * 1024;
+    if (t < rp) {
+      mv_src[t] = prow[h];
+      mv_dst[t] = r0 + t;
+      rowflag[prow[h]] = 0;  // flags are per block
+    }
+    if (isdisp[h]) {  // the k-th ordinary row of the target range takes the place of the k-th pivot from below
+      mv_src[rp + dpos[h]] = r0 + t;
+      mv_dst[rp + dpos[h]] = s_vac[dpos[h]];
+    }
+  }
+  if (tid == 0) {
+    st->nmoves = rp + s_run[0];
+    st->np = 0;
+  }
+}
+
 __global__ __launch_bounds__(256) void gf2_elim_gather_kernel(const u64 *__restrict__ A, long long lda, long long aw,
-                                                              long long c0w, int sw, const u64 *__restrict__ U,
-                                                              long long ldu, int uw, const gf2k_elim_state *st,
-                                                              const u64 *__restrict__ ptab, u64 *__restrict__ tmp,
-                                                              long long tld) {
+                                                              long long c0w, const u64 *__restrict__ U, long long ldu, int uw,
+                                                              const gf2k_elim_state *st, const int *__restrict__ moves,
+                                                              u64 *__restrict__ tmp, long long tld) {
   const int q = blockIdx.x;
   if (q >= st->nmoves) return;
-  const long long src = st->mv_src[q];
-  const int piv = st->mv_piv[q];
+  const long long src = moves[q];
   const long long nA = aw - c0w;
-  for (long long w = threadIdx.x; w < nA + uw; w += 256) {
-    u64 v;
-    if (w < nA)
-      v = (piv >= 0 && w < sw) ? ptab[piv * 64 + w] : A[src * lda + c0w + w];
-    else
-      v = piv >= 0 ? ptab[piv * 64 + sw + (w - nA)] : U[src * ldu + (w - nA)];
-    tmp[q * tld + w] = v;
-  }
+  for (long long w = threadIdx.x; w < nA + uw; w += 256)
+    tmp[q * tld + w] = w < nA ? A[src * lda + c0w + w] : U[src * ldu + (w - nA)];
 }
 
 __global__ __launch_bounds__(256) void gf2_elim_scatter_kernel(u64 *__restrict__ A, long long lda, long long aw,
                                                                long long c0w, u64 *__restrict__ U, long long ldu, int uw,
-                                                               const gf2k_elim_state *st, const u64 *__restrict__ tmp,
-                                                               long long tld) {
+                                                               const gf2k_elim_state *st, const int *__restrict__ moves,
+                                                               const u64 *__restrict__ tmp, long long tld) {
   const int q = blockIdx.x;
   if (q >= st->nmoves) return;
-  const long long dst = st->mv_dst[q];
+  const long long dst = moves[2 * GF2K_ELIM_BLOCK_PIVOTS + q];
   const long long nA = aw - c0w;
   for (long long w = threadIdx.x; w < nA + uw; w += 256) {
     const u64 v = tmp[q * tld + w];
@@ -316,7 +388,11 @@ __global__ __launch_bounds__(256) void gf2_elim_scatter_kernel(u64 *__restrict__
 }
 
 __global__ void gf2_elim_begin_block_kernel(gf2k_elim_state *st) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) st->r0 = st->r_cur;
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    st->r0 = st->r_cur;
+    st->scan = st->r_cur;
+    st->np = 0;
+  }
 }
 
 // pivot row j of the block holds its own original content on the right-hand columns: U'[r0+j][j] ^= 1 turns
@@ -364,12 +440,12 @@ extern "C" hipError_t gf2k_elim_begin_block(gf2k_elim_state *st, hipStream_t s) 
   return hipGetLastError();
 }
 
-extern "C" hipError_t gf2k_elim_step(u64 *A, long long lda, int m, long long aw, long long c0w, int sw, int j, u64 colmask,
-                                     int full, u64 *U, long long ldu, int uw, gf2k_elim_state *st, int *pivcols, u64 *ptab,
-                                     u64 *tmp, long long tld, hipStream_t s) {
-  if (sw + uw > 64 || j >= sw) return hipErrorInvalidValue;
+extern "C" hipError_t gf2k_elim_step(u64 *A, long long lda, int m, long long c0w, int sw, int j, u64 colmask, int full,
+                                     u64 *U, long long ldu, int uw, gf2k_elim_state *st, int *pivcols, u64 *ptab,
+                                     unsigned char *rowflag, int *blkpiv, hipStream_t s) {
+  if (sw + uw > 64 || j >= sw || sw * 64 > GF2K_ELIM_BLOCK_PIVOTS) return hipErrorInvalidValue;
   hipLaunchKernelGGL(gf2_elim_pivot_kernel, dim3(1), dim3(1024), 0, s, A, lda, m, c0w, sw, j, colmask, U, ldu, uw, st,
-                     pivcols, ptab);
+                     pivcols, ptab, rowflag, blkpiv);
   // 8 rows per wave and pass, 16 waves per workgroup, one workgroup per CU (128 KiB of LDS tables each)
   int grid = (m + 127) / 128;
   if (grid > 256) grid = 256;
@@ -380,15 +456,19 @@ extern "C" hipError_t gf2k_elim_step(u64 *A, long long lda, int m, long long aw,
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(gf2_elim_update_kernel, dim3(grid), dim3(1024), kUpdLds, s, A, lda, m, full, c0w, sw, j, U, ldu, uw, st,
-                     ptab);
-  hipLaunchKernelGGL(gf2_elim_gather_kernel, dim3(128), dim3(256), 0, s, A, lda, aw, c0w, sw, U, ldu, uw, st, ptab, tmp, tld);
-  hipLaunchKernelGGL(gf2_elim_scatter_kernel, dim3(128), dim3(256), 0, s, A, lda, aw, c0w, U, ldu, uw, st, tmp, tld);
+                     ptab, rowflag);
   return hipGetLastError();
 }
 
-extern "C" hipError_t gf2k_elim_toggle(u64 *U, long long ldu, int max_rank, gf2k_elim_state *st, hipStream_t s) {
-  if (max_rank <= 0) return hipSuccess;
-  hipLaunchKernelGGL(gf2_elim_toggle_kernel, dim3((max_rank + 255) / 256), dim3(256), 0, s, U, ldu, st);
+extern "C" hipError_t gf2k_elim_end_block(u64 *A, long long lda, long long aw, long long c0w, u64 *U, long long ldu, int uw,
+                                          gf2k_elim_state *st, unsigned char *rowflag, const int *blkpiv, int *moves, u64 *tmp,
+                                          long long tld, hipStream_t s) {
+  hipLaunchKernelGGL(gf2_elim_plan_kernel, dim3(1), dim3(1024), 0, s, st, rowflag, blkpiv, moves);
+  hipLaunchKernelGGL(gf2_elim_gather_kernel, dim3(2 * GF2K_ELIM_BLOCK_PIVOTS), dim3(256), 0, s, A, lda, aw, c0w, U, ldu, uw,
+                     st, moves, tmp, tld);
+  hipLaunchKernelGGL(gf2_elim_scatter_kernel, dim3(2 * GF2K_ELIM_BLOCK_PIVOTS), dim3(256), 0, s, A, lda, aw, c0w, U, ldu, uw,
+                     st, moves, tmp, tld);
+  hipLaunchKernelGGL(gf2_elim_toggle_kernel, dim3(GF2K_ELIM_BLOCK_PIVOTS / 256), dim3(256), 0, s, U, ldu, st);
   return hipGetLastError();
 }
 

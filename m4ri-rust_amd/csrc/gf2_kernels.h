@@ -28,22 +28,30 @@ struct gf2k_mul_args {
 // Device-side record of a blocked elimination (gf2_elim.hip): the kernels of a step read their ranges from it, so a
 // whole column block is enqueued without host round trips.
 struct gf2k_elim_state {
-  int r0;     // rank when the current column block started
-  int r_cur;  // rank so far: rows [0, r_cur) hold the pivots found, in pivot-column order
-  int np;     // pivots found by the current step (one 64-bit word of columns)
-  int nmoves;
-  int jbase;  // r_cur - r0 before the current step: index of its first pivot inside the block
-  int pad_;
-  unsigned long long pcmask;   // pivot columns of the current word
-  int mv_src[128], mv_dst[128], mv_piv[128];  // row moves of the step (mv_piv >= 0: the source is pivot mv_piv)
+  int r0;      // rank when the current column block started: rows [0, r0) hold the pivots of the earlier blocks in order
+  int r_cur;   // rank so far
+  int np;      // pivots found by the current step (one 64-bit word of columns)
+  int nmoves;  // row moves of the block-end permutation
+  int jbase;   // r_cur - r0 before the current step: index of its first pivot inside the block
+  int scan;    // every row in [r0, scan) is a pivot of the current block: the search for candidates starts here
+  unsigned long long pcmask;  // pivot columns of the current word
+  int cur_row[64];            // rows chosen by the current step (their flag says "pivot of this step" until the next one)
 };
+// Row flags (one byte per row) during a block: 0 = ordinary row, 1 + c = pivot of the CURRENT step with pivot column c of
+// the word, 255 = pivot of an earlier step of this block.  Rows are not moved inside a block; gf2k_elim_end_block brings
+// block pivot j to row r0 + j.
+enum { GF2K_ELIM_BLOCK_PIVOTS = 2048 };
 
 extern "C" {
 hipError_t gf2k_elim_begin_block(gf2k_elim_state *st, hipStream_t s);
-hipError_t gf2k_elim_step(uint64_t *A, long long lda, int m, long long aw, long long c0w, int sw, int j, uint64_t colmask,
-                          int full, uint64_t *U, long long ldu, int uw, gf2k_elim_state *st, int *pivcols, uint64_t *ptab,
-                          uint64_t *tmp, long long tld, hipStream_t s);
-hipError_t gf2k_elim_toggle(uint64_t *U, long long ldu, int max_rank, gf2k_elim_state *st, hipStream_t s);
+hipError_t gf2k_elim_step(uint64_t *A, long long lda, int m, long long c0w, int sw, int j, uint64_t colmask, int full,
+                          uint64_t *U, long long ldu, int uw, gf2k_elim_state *st, int *pivcols, uint64_t *ptab,
+                          unsigned char *rowflag, int *blkpiv, hipStream_t s);
+// end of a block: permutation of whole rows (columns [c0w, aw) and the tracking words) through `tmp` (>= 2 *
+// GF2K_ELIM_BLOCK_PIVOTS rows of tld words), flags cleared, U' toggled; `moves` holds 4 * GF2K_ELIM_BLOCK_PIVOTS ints
+hipError_t gf2k_elim_end_block(uint64_t *A, long long lda, long long aw, long long c0w, uint64_t *U, long long ldu, int uw,
+                               gf2k_elim_state *st, unsigned char *rowflag, const int *blkpiv, int *moves, uint64_t *tmp,
+                               long long tld, hipStream_t s);
 hipError_t gf2k_set_diag(uint64_t *M, long long ld, int n, long long col0, hipStream_t s);
 hipError_t gf2k_scatter_rows(uint64_t *X, long long ldx, const uint64_t *R, long long ldr, int words, const int *pivcols,
                              int rank, hipStream_t s);

@@ -1005,16 +1005,20 @@ int echelonize_dev(gf2_dmat *A, int full, int col_limit, int *rank_out, int *piv
   const long long pld = (aw + 1) & ~1ll, tld = aw + uw;
   const int prow_max = m < KBW * 64 ? m : KBW * 64;
 
-  DevBuf st, pivs, U, ptab, tmp, P;
+  DevBuf st, pivs, U, ptab, tmp, P, flags, blkpiv, moves;
   DevBuf &pv = pivcols_keep ? *pivcols_keep : pivs;
   if (int rc = st.alloc(sizeof(gf2k_elim_state))) return rc;
   if (int rc = pv.alloc((size_t)(max_rank + 64) * sizeof(int))) return rc;
   if (int rc = U.alloc((size_t)m * uw * sizeof(u64))) return rc;
   if (int rc = ptab.alloc(64 * 64 * sizeof(u64))) return rc;
-  if (int rc = tmp.alloc((size_t)128 * tld * sizeof(u64))) return rc;
+  if (int rc = tmp.alloc((size_t)2 * GF2K_ELIM_BLOCK_PIVOTS * tld * sizeof(u64))) return rc;
   if (int rc = P.alloc((size_t)prow_max * pld * sizeof(u64))) return rc;
+  if (int rc = flags.alloc((size_t)m)) return rc;
+  if (int rc = blkpiv.alloc(GF2K_ELIM_BLOCK_PIVOTS * sizeof(int))) return rc;
+  if (int rc = moves.alloc(4 * GF2K_ELIM_BLOCK_PIVOTS * sizeof(int))) return rc;
   gf2k_elim_state *dst = st.as<gf2k_elim_state>();
   HIP_TRY(hipMemsetAsync(dst, 0, sizeof(gf2k_elim_state), s));
+  HIP_TRY(hipMemsetAsync(flags.p, 0, (size_t)m, s));
 
   int r_cur = 0;
   for (long long c0w = 0; c0w < lw && r_cur < m; c0w += KBW) {
@@ -1024,10 +1028,11 @@ int echelonize_dev(gf2_dmat *A, int full, int col_limit, int *rank_out, int *piv
     for (int j = 0; j < sw; ++j) {
       const bool last = (c0w + j == lw - 1) && (limit & 63);
       const u64 colmask = last ? ((1ull << (limit & 63)) - 1) : ~0ull;
-      HIP_TRY(gf2k_elim_step(A->data, lda, m, aw, c0w, sw, j, colmask, full, U.as<u64>(), uw, uw, dst, pv.as<int>(),
-                             ptab.as<u64>(), tmp.as<u64>(), tld, s));
+      HIP_TRY(gf2k_elim_step(A->data, lda, m, c0w, sw, j, colmask, full, U.as<u64>(), uw, uw, dst, pv.as<int>(),
+                             ptab.as<u64>(), flags.as<unsigned char>(), blkpiv.as<int>(), s));
     }
-    HIP_TRY(gf2k_elim_toggle(U.as<u64>(), uw, prow_max, dst, s));
+    HIP_TRY(gf2k_elim_end_block(A->data, lda, aw, c0w, U.as<u64>(), uw, uw, dst, flags.as<unsigned char>(), blkpiv.as<int>(),
+                                moves.as<int>(), tmp.as<u64>(), tld, s));
     int head[2] = {0, 0};  // r0, r_cur
     HIP_TRY(hipMemcpyAsync(head, dst, sizeof(head), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
