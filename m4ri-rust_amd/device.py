@@ -85,6 +85,36 @@ class DMat:
     def to_words(self, stream=None):
         return self.to_host(stream).to_words()
 
+    # -- the friendly layer's operators on device-resident operands: same meaning as on
+    #    BinMatrix (binary_matrix.rs:434-526), no PCIe traffic; everything runs on the default stream --
+    def __mul__(self, other):
+        return mul(self, other)
+
+    def __add__(self, other):
+        return add(self, other)
+
+    def __eq__(self, other):
+        return isinstance(other, DMat) and equal(self, other)
+
+    __hash__ = None
+
+    def transposed(self):
+        return transpose(self)
+
+    def clone(self):
+        zero = DMat(self.nrows, self.ncols)
+        _lib.check(_lib.lib().gf2_add_dev(ctypes.byref(zero.s), ctypes.byref(self.s), ctypes.byref(self.s), None), "gf2_add_dev")
+        return add(self, zero)  # self ^ (self ^ self)
+
+    def rank(self):
+        return echelonize(self.clone(), full=False)[0]
+
+    def inverted(self):
+        inv = inverse(self)
+        if inv is None:
+            raise _lib.HipError("matrix is singular")
+        return inv
+
 
 def mul(A, B, C=None, accumulate=False, algo="auto", param=0, stream=None):
     """C (+)= A*B on the device; asynchronous on `stream` (int hipStream_t or None)."""

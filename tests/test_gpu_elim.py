@@ -290,3 +290,19 @@ def test_elimination_fixtures(pkg, path):
         assert np.array_equal(B.to_words(), d["x"])
         B2 = pkg.BinMatrix.from_words(d["b_inconsistent"], k)
         assert pkg.solve_left(pkg.BinMatrix.from_words(d["a"], n), B2) is (not bool(d["inconsistent"][0]))
+
+
+def test_device_operators(pkg, dev):
+    """DMat mirrors the friendly operators on device-resident operands: chained work without PCIe round trips."""
+    n = 3000
+    a, b = g.random_words(n, n, 5), g.random_words(n, n, 6)
+    A, B = dev.DMat.from_words(a, n), dev.DMat.from_words(b, n)
+    ab = g.o_mul_m4rm(a, b, n, n, n)
+    assert np.array_equal((A * B).to_words(), ab)
+    assert np.array_equal((A + B).to_words(), a ^ b)
+    assert (A * B).transposed() == B.transposed() * A.transposed()
+    assert A.clone() == A and not (A == B)
+    assert A.rank() == g.o_echelonize(a, n, n)[1] and np.array_equal(A.to_words(), a)
+    inv = dev.DMat.from_words(_invertible(500, 77), 500)
+    ident = dev.DMat.from_words(g.bits_to_words(np.eye(500, dtype=np.uint8)), 500)
+    assert inv * inv.inverted() == ident
