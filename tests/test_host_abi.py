@@ -195,6 +195,21 @@ def test_mul_fails_loudly_without_gpu(pkg):
         device.require_gpu()
 
 
+def test_elimination_fails_loudly_without_gpu(pkg):
+    """mzd_echelonize / mzd_solve_left return a rank / a status, so a missing device cannot be reported through them: the
+    process is stopped with a diagnostic (no CPU fallback); mzd_inv_m4ri returns NULL like the products."""
+    from m4ri_rust_amd import device
+    if device.device_count() > 0:
+        pytest.skip("a GPU is present: the loud-failure path is for GPU-less hosts")
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import m4ri_rust_amd as p; "
+            "print(p.BinMatrix.identity(8).rank())" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode != 0 and "mzd_echelonize failed" in r.stderr and "no CPU fallback" in r.stderr
+    with pytest.raises(pkg.PanicError, match="Can't be NULL"):
+        pkg.BinMatrix.identity(8).inverted()
+
+
 def test_product_code_never_touches_the_oracle():
     """The product path must not import, link or execute anything under oracle/."""
     for dirpath, _, files in os.walk(os.path.join(ROOT, "m4ri-rust_amd")):
