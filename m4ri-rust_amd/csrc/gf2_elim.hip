@@ -79,9 +79,12 @@ __global__ __launch_bounds__(1024) void gf2_elim_pivot_kernel(const u64 *__restr
   for (int base = scan0; base < m; base += csz, csz = 1024) {
     const int i = base + tid;
     // w: candidate reduced against the basis; t: which chosen rows were added to it
-    const unsigned char fl = (tid < csz && i < m) ? rowflag[i] : 1;  // pivots of this block are no candidates
+    // flag and word are requested together (the word of a flagged row is simply discarded): one memory latency, not two
+    const bool inr = tid < csz && i < m;
+    const unsigned char fl = inr ? rowflag[i] : 1;  // pivots of this block are no candidates
+    const u64 wraw = inr ? A[(long long)i * lda + wc] : 0;
     if (base == scan0) f0 = fl;
-    u64 w = fl == 0 ? (A[(long long)i * lda + wc] & colmask) : 0, t = 0;
+    u64 w = fl == 0 ? (wraw & colmask) : 0, t = 0;
     int done = 0;  // basis vectors already applied to w
     for (;;) {
       const int nb = s_nb;
