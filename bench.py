@@ -45,6 +45,9 @@ def main():
                          "but 4 x 32768x65536x16384 take 31 ms; from 4 GPUs on the transfer is the longer leg)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--check", action="store_true", help="spot-check rows of C against the oracle after timing")
+    ap.add_argument("--density", default="half", choices=["half", "sparse", "ones"],
+                    help="N = 1 only: bit density of the synthetic operands -- half = i.i.d. Bernoulli(1/2) (the metric's "
+                         "workload), sparse = 1/64, ones = all ones (clock / data-dependence sanity runs, SURVEY.md section 8d)")
     args = ap.parse_args()
 
     import torch
@@ -98,6 +101,19 @@ def main():
         B = device.DMat.from_torch(B_t, n)
         C = device.DMat.from_torch(C_t, n)
         B.fill_random(2, stream)
+        if args.density != "half":
+            with torch.cuda.stream(comp):
+                if args.density == "ones":
+                    A_t.fill_(-1)
+                    B_t.fill_(-1)
+                else:  # AND of six independent fills: density 2^-6
+                    tmp_t = torch.empty_like(A_t)
+                    tmp = device.DMat.from_torch(tmp_t, n)
+                    for t_, base in ((A_t, 100), (B_t, 200)):
+                        for k in range(5):
+                            tmp.fill_random(base + k, stream)
+                            t_.bitwise_and_(tmp_t)
+                    del tmp, tmp_t
     else:
         # B and C are kept as P column panels ("tiles"), each contiguous, so that a panel can be broadcast /
         # gathered by RCCL while the previous one is being multiplied
@@ -194,7 +210,7 @@ def main():
         "scaling": "strong" if world > 1 else "weak",
         "vs_baseline": None,
         "dtype": "u64",
-        "data": "synthetic",
+        "data": "synthetic" if args.density == "half" else "synthetic, bit density %s" % args.density,
         "config": {
             "workload": "GF(2) %dx%dx%d matmul, inputs resident in HBM, %s" % (
                 n, n, n, "Strassen(%d levels)-over-M4RM" % levels if levels else "M4RM only"),

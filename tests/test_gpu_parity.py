@@ -386,3 +386,27 @@ def test_strassen_overlap_switch(pkg, dev, monkeypatch):
         monkeypatch.setenv("M4RI_HIP_STRASSEN_OVERLAP", "0")
         C0 = dev.mul(A, B, algo="strassen", param=levels)
         assert dev.equal(C1, ref) and dev.equal(C1b, ref) and dev.equal(C0, ref)
+
+
+@pytest.mark.parametrize("kind", ["sparse", "ones", "zero_a", "identity_b"])
+def test_extreme_densities(pkg, dev, kind):
+    """Sparse (density 1/64), all-ones and degenerate operands: the table kernels are data-independent, the split-K and
+    v*A paths skip zero partial sums; all must agree with the oracle (SURVEY.md section 8d's sanity inputs)."""
+    n = 2048
+    if kind == "sparse":
+        a = g.random_words(n, n, 1)
+        b = g.random_words(n, n, 2)
+        for k in range(5):
+            a &= g.random_words(n, n, 10 + k)
+            b &= g.random_words(n, n, 20 + k)
+    elif kind == "ones":
+        a = np.full((n, n // 64), np.uint64(0xFFFFFFFFFFFFFFFF))
+        b = a.copy()
+    elif kind == "zero_a":
+        a, b = np.zeros((n, n // 64), dtype=np.uint64), g.random_words(n, n, 2)
+    else:
+        a, b = g.random_words(n, n, 1), g.bits_to_words(np.eye(n, dtype=np.uint8))
+    ref = g.o_mul_m4rm(a, b, n, n, n)
+    A, B = dev.DMat.from_words(a, n), dev.DMat.from_words(b, n)
+    for algo, param in (("m4rm", 0), ("strassen", 1), ("strassen", 2)):
+        assert np.array_equal(dev.mul(A, B, algo=algo, param=param).to_words(), ref), (kind, algo, param)
