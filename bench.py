@@ -29,6 +29,17 @@ HBM_COPY_GBS = 6290.0
 LDS_PEAK_TBS = 150.0       # aggregate ds_read_b128 rate, all CUs (MI355X_MICROARCH.md, LDS)
 
 
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -275,7 +286,7 @@ def main():
             "value": 2.0 * cn ** 3 / cdt, "unit": "bit-ops/s", "cores": 1, "kind": "port",
             "sample": "one %dx%dx%d product by oracle_mul_fast (single-thread M4RM k=8 + Strassen-Winograd, "
                       "gcc -Ofast, no -march), %.2f s; M4RI itself is absent from the reference tree" % (cn, cn, cn, cdt),
-            "host_cpus": os.cpu_count(),
+            "host_cpus": os.cpu_count(), "host_cpu_model": _cpu_model(),
         }
         if args.check and cn <= n:
             # the GPU must reproduce the CPU sample product bit for bit
