@@ -306,3 +306,43 @@ def test_device_operators(pkg, dev):
     inv = dev.DMat.from_words(_invertible(500, 77), 500)
     ident = dev.DMat.from_words(g.bits_to_words(np.eye(500, dtype=np.uint8)), 500)
     assert inv * inv.inverted() == ident
+
+
+def test_concurrent_host_threads_elimination(pkg):
+    """BinMatrix is Send + Sync upstream (binary_matrix.rs:38-39): several host threads run rank / inverse / products on
+    shared inputs at once through the C ABI (ctypes drops the GIL); every call owns its stream and buffers."""
+    import threading
+    n = 1500
+    a = _invertible(n, 5)
+    low = _low_rank(1200, 1700, 333, 6)
+    A, Lo = pkg.BinMatrix.from_words(a, n), pkg.BinMatrix.from_words(low, 1700)
+    inv_ref = g.o_inverse(a, n)
+    rank_ref = g.o_echelonize(low, 1200, 1700)[1]
+    rref_ref = g.o_echelonize(low, 1200, 1700, full=True)[0]
+    ident = pkg.BinMatrix.identity(n)
+    errors = []
+
+    def worker(k):
+        try:
+            for it in range(4):
+                what = (k + it) % 4
+                if what == 0:
+                    ok = np.array_equal(A.inverted().to_words(), inv_ref)
+                elif what == 1:
+                    ok = Lo.rank() == rank_ref
+                elif what == 2:
+                    c = Lo.clone()
+                    ok = c.echelonize(full=True) == rank_ref and np.array_equal(c.to_words(), rref_ref)
+                else:
+                    ok = (A * A.inverted()) == ident
+                if not ok:
+                    errors.append((k, it, what))
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
