@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--levels", type=int, default=0, help="Strassen levels (0 = automatic)")
     ap.add_argument("--cpu-n", type=int, default=32768, help="dimension of the CPU-baseline sample product")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-threads", type=int, default=16,
+                    help="threads of the additional multi-core CPU figure (0/1 = skip; 16 = a one-GPU box's CPU share)")
     ap.add_argument("--panels", type=int, default=0,
                     help="column panels of B per step when N > 1 (RCCL/compute overlap); 0 = 2 panels on 2 GPUs, 4 above "
                          "(measured per-rank products: thin panels cost Strassen efficiency, 32768x65536x32768 takes 13.0 ms "
@@ -288,6 +290,28 @@ def main():
                       "gcc -Ofast, no -march), %.2f s; M4RI itself is absent from the reference tree" % (cn, cn, cn, cdt),
             "host_cpus": os.cpu_count(), "host_cpu_model": _cpu_model(),
         }
+        # optional second figure: the same port on several cores, row blocks of A in threads
+        # (ctypes releases the GIL).  NOT the reference's configuration: its M4RI build is single-threaded.
+        nthr = min(args.cpu_threads, os.cpu_count() or 1, cn // 2048)
+        if nthr > 1:
+            import threading
+            blk = cn // nthr
+            outs = [None] * nthr
+
+            def work(k):
+                outs[k] = g.o_mul_fast(np.ascontiguousarray(a[k * blk:(k + 1) * blk]), b, blk, cn, cn)
+
+            t1 = time.perf_counter()
+            ths = [threading.Thread(target=work, args=(k,)) for k in range(nthr)]
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+            mdt = time.perf_counter() - t1
+            out["cpu_baseline"]["threaded_port"] = {
+                "value": 2.0 * (blk * nthr) * cn * cn / mdt, "unit": "bit-ops/s", "cores": nthr,
+                "matches_single_core": bool(np.array_equal(np.concatenate(outs), c[:blk * nthr])),
+                "note": "non-reference configuration (the reference builds M4RI single-threaded): row blocks of A in %d threads, %.2f s" % (nthr, mdt)}
         if args.check and cn <= n:
             # the GPU must reproduce the CPU sample product bit for bit
             Ad, Bd = device.DMat.random(cn, cn, 1), device.DMat.random(cn, cn, 2)
