@@ -395,7 +395,23 @@ __global__ void gf2_elim_begin_block_kernel(gf2k_elim_state *st) {
     st->r0 = st->r_cur;
     st->scan = st->r_cur;
     st->np = 0;
+    st->lastword = -1;
   }
+}
+
+// last non-zero word (absolute index, words [w_lo, aw)) over the block's pivot rows [r0, r_cur) after the permutation: the
+// trailing product only has to cover the columns up to it (an augmented identity is mostly zero columns for a long time)
+__global__ __launch_bounds__(256) void gf2_elim_lastword_kernel(const u64 *__restrict__ A, long long lda, long long aw,
+                                                                long long w_lo, gf2k_elim_state *st) {
+  const int r0 = st->r0, rp = st->r_cur - r0;
+  const long long nwd = aw - w_lo, total = (long long)rp * nwd;
+  int best = -1;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / nwd, w = w_lo + i % nwd;
+    if (A[(r0 + r) * lda + w]) best = max(best, (int)w);
+  }
+  for (int o = 32; o; o >>= 1) best = max(best, __shfl_xor(best, o));
+  if ((threadIdx.x & 63) == 0 && best >= 0) atomicMax(&st->lastword, best);
 }
 
 // pivot row j of the block holds its own original content on the right-hand columns: U'[r0+j][j] ^= 1 turns
@@ -465,13 +481,14 @@ extern "C" hipError_t gf2k_elim_step(u64 *A, long long lda, int m, long long c0w
 
 extern "C" hipError_t gf2k_elim_end_block(u64 *A, long long lda, long long aw, long long c0w, u64 *U, long long ldu, int uw,
                                           gf2k_elim_state *st, unsigned char *rowflag, const int *blkpiv, int *moves, u64 *tmp,
-                                          long long tld, hipStream_t s) {
+                                          long long tld, long long w_right, hipStream_t s) {
   hipLaunchKernelGGL(gf2_elim_plan_kernel, dim3(1), dim3(1024), 0, s, st, rowflag, blkpiv, moves);
   hipLaunchKernelGGL(gf2_elim_gather_kernel, dim3(2 * GF2K_ELIM_BLOCK_PIVOTS), dim3(256), 0, s, A, lda, aw, c0w, U, ldu, uw,
                      st, moves, tmp, tld);
   hipLaunchKernelGGL(gf2_elim_scatter_kernel, dim3(2 * GF2K_ELIM_BLOCK_PIVOTS), dim3(256), 0, s, A, lda, aw, c0w, U, ldu, uw,
                      st, moves, tmp, tld);
   hipLaunchKernelGGL(gf2_elim_toggle_kernel, dim3(GF2K_ELIM_BLOCK_PIVOTS / 256), dim3(256), 0, s, U, ldu, st);
+  if (w_right < aw) hipLaunchKernelGGL(gf2_elim_lastword_kernel, dim3(1024), dim3(256), 0, s, A, lda, aw, w_right, st);
   return hipGetLastError();
 }
 

@@ -34,6 +34,7 @@ struct gf2k_elim_state {
   int nmoves;  // row moves of the block-end permutation
   int jbase;   // r_cur - r0 before the current step: index of its first pivot inside the block
   int scan;    // every row in [r0, scan) is a pivot of the current block: the search for candidates starts here
+  int lastword;  // after gf2k_elim_end_block: last word index (absolute) in which a pivot row of the block is non-zero
   unsigned long long pcmask;  // pivot columns of the current word
   int cur_row[64];            // rows chosen by the current step (their flag says "pivot of this step" until the next one)
 };
@@ -48,10 +49,11 @@ hipError_t gf2k_elim_step(uint64_t *A, long long lda, int m, long long c0w, int 
                           uint64_t *U, long long ldu, int uw, gf2k_elim_state *st, int *pivcols, uint64_t *ptab,
                           unsigned char *rowflag, int *blkpiv, hipStream_t s);
 // end of a block: permutation of whole rows (columns [c0w, aw) and the tracking words) through `tmp` (>= 2 *
-// GF2K_ELIM_BLOCK_PIVOTS rows of tld words), flags cleared, U' toggled; `moves` holds 4 * GF2K_ELIM_BLOCK_PIVOTS ints
+// GF2K_ELIM_BLOCK_PIVOTS rows of tld words), flags cleared, U' toggled, st->lastword set over words [w_right, aw);
+// `moves` holds 4 * GF2K_ELIM_BLOCK_PIVOTS ints
 hipError_t gf2k_elim_end_block(uint64_t *A, long long lda, long long aw, long long c0w, uint64_t *U, long long ldu, int uw,
                                gf2k_elim_state *st, unsigned char *rowflag, const int *blkpiv, int *moves, uint64_t *tmp,
-                               long long tld, hipStream_t s);
+                               long long tld, long long w_right, hipStream_t s);
 hipError_t gf2k_set_diag(uint64_t *M, long long ld, int n, long long col0, hipStream_t s);
 hipError_t gf2k_scatter_rows(uint64_t *X, long long ldx, const uint64_t *R, long long ldr, int words, const int *pivcols,
                              int rank, hipStream_t s);

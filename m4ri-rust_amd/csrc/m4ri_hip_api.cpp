@@ -1032,19 +1032,20 @@ int echelonize_dev(gf2_dmat *A, int full, int col_limit, int *rank_out, int *piv
                              ptab.as<u64>(), flags.as<unsigned char>(), blkpiv.as<int>(), s));
     }
     HIP_TRY(gf2k_elim_end_block(A->data, lda, aw, c0w, U.as<u64>(), uw, uw, dst, flags.as<unsigned char>(), blkpiv.as<int>(),
-                                moves.as<int>(), tmp.as<u64>(), tld, s));
-    int head[2] = {0, 0};  // r0, r_cur
+                                moves.as<int>(), tmp.as<u64>(), tld, c0w + sw, s));
+    int head[7] = {0, 0, 0, 0, 0, 0, -1};  // r0, r_cur, np, nmoves, jbase, scan, lastword
     HIP_TRY(hipMemcpyAsync(head, dst, sizeof(head), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     const int r0 = head[0], rp = head[1] - head[0];
     r_cur = head[1];
     const long long cR = c0w + sw;
-    if (rp > 0 && cR < aw) {
+    const long long wlast = head[6];  // the block's pivot rows are zero beyond this word: so is their contribution
+    if (rp > 0 && cR < aw && wlast >= cR) {
       // everything right of the block in one product: A[rows, right] ^= U'[rows, 0:rp] * (pivot rows of the block)
       const int rows_lo = full ? 0 : r0;
-      const int nright = ncols - (int)(cR * 64);
+      const int nright = wlast == aw - 1 ? ncols - (int)(cR * 64) : (int)((wlast + 1 - cR) * 64);
       HIP_TRY(hipMemcpy2DAsync(P.p, (size_t)pld * sizeof(u64), A->data + (long long)r0 * lda + cR, (size_t)lda * sizeof(u64),
-                               (size_t)(aw - cR) * sizeof(u64), rp, hipMemcpyDeviceToDevice, s));
+                               (size_t)(wlast + 1 - cR) * sizeof(u64), rp, hipMemcpyDeviceToDevice, s));
       gf2_dmat Cw{A->data + (long long)rows_lo * lda + cR, lda, m - rows_lo, nright};
       gf2_dmat Uw{U.as<u64>() + (long long)rows_lo * uw, uw, m - rows_lo, rp};
       gf2_dmat Pw{P.as<u64>(), pld, rp, nright};
