@@ -181,6 +181,24 @@ class BinMatrix {
     return BinMatrix(mzd_mul_naive(nullptr, mzd_, vt.mzd_));
   }
 
+  // serde wire format (feature "serde", binary_matrix.rs:10-35): exactly what serde_json::to_string prints
+  // (test_serialize, binary_matrix.rs:693-699): {"matrix":{"rows":[{"len":N,"vec":[u64 words]},...]}}
+  std::string to_json() const {
+    std::string out = "{\"matrix\":{\"rows\":[";
+    for (size_t r = 0; r < nrows(); ++r) {
+      if (r) out += ',';
+      out += "{\"len\":" + std::to_string(ncols()) + ",\"vec\":[";
+      for (wi_t j = 0; j < mzd_->width; ++j) {
+        uint64_t v = mzd_->rows[r][j];
+        if (j == mzd_->width - 1) v &= mzd_->high_bitmask;
+        if (j) out += ',';
+        out += std::to_string(v);
+      }
+      out += "]}";
+    }
+    return out + "]}}";
+  }
+
   bool operator==(const BinMatrix &o) const { return mzd_equal(mzd_, o.mzd_) == 1; }  // binary_matrix.rs:434-438
   bool operator!=(const BinMatrix &o) const { return !(*this == o); }
   BinMatrix operator+(const BinMatrix &o) const { return BinMatrix(mzd_add(nullptr, mzd_, o.mzd_)); }

@@ -186,6 +186,16 @@ class BinVector:
         x = self._w[:k] & other._w[:k]
         return sum(bin(int(v)).count("1") for v in x) % 2 == 1
 
+    def to_json(self):
+        """serde format of BinVector { vec: Vob } (binary_vector.rs:13-17): {"vec":{"len":N,"vec":[u64 words]}}."""
+        return '{"vec":{"len":%d,"vec":[%s]}}' % (len(self), ",".join(str(int(w)) for w in self.get_storage()))
+
+    @staticmethod
+    def from_json(text):
+        import json
+        v = json.loads(text)["vec"]
+        return BinVector(np.array(v["vec"], dtype=np.uint64), v["len"])
+
     def __repr__(self):
         return "BinVector(%s)" % "".join("1" if b else "0" for b in self.to_bools())
 
@@ -377,6 +387,24 @@ class BinMatrix:
 
     def __repr__(self):
         return "BinMatrix(%dx%d)" % (self.nrows(), self.ncols())
+
+    # -- serde wire format (feature "serde", binary_matrix.rs:10-35): {"matrix":{"rows":[<Vob>, ...]}}, a Vob being
+    #    {"len": bits, "vec": [u64 words, LSB-first]}; byte-for-byte what serde_json::to_string prints (test_serialize,
+    #    binary_matrix.rs:693-699).  Upstream only serialises matrices; from_json is the obvious inverse. --
+    def to_json(self):
+        words = self.to_words()
+        n = self.ncols()
+        rows = ",".join('{"len":%d,"vec":[%s]}' % (n, ",".join(str(int(w)) for w in r)) for r in words)
+        return '{"matrix":{"rows":[%s]}}' % rows
+
+    @staticmethod
+    def from_json(text):
+        import json
+        rows = json.loads(text)["matrix"]["rows"]
+        if not rows:
+            raise PanicError("Can't create a 0 matrix")
+        n = rows[0]["len"]
+        return BinMatrix.from_slices([np.array(r["vec"], dtype=np.uint64) for r in rows], n)
 
 
 def solve_left(a, b):

@@ -41,6 +41,10 @@ static int host_tests() {
     BinVector w = r.as_vector();
     CHECK(w.len() == (size_t)i && r == w.as_matrix());
   }
+  {  // test_serialize (binary_matrix.rs:693-699)
+    CHECK(BinMatrix::identity(3).to_json() ==
+          "{\"matrix\":{\"rows\":[{\"len\":3,\"vec\":[1]},{\"len\":3,\"vec\":[2]},{\"len\":3,\"vec\":[4]}]}}");
+  }
   {  // BinVector (binary_vector.rs:222-287)
     CHECK(BinVector::from_bytes({0xFF}).len() == 8);
     BinVector b = BinVector::from_bytes({0x80});

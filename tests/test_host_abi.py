@@ -231,3 +231,14 @@ def test_binary_file_roundtrip(pkg, tmp_path):
         assert back and pkg.BinMatrix(back) == m
         assert os.path.getsize(path) == 16 + r * g.width(c) * 8
     assert not L.gf2_mzd_load(str(tmp_path / "missing.gf2").encode())
+
+
+def test_serde_wire_format(pkg):
+    """The reference's own known answer (binary_matrix.rs:693-699, feature "serde")."""
+    m = pkg.BinMatrix.identity(3)
+    assert m.to_json() == '{"matrix":{"rows":[{"len":3,"vec":[1]},{"len":3,"vec":[2]},{"len":3,"vec":[4]}]}}'
+    big = pkg.BinMatrix.from_words(g.random_words(5, 130, 9), 130)
+    back = pkg.BinMatrix.from_json(big.to_json())
+    assert back == big and back.ncols() == 130
+    v = pkg.BinVector.from_bools([True, False, True])
+    assert v.to_json() == '{"vec":{"len":3,"vec":[5]}}' and pkg.BinVector.from_json(v.to_json()) == v
