@@ -861,195 +861,164 @@ __global__ __launch_bounds__(NT) void gf2_tallskinny_kernel(const u64 *__restric
 }
 
 // ---------------------------------------------------------------------------------------------
-// tall-skinny kernel, second generation: same job as gf2_tallskinny_kernel (n <= 256, m large), used when the rows of B
-// are wider than 128 bits, where the first kernel's random 32-byte lookups collide in the LDS banks (50.6 us for
-// 2^20 x 256 times 256 x 256 against 36.5 us here).  Every lookup here is conflict-free:
-//   * a launch covers <= 256 bits of the inner dimension (the host loops over longer ones, accumulating into C) and
-//     blockIdx.y selects a panel of 128 columns; the 32 chunk tables of a panel (8-bit chunks, 16-byte entries) fill
-//     128 KiB: a 256-B LDS row holds entry e of 16 tables side by side;
-//   * a row is handled by a QUAD of lanes: lane j of quad k looks up, in step i, table 4*((i+k)&3)+j -- the rotation
-//     by k makes the 16 lanes that the LDS serves together hit 16 different tables, i.e. different banks; the
-//     selecting byte is byte j of dword (i+k)&3 of the row's 128-bit piece;
-//   * each lane accumulates all its lookups of a row in one register set; 2 DPP XORs (quad_perm) finish the row and
-//     lane 0 of the quad stores it (buffer store, 32-bit offsets);
-//   * workgroups are persistent (grid.x <= 256): the tables are built once (one thread per (table, word, high nibble):
-//     8 rows of B from global memory, 4 select-XORs + 15 Gray-code steps for 16 entries), then 8 waves stream
-//     half-blocks of 64 rows: coalesced buffer loads into a register ring of 4 half-blocks, a wave-private 2 KiB LDS
-//     staging area, rotated ds_read_b32 per lane.
-// Known limit: the row stores sit between the ring's loads, and since stores may complete out of order with respect to
-// loads the compiler has to wait for vmcnt(0) before a ring entry is consumed -- the effective prefetch distance is one
-// half-block, not four.  Tried: a dedicated store wave (the compute waves' waits then become vmcnt(15..12), the whole ring
-// stays in flight) -- 44.7 us instead of 36.5: with two waves per SIMD the dependent LDS chains of a half-block
-// (staged dword -> byte -> table entry -> XOR) bound the step, and the per-step workgroup barrier adds to it.
+// tall-skinny kernel with skewed lookups (used for n > 64): one lane per row like the first kernel, but with
+// conflict-free LDS lookups.  A 256-B LDS row holds entry e of TPR = 32/NW tables side by side (two such row sets =
+// 128 KiB).  Lane L visits the TPR chunks of a row set in the order c ^ s, s = L mod TPR, so that the lanes the LDS serves
+// together read TPR different tables, i.e. different banks.  To keep every register index static, the row's bytes are
+// XOR-permuted by s once after loading (dword butterfly with v_cndmask, bytes inside a dword with one v_perm_b32):
+// byte c of the permuted row is byte c ^ s of the row.  NW = 4 (two 16-byte reads per entry): lanes 8..15 of every 16
+// read the halves in the opposite order and swap their accumulators at the end.
 // ---------------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ u32 xor_dpp(u32 v) {
-  return v ^ (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
-}
-
-template <int NW>
-__global__ __launch_bounds__(512) void gf2_tallskinny2_kernel(const u64 *__restrict__ A, long long lda,
-                                                              const u64 *__restrict__ B, long long ldb,
-                                                              u64 *__restrict__ C, long long ldc, int m, int l, int n,
-                                                              int accumulate) {
+template <int NW, int RPT, int NT>
+__global__ __launch_bounds__(NT) void gf2_tallskinny3_kernel(const u64 *__restrict__ A, long long lda, const u64 *__restrict__ B,
+                                                              long long ldb, u64 *__restrict__ C, long long ldc, int m, int l,
+                                                              int n, int accumulate) {
   extern __shared__ __align__(16) unsigned char lds[];
-  constexpr int NT = 512;                // 8 waves, 256 VGPRs each
-  constexpr int D = 4;                   // half-blocks of 64 rows in flight per wave (register ring)
-  constexpr int kStage = 128 * 1024;     // wave-private staging of 64 rows x 32 B behind the tables (8 x 2 KiB)
+  constexpr int TPR = 32 / NW;            // tables per row set
+  constexpr int ND = TPR / 4;             // dwords of a row that select inside one row set
+  constexpr int WRS = TPR / 8;            // 64-bit words of the inner dimension per row set (NW=4: 1)
+  constexpr int kWordsPerGroup = 2 * WRS; // two row sets in LDS
+  constexpr int kStage = 128 * 1024;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row-block offsets go into SGPR operands
-  const int k = lane >> 2, j = lane & 3;
-  const int panel = blockIdx.y;
-  const int wl = (l + 63) >> 6, wn_all = (n + 63) >> 6;
-  const int wn = min(NW, wn_all - panel * NW);  // valid words of this panel
+  const int wl = (l + 63) >> 6, wn = (n + 63) >> 6;
   const u64 maskL = (l & 63) ? ((1ull << (l & 63)) - 1) : ~0ull;
-  const u64 maskC = (n & 63) ? ((1ull << (n & 63)) - 1) : ~0ull;
-  B += panel * NW;
-  C += panel * NW;
+  const long long row_base = (long long)blockIdx.x * (NT * RPT);
+  const int s = lane & (TPR - 1);
+  const u32 bsel = (s & 3) == 0 ? 0x03020100u : (s & 3) == 1 ? 0x02030001u : (s & 3) == 2 ? 0x01000302u : 0x00010203u;
+  const int hsw = NW == 4 ? (lane >> 3) & 1 : 0;  // NW=4: which 16-byte half this lane reads first
+  const u32 xl0 = (u32)s * (8u * NW) + (u32)hsw * 16u, xl1 = xl0 + 65536u;
 
-  // lane constants: in step i this lane uses table ((i+k)&3)*4+j, selected by byte j of dword (i+k)&3 of the 128-bit piece
-  u32 lane_tab[4], rot4[4];
+  u32 acc[RPT][2 * NW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int dq = (i + k) & 3, t = dq * 4 + j;
-    lane_tab[i] = NW == 1 ? (u32)(((k >> 2) & 1) * 128 + t * 8) : (u32)(t * 16);
-    rot4[i] = (u32)dq * 4u;
-  }
-  const u32 bsh = 8u * (u32)j;
+  for (int r = 0; r < RPT; ++r)
+#pragma unroll
+    for (int w = 0; w < 2 * NW; ++w) acc[r][w] = 0;
 
-  // A and C through buffer descriptors with 32-bit offsets (the launcher guarantees that they fit): the row block goes
-  // into the scalar offset, lanes that must not touch memory get an out-of-range vector offset (reads 0 / store dropped)
-  const u32 ldaB = (u32)lda * 8u, ldcB = (u32)ldc * 8u;
-  const __amdgpu_buffer_rsrc_t rsrcA =
-      __builtin_amdgcn_make_buffer_rsrc((void *)A, (short)0, (int)((u32)(m - 1) * ldaB + (u32)wl * 8u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrcC =
-      __builtin_amdgcn_make_buffer_rsrc((void *)C, (short)0, (int)((u32)(m - 1) * ldcB + (u32)wn * 8u), 0x00020000);
-  typedef u32 u32x2 __attribute__((ext_vector_type(2)));
-  // a half-block = 64 rows x 4 words; element e of lane L is word L%4 of row L/4 + 16e: consecutive lanes read
-  // consecutive words, so rows of 4 words (the LPN shape) arrive in fully coalesced 512-byte pieces
-  const bool wok = (lane & 3) < wl;
-  const u32 laneA = wok ? (u32)(lane >> 2) * ldaB + (u32)(lane & 3) * 8u : 0x80000000u;
-  const u64 lmask = (lane & 3) == wl - 1 ? maskL : ~0ull;
-  const u32 lmlo = (u32)lmask, lmhi = (u32)(lmask >> 32);
-  auto load_half = [&](long long row0, u32x2 (&pre)[4]) {
-    const bool inside = row0 + 64 <= m;  // uniform; only the last rows of the matrix need per-row checks
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const u32 vo = (inside || row0 + 16 * e + (lane >> 2) < m) ? laneA : 0x80000000u;
-      // nothing may consume the loaded value here (that would put a wait right behind every load): the ragged-word
-      // mask is applied when the ring entry is written to the staging area
-      pre[e] = __builtin_amdgcn_raw_buffer_load_b64(rsrcA, vo, (u32)(row0 + 16 * e) * ldaB, 0);
+  for (int w0 = 0; w0 < wl; w0 += kWordsPerGroup) {  // group of 64-bit words of the inner dimension
+    __syncthreads();  // previous group's lookups are done
+    // stage the group's rows of B behind the tables, coalesced (rows past l are zero: their tables select nothing)
+    u64 *bst = reinterpret_cast<u64 *>(lds + kStage);
+    for (int idx = tid; idx < kWordsPerGroup * 64 * NW; idx += NT) {
+      const int rr_ = idx / NW, w = idx % NW;
+      const long long brow = (long long)w0 * 64 + rr_;
+      bst[idx] = (brow < l && w < wn) ? B[brow * ldb + w] : 0;
     }
-  };
-  // half-block h of this wave covers rows (h * gridDim.x + blockIdx.x) * 512 + wave * 64 ...
-  const long long hstride = (long long)gridDim.x * NT;
-  const long long first = (long long)blockIdx.x * NT + wave * 64;
-  const long long nh = first < m ? (m - first + hstride - 1) / hstride : 0;
-  u32x2 ring[D][4];
+    __syncthreads();
+    // build: item = (row set, table, word, high nibble); lanes differ in (word, table) first -> conflict-free writes;
+    // 8 rows of B, 4 select-XORs, 15 Gray-code steps for the 16 entries of the nibble
+    for (int item = tid; item < 2 * TPR * NW * 16; item += NT) {
+      const int w = item % NW, t = (item / NW) % TPR;
+      int rest = item / (NW * TPR);
+      const int rs = rest & 1, h = rest >> 1;
+      const u64 *rows = bst + ((rs * TPR + t) * 8) * NW + w;
+      u64 v = 0;
 #pragma unroll
-  for (int d = 0; d < D; ++d)
-    if (d < nh) load_half(first + d * hstride, ring[d]);  // in flight while the tables are built
-
-  // build: item = (table group, table, word, high nibble [, copy]); lanes of a wave differ in (word, table) first.
-  // 8 rows of B per item straight from global memory, then 4 select-XORs + 15 Gray-code steps for 16 entries
-  for (int item = tid; item < (NW == 1 ? 2 : 1) * 2 * 16 * NW * 16; item += NT) {
-    const int w = item % NW, t = (item / NW) % 16;
-    int rest = item / (NW * 16);
-    const int tg = rest & 1;
-    rest >>= 1;
-    const int h = rest & 15, copy = rest >> 4;
-    u64 rw[8];
+      for (int b = 0; b < 4; ++b) v ^= rows[(4 + b) * NW] & (0ull - (u64)((h >> b) & 1));
+      const u64 r0 = rows[0], r1 = rows[NW], r2 = rows[2 * NW], r3 = rows[3 * NW];
+      unsigned char *tb = lds + rs * 65536 + t * (8 * NW) + w * 8;
 #pragma unroll
-    for (int b2 = 0; b2 < 8; ++b2) {
-      const int brow = (tg * 16 + t) * 8 + b2;
-      rw[b2] = (brow < l && w < wn) ? B[(long long)brow * ldb + w] : 0;
+      for (int i = 0; i < 16; ++i) {
+        const int gc = i ^ (i >> 1);
+        if (i) {
+          const int flip = __builtin_ctz(i);
+          v ^= flip == 0 ? r0 : flip == 1 ? r1 : flip == 2 ? r2 : r3;
+        }
+        *reinterpret_cast<u64 *>(tb + (h * 16 + gc) * 256) = v;
+      }
     }
-    u64 v = 0;
+    __syncthreads();
 #pragma unroll
-    for (int b2 = 0; b2 < 4; ++b2) v ^= rw[4 + b2] & (0ull - (u64)((h >> b2) & 1));
-    unsigned char *tb = lds + tg * 65536 + (NW == 1 ? copy * 128 + t * 8 : t * 16 + w * 8);
+    for (int r = 0; r < RPT; ++r) {
+      const long long row = min(row_base + (long long)r * NT + tid, (long long)m - 1);  // clamped: stores are guarded below
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {  // Gray code over the low nibble
-      const int gc = i ^ (i >> 1);
-      if (i) v ^= rw[__builtin_ctz(i)];
-      *reinterpret_cast<u64 *>(tb + (h * 16 + gc) * 256) = v;
-    }
-  }
-  __syncthreads();
-
-  unsigned char *const stg = lds + kStage + wave * 2048;
-  auto process = [&](long long row0) {  // the 64 staged rows: 4 groups of 16 rows, one quad per row
+      for (int rs = 0; rs < 2; ++rs) {
+        if ((w0 + rs * WRS) * 64 < l) {  // uniform: the row set holds bits of the inner dimension
+          u32 d[ND];
+          const int wi0 = w0 + rs * WRS;
+          if (wi0 + WRS <= wl) {  // uniform: the whole row set lies inside the row -> plain adjacent loads (they merge)
+            const u64 *ap = A + row * lda + wi0;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      u32 acc[2 * NW];
-#pragma unroll
-      for (int r = 0; r < 2 * NW; ++r) acc[r] = 0;
-      const unsigned char *rowp = stg + (16 * s + k) * 32;
-#pragma unroll
-      for (int tg = 0; tg < 2; ++tg) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const u32 dw = *reinterpret_cast<const u32 *>(rowp + tg * 16 + rot4[i]);
-          const u32 e = __builtin_amdgcn_ubfe(dw, bsh, 8u);
-          const unsigned char *tp = lds + tg * 65536 + ((e << 8) + lane_tab[i]);
-          // in-place asm XOR: keeps LLVM from re-associating the XOR chains across lookups
-          if constexpr (NW == 2) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(tp);
-            asm("v_xor_b32 %0, %1, %0" : "+v"(acc[0]) : "v"(v.x));
-            asm("v_xor_b32 %0, %1, %0" : "+v"(acc[1]) : "v"(v.y));
-            asm("v_xor_b32 %0, %1, %0" : "+v"(acc[2]) : "v"(v.z));
-            asm("v_xor_b32 %0, %1, %0" : "+v"(acc[3]) : "v"(v.w));
+            for (int q = 0; q < WRS; ++q) {
+              u64 aw = ap[q];
+              if (wi0 + q == wl - 1) aw &= maskL;
+              d[2 * q] = (u32)aw;
+              d[2 * q + 1] = (u32)(aw >> 32);
+            }
           } else {
-            const uint2 v = *reinterpret_cast<const uint2 *>(tp);
-            asm("v_xor_b32 %0, %1, %0" : "+v"(acc[0]) : "v"(v.x));
-            asm("v_xor_b32 %0, %1, %0" : "+v"(acc[1]) : "v"(v.y));
+#pragma unroll
+            for (int q = 0; q < WRS; ++q) {
+              const int wi = wi0 + q;
+              u64 aw = wi < wl ? A[row * lda + wi] : 0;
+              if (wi == wl - 1) aw &= maskL;
+              d[2 * q] = (u32)aw;
+              d[2 * q + 1] = (u32)(aw >> 32);
+            }
+          }
+          // byte c of the permuted dwords = byte c ^ s of the row set's bytes
+#pragma unroll
+          for (int k = 0; (1 << k) < ND; ++k) {
+            const bool sw = (s >> (2 + k)) & 1;
+            u32 t2[ND];
+#pragma unroll
+            for (int i = 0; i < ND; ++i) t2[i] = sw ? d[i ^ (1 << k)] : d[i];
+#pragma unroll
+            for (int i = 0; i < ND; ++i) d[i] = t2[i];
+          }
+#pragma unroll
+          for (int i = 0; i < ND; ++i) d[i] = __builtin_amdgcn_perm(d[i], d[i], bsel);
+          const u32 xl = rs ? xl1 : xl0;
+#pragma unroll
+          for (int c = 0; c < TPR; ++c) {
+            const u32 e = __builtin_amdgcn_ubfe(d[c >> 2], 8u * (c & 3), 8u);
+            const u32 off = (e << 8) | (xl ^ (u32)(c * 8 * NW));
+            const unsigned char *tp = lds + off;
+            if constexpr (NW == 1) {
+              const uint2 v = *reinterpret_cast<const uint2 *>(tp);
+              asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][0]) : "v"(v.x));
+              asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][1]) : "v"(v.y));
+            } else if constexpr (NW == 2) {
+              const uint4 v = *reinterpret_cast<const uint4 *>(tp);
+              asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][0]) : "v"(v.x));
+              asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][1]) : "v"(v.y));
+              asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][2]) : "v"(v.z));
+              asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][3]) : "v"(v.w));
+            } else {
+              const uint4 v = *reinterpret_cast<const uint4 *>(tp);
+              const uint4 v2 = *reinterpret_cast<const uint4 *>(lds + (off ^ 16u));
+              asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][0]) : "v"(v.x));
+              asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][1]) : "v"(v.y));
+              asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][2]) : "v"(v.z));
+              asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][3]) : "v"(v.w));
+              asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][4]) : "v"(v2.x));
+              asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][5]) : "v"(v2.y));
+              asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][6]) : "v"(v2.z));
+              asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][7]) : "v"(v2.w));
+            }
           }
         }
       }
+    }
+  }
+  const u64 maskC = (n & 63) ? ((1ull << (n & 63)) - 1) : ~0ull;
 #pragma unroll
-      for (int r2 = 0; r2 < 2 * NW; ++r2) acc[r2] = xor_dpp<0x4E>(xor_dpp<0xB1>(acc[r2]));  // quad_perm [1,0,3,2], [2,3,0,1]
-      // lane 0 of the quad stores the row
-      const u32 coff = (j == 0 && row0 + 16 * s + k < m) ? (u32)k * ldcB : 0x80000000u;
-      const u32 csoff = (u32)(row0 + 16 * s) * ldcB;
+  for (int r = 0; r < RPT; ++r) {
+    const long long row = row_base + (long long)r * NT + tid;
+    if (row < m) {
 #pragma unroll
       for (int w = 0; w < NW; ++w)
-        if (w < wn) {  // uniform
-          u32 lo = acc[2 * w], hi = acc[2 * w + 1];
-          if (panel * NW + w == wn_all - 1) {
-            lo &= (u32)maskC;
-            hi &= (u32)(maskC >> 32);
+        if (w < wn) {
+          // NW=4: lanes that read the upper half first hold words 2,3 in acc[0..3] and words 0,1 in acc[4..7]
+          u32 lo = acc[r][2 * w], hi = acc[r][2 * w + 1];
+          if constexpr (NW == 4) {
+            lo = hsw ? acc[r][(2 * w) ^ 4] : lo;
+            hi = hsw ? acc[r][(2 * w + 1) ^ 4] : hi;
           }
-          if (accumulate) {
-            const u32x2 old = __builtin_amdgcn_raw_buffer_load_b64(rsrcC, coff, csoff + w * 8, 0);
-            lo ^= old.x;
-            hi ^= old.y;
-          }
-          u32x2 o2;
-          o2.x = lo;
-          o2.y = hi;
-          __builtin_amdgcn_raw_buffer_store_b64(o2, rsrcC, coff, csoff + w * 8, 0);
+          u64 v = (u64)lo | ((u64)hi << 32);
+          if (w == wn - 1) v &= maskC;
+          u64 *dd = C + row * ldc + w;
+          if (accumulate) v ^= *dd;
+          *dd = v;
         }
-    }
-  };
-
-  for (long long h = 0; h < nh; h += D) {
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-      if (h + d < nh) {  // uniform per wave
-        // the staging area is private to the wave and LDS operations of one wave execute in order; no fence here:
-        // a fence would also wait for the global loads of the ring, which is exactly what must stay in flight
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          u32x2 x = ring[d][e];
-          x.x &= lmlo;
-          x.y &= lmhi;
-          *reinterpret_cast<u32x2 *>(stg + e * 512 + lane * 8) = x;
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (h + d + D < nh) load_half(first + (h + d + D) * hstride, ring[d]);
-        process(first + (h + d) * hstride);
-      }
     }
   }
 }
@@ -1558,28 +1527,29 @@ extern "C" hipError_t gf2k_tallskinny(const u64 *A, long long lda, const u64 *B,
   if (m <= 0 || n <= 0) return hipSuccess;
   if (n > 256 || l <= 0) return hipErrorInvalidValue;
   const int nw = (n + 63) / 64;
-  // measured on 2^20 x 256 times 256 x V: first kernel 14.6 / 21.3 / 50.6 us for V = 64 / 128 / 256, second 17.1 / 22.2 / 36.5:
-  // the second generation pays off once the entries are wider than 16 bytes (the first one then loses to LDS bank
-  // conflicts).  M4RI_HIP_TALLSKINNY_GEN=1|2 forces one of them (A/B runs).
+  // measured on 2^20 x 256 times 256 x V (us): first kernel 14.4 / 20.2 / 50.6 for V = 64 / 128 / 256, skewed kernel
+  // 22.1 / 17.5 / 33.2: the skew pays off once the entries are 16 bytes or wider (the first kernel then loses to LDS bank
+  // conflicts), below that its byte permutation costs more than the conflicts.  M4RI_HIP_TALLSKINNY_GEN=1|3 forces one.
   static const int forced_gen = getenv("M4RI_HIP_TALLSKINNY_GEN") ? atoi(getenv("M4RI_HIP_TALLSKINNY_GEN")) : 0;
-  const bool gen2 = forced_gen ? forced_gen == 2 : nw >= 3;
-  if (gen2 && ((long long)m + 1024) * lda * 8 < (1ll << 31) && ((long long)m + 1024) * ldc * 8 < (1ll << 31)) {
-    // second generation: <= 256 bits of the inner dimension per launch (longer ones accumulate into C pass by pass),
-    // column panels of 128 bits in blockIdx.y, persistent workgroups
-    const int panels = (nw + 1) / 2;
-    const long long nblk = ((long long)m + 511) / 512;
-    int gx = 256 / panels;
-    if (gx > nblk) gx = (int)nblk;
-    const size_t lds2 = 128 * 1024 + 8 * 2048;
-    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&gf2_tallskinny2_kernel<2>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-    if (e2 != hipSuccess) return e2;
-    for (int l0 = 0; l0 < l; l0 += 256) {
-      const int lp = l - l0 < 256 ? l - l0 : 256;
-      const int acc = (accumulate || l0 > 0) ? 1 : 0;
-      hipLaunchKernelGGL((gf2_tallskinny2_kernel<2>), dim3(gx, panels), dim3(512), lds2, stream, A + l0 / 64, lda,
-                         B + (long long)l0 * ldb, ldb, C, ldc, m, lp, n, acc);
+  if (forced_gen ? forced_gen == 3 : nw >= 2) {
+    constexpr int RPT3 = 4, NT3 = 1024;
+    const unsigned grid3 = (unsigned)(((long long)m + NT3 * RPT3 - 1) / (NT3 * RPT3));
+    const size_t lds3 = 128 * 1024 + 4 * 1024;
+    hipError_t e3;
+#define GF2_TS3_LAUNCH(NWV)                                                                                              \
+  e3 = hipFuncSetAttribute(reinterpret_cast<const void *>(&gf2_tallskinny3_kernel<NWV, RPT3, NT3>),                      \
+                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);                                       \
+  if (e3 != hipSuccess) return e3;                                                                                       \
+  hipLaunchKernelGGL((gf2_tallskinny3_kernel<NWV, RPT3, NT3>), dim3(grid3), dim3(NT3), lds3, stream, A, lda, B, ldb, C, ldc, m, \
+                     l, n, accumulate)
+    if (nw == 1) {
+      GF2_TS3_LAUNCH(1);
+    } else if (nw == 2) {
+      GF2_TS3_LAUNCH(2);
+    } else {
+      GF2_TS3_LAUNCH(4);
     }
+#undef GF2_TS3_LAUNCH
     return hipGetLastError();
   }
   constexpr int RPT = 4, NT = 1024;
