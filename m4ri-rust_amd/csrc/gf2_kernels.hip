@@ -255,6 +255,8 @@ __device__ __forceinline__ void static_for(F &&f) {
 
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const u32x4 lds_cu32x4;
+typedef u32 u32x2v __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const u32x2v lds_cu32x2;
 typedef __attribute__((address_space(3))) const u64 lds_cu64;
 typedef __attribute__((address_space(3))) u64 lds_u64;
 typedef __attribute__((address_space(3))) u32 lds_u32;
@@ -969,22 +971,22 @@ __global__ __launch_bounds__(NT) void gf2_tallskinny3_kernel(const u64 *__restri
           const u32 xl = rs ? xl1 : xl0;
 #pragma unroll
           for (int c = 0; c < TPR; ++c) {
-            const u32 e = __builtin_amdgcn_ubfe(d[c >> 2], 8u * (c & 3), 8u);
-            const u32 off = (e << 8) | (xl ^ (u32)(c * 8 * NW));
-            const unsigned char *tp = lds + off;
+            // LDS byte address {0, row set, selecting byte, skewed table offset} in one v_perm_b32 (bytes 0, 2, 3 from the
+            // lane's table offset, byte 1 = byte c&3 of the permuted dword); integer -> LDS pointer, no base to add
+            const u32 off = __builtin_amdgcn_perm(d[c >> 2], xl ^ (u32)(c * 8 * NW), 0x03020000u | ((4u + (c & 3)) << 8));
             if constexpr (NW == 1) {
-              const uint2 v = *reinterpret_cast<const uint2 *>(tp);
+              const u32x2v v = *reinterpret_cast<lds_cu32x2 *>(off);
               asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][0]) : "v"(v.x));
               asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][1]) : "v"(v.y));
             } else if constexpr (NW == 2) {
-              const uint4 v = *reinterpret_cast<const uint4 *>(tp);
+              const u32x4 v = *reinterpret_cast<lds_cu32x4 *>(off);
               asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][0]) : "v"(v.x));
               asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][1]) : "v"(v.y));
               asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][2]) : "v"(v.z));
               asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][3]) : "v"(v.w));
             } else {
-              const uint4 v = *reinterpret_cast<const uint4 *>(tp);
-              const uint4 v2 = *reinterpret_cast<const uint4 *>(lds + (off ^ 16u));
+              const u32x4 v = *reinterpret_cast<lds_cu32x4 *>(off);
+              const u32x4 v2 = *reinterpret_cast<lds_cu32x4 *>(off ^ 16u);
               asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][0]) : "v"(v.x));
               asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][1]) : "v"(v.y));
               asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][2]) : "v"(v.z));
