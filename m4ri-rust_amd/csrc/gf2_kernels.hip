@@ -18,7 +18,12 @@
 //    by a byte of A with one conflict-free ds_read_b128 and XORs it into its accumulators.  The table
 //    row is exactly one LDS bank row (64 banks x 4 B), so any mix of entries is conflict free.
 //    The LDS byte address is formed by ONE v_perm_b32: {0, table-select, A byte, lane offset}.
-//  * everything else is an HBM-streaming kernel with 16-byte accesses.
+//  * few-tile products cut the inner dimension into slices (split-K); gf2_splitk_reduce_kernel XORs the partial tiles.
+//  * products with n <= 256 and many rows (batches of matrix x vector products) have their own Four-Russians kernels
+//    with tables over ALL of B in LDS (gf2_tallskinny_kernel, gf2_tallskinny3_kernel); n <= 8 uses an AND/popcount
+//    kernel (gf2_narrow_kernel) that streams A at HBM speed.
+//  * everything else (Strassen split / merge passes, transpose, XOR, compare, fill) is an HBM-streaming kernel with
+//    16-byte accesses.  The elimination kernels live in gf2_elim.hip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
