@@ -935,31 +935,28 @@ __global__ __launch_bounds__(NT) void gf2_tallskinny3_kernel(const u64 *__restri
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < RPT; ++r) {
-      const long long row = min(row_base + (long long)r * NT + tid, (long long)m - 1);  // clamped: stores are guarded below
+    for (int rs = 0; rs < 2; ++rs) {
+      if ((w0 + rs * WRS) * 64 < l) {  // uniform: the row set holds bits of the inner dimension
+        // the words of ALL of this lane's rows first (one memory latency per row set instead of one per row)
+        u64 aw[RPT][WRS];
+        const int wi0 = w0 + rs * WRS;
 #pragma unroll
-      for (int rs = 0; rs < 2; ++rs) {
-        if ((w0 + rs * WRS) * 64 < l) {  // uniform: the row set holds bits of the inner dimension
+        for (int r = 0; r < RPT; ++r) {
+          const long long row = min(row_base + (long long)r * NT + tid, (long long)m - 1);  // clamped: stores are guarded below
+          const u64 *ap = A + row * lda;
+#pragma unroll
+          for (int q = 0; q < WRS; ++q) aw[r][q] = ap[min(wi0 + q, wl - 1)];  // clamped as well, masked below
+        }
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+          __builtin_amdgcn_sched_barrier(0);  // one row at a time: interleaving the rows' lookups spills
           u32 d[ND];
-          const int wi0 = w0 + rs * WRS;
-          if (wi0 + WRS <= wl) {  // uniform: the whole row set lies inside the row -> plain adjacent loads (they merge)
-            const u64 *ap = A + row * lda + wi0;
 #pragma unroll
-            for (int q = 0; q < WRS; ++q) {
-              u64 aw = ap[q];
-              if (wi0 + q == wl - 1) aw &= maskL;
-              d[2 * q] = (u32)aw;
-              d[2 * q + 1] = (u32)(aw >> 32);
-            }
-          } else {
-#pragma unroll
-            for (int q = 0; q < WRS; ++q) {
-              const int wi = wi0 + q;
-              u64 aw = wi < wl ? A[row * lda + wi] : 0;
-              if (wi == wl - 1) aw &= maskL;
-              d[2 * q] = (u32)aw;
-              d[2 * q + 1] = (u32)(aw >> 32);
-            }
+          for (int q = 0; q < WRS; ++q) {
+            u64 x = wi0 + q < wl ? aw[r][q] : 0;
+            if (wi0 + q == wl - 1) x &= maskL;
+            d[2 * q] = (u32)x;
+            d[2 * q + 1] = (u32)(x >> 32);
           }
           // byte c of the permuted dwords = byte c ^ s of the row set's bytes
 #pragma unroll
@@ -1536,9 +1533,10 @@ extern "C" hipError_t gf2k_tallskinny(const u64 *A, long long lda, const u64 *B,
   const int nw = (n + 63) / 64;
   // measured on 2^20 x 256 times 256 x V (us): first kernel 14.4 / 20.2 / 50.6 for V = 64 / 128 / 256, skewed kernel
   // 22.1 / 17.5 / 33.2: the skew pays off once the entries are 16 bytes or wider (the first kernel then loses to LDS bank
-  // conflicts), below that its byte permutation costs more than the conflicts.  M4RI_HIP_TALLSKINNY_GEN=1|3 forces one.
+  // conflicts), below that its byte permutation costs more than the conflicts.  M4RI_HIP_TALLSKINNY_GEN=1 forces the first
+  // kernel for every width (A/B runs).
   static const int forced_gen = getenv("M4RI_HIP_TALLSKINNY_GEN") ? atoi(getenv("M4RI_HIP_TALLSKINNY_GEN")) : 0;
-  if (forced_gen ? forced_gen == 3 : nw >= 2) {
+  if (nw >= 2 && forced_gen != 1) {
     constexpr int RPT3 = 4, NT3 = 1024;
     const unsigned grid3 = (unsigned)(((long long)m + NT3 * RPT3 - 1) / (NT3 * RPT3));
     const size_t lds3 = 128 * 1024 + 4 * 1024;
@@ -1549,9 +1547,7 @@ extern "C" hipError_t gf2k_tallskinny(const u64 *A, long long lda, const u64 *B,
   if (e3 != hipSuccess) return e3;                                                                                       \
   hipLaunchKernelGGL((gf2_tallskinny3_kernel<NWV, RPT3, NT3>), dim3(grid3), dim3(NT3), lds3, stream, A, lda, B, ldb, C, ldc, m, \
                      l, n, accumulate)
-    if (nw == 1) {
-      GF2_TS3_LAUNCH(1);
-    } else if (nw == 2) {
+    if (nw == 2) {
       GF2_TS3_LAUNCH(2);
     } else {
       GF2_TS3_LAUNCH(4);
