@@ -184,6 +184,10 @@ int gf2_strassen_levels(int m, int l, int n, int algo, int param);
  * the library keeps one cached arena per device and grows it on demand. */
 size_t gf2_mul_workspace_bytes(int m, int l, int n, int algo, int param);
 
+/* give cached device memory (per-stream scratch arenas, block cache) of the current device back to the driver;
+ * waits for the device first.  The library otherwise keeps what it allocated: the arena of a 131072^3 product is 141 GiB. */
+int gf2_trim(void);
+
 /* compact binary file format for host matrices ("GF2M", version, nrows, ncols, dense little-endian rows);
  * 0 / non-NULL on success.  (the reference only serialises to JSON, binary_matrix.rs:10-35) */
 int gf2_mzd_save(const char *path, mzd_t const *M);

@@ -225,6 +225,37 @@ int stream_workspace(hipStream_t s, size_t bytes, void **out, int slot = 0) {
   return 0;
 }
 
+}  // namespace
+
+// Give cached device memory back to the driver: waits for the device, then frees the per-stream scratch arenas (a
+// 131072^3 product leaves a 141 GiB Strassen arena behind), the deferred frees and the block cache of the current
+// device.  Safe at any quiet point; the next product allocates again.
+extern "C" int gf2_trim(void) {
+  if (int rc = require_device()) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    for (auto it = g_ws.begin(); it != g_ws.end();) {
+      if (std::get<0>(it->first) == dev) {
+        dev_free(it->second.p, it->second.bytes);
+        it = g_ws.erase(it);
+      } else {
+        ++it;
+      }
+    }
+  }
+  reap_deferred(true);
+  DevPool &pool = g_pools[dev & 15];
+  std::lock_guard<std::mutex> lk(pool.mu);
+  for (auto &kv : pool.free_) (void)hipFree(kv.second);
+  pool.free_.clear();
+  pool.cached = 0;
+  return 0;
+}
+
+namespace {
 // Side stream + events for one main stream: the leaf products of a Strassen product run there, chunk by chunk, while
 // the main stream streams the operands of the next chunk / folds the previous chunk's products (HBM-bound passes under
 // an LDS-bound kernel).  Cached per (device, stream); never destroyed (a handful per process).

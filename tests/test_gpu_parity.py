@@ -410,3 +410,19 @@ def test_extreme_densities(pkg, dev, kind):
     A, B = dev.DMat.from_words(a, n), dev.DMat.from_words(b, n)
     for algo, param in (("m4rm", 0), ("strassen", 1), ("strassen", 2)):
         assert np.array_equal(dev.mul(A, B, algo=algo, param=param).to_words(), ref), (kind, algo, param)
+
+
+def test_trim_releases_and_work_continues(pkg, dev):
+    """gf2_trim gives the scratch arenas and the block cache back to the driver; products afterwards allocate again."""
+    import torch
+    n = 8192
+    A, B = dev.DMat.random(n, n, 1), dev.DMat.random(n, n, 2)
+    ref = dev.mul(A, B, algo="m4rm")
+    c1 = dev.mul(A, B, algo="strassen", param=3)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    pkg._lib.check(pkg._lib.lib().gf2_trim(), "gf2_trim")
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free1 >= free0  # at least the Strassen arena went back
+    c2 = dev.mul(A, B, algo="strassen", param=3)
+    assert dev.equal(c1, ref) and dev.equal(c2, ref)
