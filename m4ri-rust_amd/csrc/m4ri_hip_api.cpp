@@ -666,7 +666,31 @@ static int mul_dispatch(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int a
     case GF2_ALGO_AUTO:
     case GF2_ALGO_STRASSEN: {
       static const int leaf_min = env_int("M4RI_HIP_STRASSEN_LEAF_MIN", 2048);
-      const int L = pick_levels(A->nrows, A->ncols, B->ncols, param, leaf_min);
+      int L = pick_levels(A->nrows, A->ncols, B->ncols, param, leaf_min);
+      // the operand arena of L levels must fit: what the driver reports free plus what this library already holds
+      // (its block cache and this stream's current arena are handed back before a larger one is allocated)
+      if (L > 0) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+          size_t mine = 0;
+          int dev = 0;
+          (void)hipGetDevice(&dev);
+          {
+            std::lock_guard<std::mutex> lk(g_ws_mu);
+            auto it = g_ws.find(std::make_tuple(dev, s, 0));
+            if (it != g_ws.end()) mine += it->second.bytes;
+          }
+          {
+            DevPool &pool = g_pools[dev & 15];
+            std::lock_guard<std::mutex> lk(pool.mu);
+            mine += pool.cached;
+          }
+          const size_t avail = (size_t)((free_b + mine) * 0.95);
+          while (L > 0 && strassen_ws_words(A->nrows, A->ncols, B->ncols, L) * sizeof(u64) > avail) --L;
+        } else {
+          (void)hipGetLastError();
+        }
+      }
       return mul_strassen(C, A, B, accumulate, L, s, sync_free);
     }
     default:
