@@ -181,6 +181,12 @@ class BinMatrix {
     return BinMatrix(mzd_mul_naive(nullptr, mzd_, vt.mzd_));
   }
 
+  // operand cache (m4ri_hip.h): products whose operand is this matrix skip its upload until uncache() / destruction
+  void cache_on_device() const {
+    if (gf2_mzd_cache_on_device(mzd_) != 0) throw Panic(std::string("gf2_mzd_cache_on_device: ") + gf2_last_error());
+  }
+  void uncache() const { gf2_mzd_uncache(mzd_); }
+
   // serde wire format (feature "serde", binary_matrix.rs:10-35): exactly what serde_json::to_string prints
   // (test_serialize, binary_matrix.rs:693-699): {"matrix":{"rows":[{"len":N,"vec":[u64 words]},...]}}
   std::string to_json() const {

@@ -185,6 +185,14 @@ int gf2_strassen_levels(int m, int l, int n, int algo, int param);
  * the library keeps one cached arena per device and grows it on demand. */
 size_t gf2_mul_workspace_bytes(int m, int l, int n, int algo, int param);
 
+/* Operand cache for the drop-in entry points: keep a device copy of the host matrix M until gf2_mzd_uncache(M) or
+ * mzd_free(M); mzd_mul* calls whose A or B is M then skip its upload (repeated A*v with a fixed A -- mul_slice,
+ * binary_matrix.rs:416-431 -- is otherwise bound by moving A over PCIe on every call).  The caller promises not to
+ * change M's bits through the host pointers meanwhile; library calls that write M (as destination, mzd_echelonize,
+ * mzd_solve_left, ...) drop the copy themselves. */
+int gf2_mzd_cache_on_device(mzd_t const *M);
+void gf2_mzd_uncache(mzd_t const *M);
+
 /* give cached device memory (per-stream scratch arenas, block cache) of the current device back to the driver;
  * waits for the device first.  The library otherwise keeps what it allocated: the arena of a 131072^3 product is 141 GiB. */
 int gf2_trim(void);

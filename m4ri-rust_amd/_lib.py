@@ -100,6 +100,8 @@ _PROTOS = {
     "gf2_echelonize_dev": (_I, [DMatP, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.c_void_p]),
     "gf2_inverse_dev": (_I, [DMatP, DMatP, ctypes.POINTER(_I), ctypes.c_void_p]),
     "gf2_mul_workspace_bytes": (ctypes.c_size_t, [_I, _I, _I, _I, _I]),
+    "gf2_mzd_cache_on_device": (_I, [MzdP]),
+    "gf2_mzd_uncache": (None, [MzdP]),
     "gf2_trim": (_I, []),
     "gf2_mzd_save": (_I, [ctypes.c_char_p, MzdP]),
     "gf2_mzd_load": (MzdP, [ctypes.c_char_p]),

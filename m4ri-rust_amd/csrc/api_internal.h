@@ -7,3 +7,5 @@ mzd_t *gf2_mzd_init_uncleared(rci_t r, rci_t c);  // mzd_init without the memset
 // for large matrices; the caller falls back to the host routine if it fails (this is not the multiply path).
 int gf2_host_transpose_gpu(mzd_t *dst, mzd_t const *src);
 int gf2_device_count(void);
+// drop the device copy kept for M by gf2_mzd_cache_on_device, if any (mzd_free and every in-place writer call this)
+void gf2_cache_forget(mzd_t const *M);

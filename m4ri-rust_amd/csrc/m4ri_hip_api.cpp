@@ -883,12 +883,41 @@ extern "C" int gf2_dmat_download(mzd_t *dst, gf2_dmat const *src, void *stream) 
 namespace {
 struct DMatOwner {
   gf2_dmat d{};
-  ~DMatOwner() { gf2_dmat_free(&d); }
+  bool borrowed = false;  // d belongs to the operand cache
+  ~DMatOwner() {
+    if (!borrowed) gf2_dmat_free(&d);
+  }
 };
+
+// Operand cache: device copies of host matrices that the caller declared constant (gf2_mzd_cache_on_device).  A product
+// whose A or B is cached skips that upload -- the drop-in path of repeated A*v with a fixed A (mul_slice,
+// binary_matrix.rs:416-431) is otherwise bound by moving A over PCIe every call.
+struct CachedOperand {
+  gf2_dmat d{};
+  int dev = 0;
+  int nrows = 0, ncols = 0;
+};
+std::mutex g_cache_mu;
+std::map<const mzd_t *, CachedOperand> g_cache;
+
+bool cache_lookup(const mzd_t *M, gf2_dmat *out) {
+  std::lock_guard<std::mutex> lk(g_cache_mu);
+  auto it = g_cache.find(M);
+  if (it == g_cache.end()) return false;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev != it->second.dev) return false;
+  if (it->second.nrows != M->nrows || it->second.ncols != M->ncols) return false;
+  *out = it->second.d;
+  return true;
+}
 
 // device copy whose row stride equals the host row stride when the host block is contiguous, so that
 // the transfer is one linear DMA
 int to_device(DMatOwner &o, const mzd_t *M, hipStream_t s, bool copy) {
+  if (copy && cache_lookup(M, &o.d)) {  // a read-only operand that already lives on the device
+    o.borrowed = true;
+    return 0;
+  }
   o.d.nrows = M->nrows;
   o.d.ncols = M->ncols;
   const bool windowed = (M->flags & mzd_flag_windowed_zerooffset) != 0;
@@ -912,6 +941,7 @@ mzd_t *host_mul(mzd_t *C, const mzd_t *A, const mzd_t *B, int accumulate, int al
   };
   if (require_device()) return bail("no device");
   if (!C) C = (A->nrows == 0 || B->ncols == 0) ? mzd_init(A->nrows, B->ncols) : gf2_mzd_init_uncleared(A->nrows, B->ncols);
+  else gf2_cache_forget(C);  // about to be overwritten
   if (A->nrows == 0 || B->ncols == 0) return C;
   hipStream_t s;
   if (get_private_stream(&s)) {
@@ -935,6 +965,41 @@ mzd_t *host_mul(mzd_t *C, const mzd_t *A, const mzd_t *B, int accumulate, int al
   return C;
 }
 }  // namespace
+
+void gf2_cache_forget(mzd_t const *M) {
+  CachedOperand c;
+  {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    auto it = g_cache.find(M);
+    if (it == g_cache.end()) return;
+    c = it->second;
+    g_cache.erase(it);
+  }
+  (void)hipDeviceSynchronize();  // products of other threads may still be reading the copy
+  gf2_dmat_free(&c.d);
+}
+
+extern "C" int gf2_mzd_cache_on_device(mzd_t const *M) {
+  if (int rc = require_device()) return rc;
+  if (!M || M->nrows == 0 || M->ncols == 0) return fail_msg("gf2_mzd_cache_on_device: empty matrix");
+  gf2_cache_forget(M);
+  hipStream_t s;
+  if (int rc = get_private_stream(&s)) return rc;
+  DMatOwner o;
+  if (int rc = to_device(o, M, s, true)) return rc;
+  HIP_TRY(hipStreamSynchronize(s));
+  CachedOperand c;
+  c.d = o.d;
+  c.nrows = M->nrows;
+  c.ncols = M->ncols;
+  HIP_TRY(hipGetDevice(&c.dev));
+  o.borrowed = true;  // ownership moves to the cache
+  std::lock_guard<std::mutex> lk(g_cache_mu);
+  g_cache[M] = c;
+  return 0;
+}
+
+extern "C" void gf2_mzd_uncache(mzd_t const *M) { gf2_cache_forget(M); }
 
 int gf2_host_transpose_gpu(mzd_t *dst, mzd_t const *src) {
   if (require_device()) return -1;
@@ -998,6 +1063,7 @@ extern "C" mzd_t *_mzd_mul_naive(mzd_t *C, mzd_t const *A, mzd_t const *Bt, int 
     return nullptr;
   }
   if (A->nrows == 0 || Bt->nrows == 0) return C;
+  gf2_cache_forget(C);  // about to be overwritten
   hipStream_t s;
   if (get_private_stream(&s)) return nullptr;
   int rc;
@@ -1162,6 +1228,7 @@ extern "C" int gf2_inverse_dev(gf2_dmat *Ainv, gf2_dmat const *A, int *singular,
 
 static int host_echelonize(mzd_t *A, int full, const char *name) {
   if (A->nrows == 0 || A->ncols == 0) return 0;
+  gf2_cache_forget(A);  // modified in place
   auto bail = [&](const char *why) {
     std::fprintf(stderr, "m4ri_hip: %s failed: %s (%s)\n", name, why, gf2_last_error());
     std::abort();  // the M4RI signature has no error channel (returns the rank)
@@ -1205,6 +1272,7 @@ extern "C" mzd_t *mzd_inv_m4ri(mzd_t *dst, mzd_t const *src, int k) {
   int rc, singular = 0;
   const bool allocated = dst == nullptr;
   if (!dst) dst = gf2_mzd_init_uncleared(n, n);
+  else gf2_cache_forget(dst);
   {
     DMatOwner dI;
     rc = to_device(dI, dst, s, false);
@@ -1226,6 +1294,8 @@ extern "C" int mzd_solve_left(mzd_t *A, mzd_t *B, int cutoff, int inconsistency_
   if (A->nrows > B->nrows) gf2_die("mzd_solve_left: A nrows must be smaller than B nrows.");
   const int m = A->nrows, n = A->ncols, kb = B->ncols;
   if (m == 0 || n == 0 || kb == 0) return 0;
+  gf2_cache_forget(A);  // both are overwritten
+  gf2_cache_forget(B);
   auto bail = [&](const char *why) {
     std::fprintf(stderr, "m4ri_hip: mzd_solve_left failed: %s (%s)\n", why, gf2_last_error());
     std::abort();  // -1 means "inconsistent" in this signature; a device failure is not that

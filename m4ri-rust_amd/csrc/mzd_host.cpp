@@ -146,6 +146,7 @@ static bool owns_blocks(const mzd_t *A) {
 
 extern "C" void mzd_free(mzd_t *A) {
   if (!A) return;
+  gf2_cache_forget(A);  // a later matrix may get the same address
   std::free(A->rows);
   if (owns_blocks(A)) {
     block_free(A->blocks[0].begin, A->padding[0], A->blocks[0].size);
@@ -189,6 +190,7 @@ static inline void copy_row_masked(word *d, const word *s, wi_t width, word mask
 }
 
 extern "C" mzd_t *mzd_copy(mzd_t *N, mzd_t const *P) {
+  if (N) gf2_cache_forget(N);  // written below: a device copy kept for it is stale
   if (N == P) return N;
   if (!N)
     N = mzd_init(P->nrows, P->ncols);
@@ -222,6 +224,7 @@ extern "C" int mzd_is_zero(mzd_t const *A) {
 }
 
 extern "C" void mzd_randomize(mzd_t *A) {
+  if (A) gf2_cache_forget(A);  // written below: a device copy kept for it is stale
   // M4RI draws from libc random(); here a process-wide counter-based splitmix64 stream (thread safe,
   // successive calls give fresh bits as the reference's tests expect: mzd.rs:389-394).
   static std::atomic<uint64_t> ctr{0x243F6A8885A308D3ull};
@@ -243,6 +246,7 @@ extern "C" void mzd_randomize(mzd_t *A) {
 }
 
 extern "C" void mzd_set_ui(mzd_t *A, unsigned int value) {
+  if (A) gf2_cache_forget(A);  // written below: a device copy kept for it is stale
   for (rci_t i = 0; i < A->nrows; ++i) {
     word *a = A->rows[i];
     for (wi_t j = 0; j + 1 < A->width; ++j) a[j] = 0;
@@ -266,6 +270,7 @@ static inline void transpose64(word x[64]) {
 }
 
 extern "C" mzd_t *mzd_transpose(mzd_t *DST, mzd_t const *A) {
+  if (DST) gf2_cache_forget(DST);  // written below: a device copy kept for it is stale
   if (DST && (DST->nrows != A->ncols || DST->ncols != A->nrows)) gf2_die("mzd_transpose: Wrong size for return matrix.");
   // large matrices: PCIe both ways plus the device kernel is ~100x faster than the host loop below
   static const long long gpu_min_bits = [] {
@@ -305,6 +310,7 @@ extern "C" mzd_t *mzd_transpose(mzd_t *DST, mzd_t const *A) {
 }
 
 extern "C" mzd_t *mzd_add(mzd_t *C, mzd_t const *A, mzd_t const *B) {
+  if (C) gf2_cache_forget(C);  // written below: a device copy kept for it is stale
   if (A->nrows != B->nrows || A->ncols != B->ncols) gf2_die("mzd_add: rows and columns must match.");
   if (!C)
     C = mzd_init(A->nrows, A->ncols);
@@ -331,6 +337,7 @@ static inline void write_bit(mzd_t *M, rci_t r, rci_t c, BIT v) {
 }
 
 extern "C" mzd_t *mzd_concat(mzd_t *C, mzd_t const *A, mzd_t const *B) {
+  if (C) gf2_cache_forget(C);  // written below: a device copy kept for it is stale
   if (A->nrows != B->nrows) gf2_die("mzd_concat: Bad arguments to concat!");
   if (!C)
     C = mzd_init(A->nrows, A->ncols + B->ncols);
@@ -344,6 +351,7 @@ extern "C" mzd_t *mzd_concat(mzd_t *C, mzd_t const *A, mzd_t const *B) {
 }
 
 extern "C" mzd_t *mzd_stack(mzd_t *C, mzd_t const *A, mzd_t const *B) {
+  if (C) gf2_cache_forget(C);  // written below: a device copy kept for it is stale
   if (A->ncols != B->ncols) gf2_die("mzd_stack: A->ncols != B->ncols!");
   if (!C)
     C = mzd_init(A->nrows + B->nrows, A->ncols);
@@ -355,6 +363,7 @@ extern "C" mzd_t *mzd_stack(mzd_t *C, mzd_t const *A, mzd_t const *B) {
 }
 
 extern "C" mzd_t *mzd_submatrix(mzd_t *S, mzd_t const *M, rci_t lowr, rci_t lowc, rci_t highr, rci_t highc) {
+  if (S) gf2_cache_forget(S);  // written below: a device copy kept for it is stale
   const rci_t nrows = highr - lowr, ncols = highc - lowc;
   if (!S)
     S = mzd_init(nrows, ncols);
@@ -366,6 +375,7 @@ extern "C" mzd_t *mzd_submatrix(mzd_t *S, mzd_t const *M, rci_t lowr, rci_t lowc
 }
 
 extern "C" void mzd_row_swap(mzd_t *M, rci_t a, rci_t b) {
+  if (M) gf2_cache_forget(M);  // written below: a device copy kept for it is stale
   if (a == b) return;
   word *x = M->rows[a], *y = M->rows[b];
   for (wi_t j = 0; j < M->width; ++j) {
@@ -377,6 +387,7 @@ extern "C" void mzd_row_swap(mzd_t *M, rci_t a, rci_t b) {
 }
 
 extern "C" void mzd_copy_row(mzd_t *B, rci_t i, mzd_t const *A, rci_t j) {
+  if (B) gf2_cache_forget(B);  // written below: a device copy kept for it is stale
   if (A->ncols > B->ncols) gf2_die("mzd_copy_row: source wider than target");
   copy_row_masked(B->rows[i], A->rows[j], A->width, A->high_bitmask);
 }

@@ -388,6 +388,15 @@ class BinMatrix:
     def __repr__(self):
         return "BinMatrix(%dx%d)" % (self.nrows(), self.ncols())
 
+    # -- operand cache of the drop-in entry points (include/m4ri_hip.h): products whose operand is this matrix skip its
+    #    upload until uncache() / drop; the caller promises not to change the bits through host pointers meanwhile --
+    def cache_on_device(self):
+        _lib.check(_lib.lib().gf2_mzd_cache_on_device(self.mzd), "gf2_mzd_cache_on_device")
+        return self
+
+    def uncache(self):
+        _lib.lib().gf2_mzd_uncache(self.mzd)
+
     # -- serde wire format (feature "serde", binary_matrix.rs:10-35): {"matrix":{"rows":[<Vob>, ...]}}, a Vob being
     #    {"len": bits, "vec": [u64 words, LSB-first]}; byte-for-byte what serde_json::to_string prints (test_serialize,
     #    binary_matrix.rs:693-699).  Upstream only serialises matrices; from_json is the obvious inverse. --

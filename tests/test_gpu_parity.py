@@ -426,3 +426,49 @@ def test_trim_releases_and_work_continues(pkg, dev):
     assert free1 >= free0  # at least the Strassen arena went back
     c2 = dev.mul(A, B, algo="strassen", param=3)
     assert dev.equal(c1, ref) and dev.equal(c2, ref)
+
+
+def test_operand_cache(pkg):
+    """gf2_mzd_cache_on_device: a fixed A stays on the device across A*v calls (the LPN use of mul_slice); every library
+    call that writes the matrix, and mzd_free, drop the copy."""
+    import time
+    L = pkg._lib.lib()
+    m, l = 1 << 18, 256
+    a = g.random_words(m, l, 3)
+    A = pkg.BinMatrix.from_words(a, l)
+    vs = [pkg.BinVector(g.random_words(1, l, 40 + i)[0], l) for i in range(6)]
+    plain = [A * v for v in vs]
+    A.cache_on_device()
+    cached = [A * v for v in vs]
+    assert all(c == p for c, p in zip(cached, plain))
+    t0 = time.perf_counter()
+    for v in vs:
+        A * v
+    t_cached = (time.perf_counter() - t0) / len(vs)
+    A.uncache()
+    t0 = time.perf_counter()
+    for v in vs:
+        A * v
+    t_plain = (time.perf_counter() - t0) / len(vs)
+    print("A*v with A (8 MiB) cached: %.0f us, uploaded every call: %.0f us" % (t_cached * 1e6, t_plain * 1e6))
+    # writers invalidate: randomize through the library, then the product must see the new bits
+    B = pkg.BinMatrix.from_words(g.random_words(300, 200, 5), 200)
+    X = pkg.BinMatrix.from_words(g.random_words(200, 100, 6), 100)
+    B.cache_on_device()
+    first = (B * X).to_words()
+    L.mzd_set_ui(B.mzd, 0)  # zero matrix now
+    assert not (B * X).to_words().any() and first.any()
+    # as a destination
+    B.cache_on_device()
+    P = pkg.BinMatrix.from_words(g.random_words(300, 50, 7), 50)
+    Q = pkg.BinMatrix.from_words(g.random_words(50, 200, 8), 200)
+    assert L.mzd_mul(B.mzd, P.mzd, Q.mzd, 0)
+    ref = g.o_mul_m4rm(P.to_words(), Q.to_words(), 300, 50, 200)
+    assert np.array_equal(B.to_words(), ref)
+    assert np.array_equal((B * X).to_words(), g.o_mul_m4rm(ref, X.to_words(), 300, 200, 100))
+    # freed and re-created matrices never see a stale copy
+    for seed in range(3):
+        T = pkg.BinMatrix.from_words(g.random_words(128, 128, 50 + seed), 128)
+        T.cache_on_device()
+        assert np.array_equal((T * T).to_words(), g.o_mul_m4rm(T.to_words(), T.to_words(), 128, 128, 128))
+        del T
