@@ -900,6 +900,28 @@ __global__ __launch_bounds__(NT) void gf2_tallskinny3_kernel(const u64 *__restri
   for (int r = 0; r < RPT; ++r)
 #pragma unroll
     for (int w = 0; w < 2 * NW; ++w) acc[r][w] = 0;
+  const u64 maskC = (n & 63) ? ((1ull << (n & 63)) - 1) : ~0ull;
+  // a row is stored as soon as its last lookup is done, so that the writes of C overlap the lookups of the other rows
+  auto store_row = [&](int r) {
+    const long long row = row_base + (long long)r * NT + tid;
+    if (row < m) {
+#pragma unroll
+      for (int w = 0; w < NW; ++w)
+        if (w < wn) {
+          // NW=4: lanes that read the upper half first hold words 2,3 in acc[0..3] and words 0,1 in acc[4..7]
+          u32 lo = acc[r][2 * w], hi = acc[r][2 * w + 1];
+          if constexpr (NW == 4) {
+            lo = hsw ? acc[r][(2 * w) ^ 4] : lo;
+            hi = hsw ? acc[r][(2 * w + 1) ^ 4] : hi;
+          }
+          u64 v = (u64)lo | ((u64)hi << 32);
+          if (w == wn - 1) v &= maskC;
+          u64 *dd = C + row * ldc + w;
+          if (accumulate) v ^= *dd;
+          *dd = v;
+        }
+    }
+  };
 
   for (int w0 = 0; w0 < wl; w0 += kWordsPerGroup) {  // group of 64-bit words of the inner dimension
     __syncthreads();  // previous group's lookups are done
@@ -999,35 +1021,14 @@ __global__ __launch_bounds__(NT) void gf2_tallskinny3_kernel(const u64 *__restri
               asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][7]) : "v"(v2.w));
             }
           }
+          // last row set of the last group that holds bits of the inner dimension (uniform)
+          if ((w0 + (rs + 1) * WRS) * 64 >= l) store_row(r);
         }
       }
     }
   }
-  const u64 maskC = (n & 63) ? ((1ull << (n & 63)) - 1) : ~0ull;
-#pragma unroll
-  for (int r = 0; r < RPT; ++r) {
-    const long long row = row_base + (long long)r * NT + tid;
-    if (row < m) {
-#pragma unroll
-      for (int w = 0; w < NW; ++w)
-        if (w < wn) {
-          // NW=4: lanes that read the upper half first hold words 2,3 in acc[0..3] and words 0,1 in acc[4..7]
-          u32 lo = acc[r][2 * w], hi = acc[r][2 * w + 1];
-          if constexpr (NW == 4) {
-            lo = hsw ? acc[r][(2 * w) ^ 4] : lo;
-            hi = hsw ? acc[r][(2 * w + 1) ^ 4] : hi;
-          }
-          u64 v = (u64)lo | ((u64)hi << 32);
-          if (w == wn - 1) v &= maskC;
-          u64 *dd = C + row * ldc + w;
-          if (accumulate) v ^= *dd;
-          *dd = v;
-        }
-    }
-  }
 }
 
-// ---------------------------------------------------------------------------------------------
 // v*A kernel: C (m x n) (+)= A (m x l) * B (l x n) for a handful of rows m <= 8 (_mzd_mul_va,
 // mzd.rs:175-181 and `&v * &A`, binary_matrix.rs:552-563).  Streams B once; the inner dimension
 // is split over blockIdx.y and partial sums are combined with 64-bit atomic XOR.
