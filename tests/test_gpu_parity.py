@@ -472,3 +472,13 @@ def test_operand_cache(pkg):
         T.cache_on_device()
         assert np.array_equal((T * T).to_words(), g.o_mul_m4rm(T.to_words(), T.to_words(), 128, 128, 128))
         del T
+
+
+def test_random_shape_fuzz(pkg):
+    """tools/fuzz_shapes.py: log-uniform random shapes (incl. tall-skinny ones) through three algorithms and the
+    elimination, all against the oracle."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_shapes.py"), "80", "3"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
