@@ -18,7 +18,8 @@ def dim(hi):
 
 bad = 0
 for it in range(count):
-    m, l, n = dim(6000), dim(6000), dim(6000)
+    hi = int(os.environ.get("FUZZ_MAX_DIM", "6000"))
+    m, l, n = dim(hi), dim(hi), dim(hi)
     if rng.random() < 0.2:
         m = int(rng.choice([2048, 4096, 5000, 70000]))
         n = dim(256)
