@@ -89,10 +89,12 @@ def _worker_panels(rank, world, port, m, l, n, P, out_path):
     dist.destroy_process_group()
 
 
-def test_pipelined_column_panels_world2_gloo(tmp_path, built):
-    """B moved in column panels with asynchronous broadcast / gather (the N > 1 step of bench.py)."""
+@pytest.mark.parametrize("P,n", [(2, 256), (4, 512)], ids=["2panels", "4panels"])
+def test_pipelined_column_panels_world2_gloo(tmp_path, built, P, n):
+    """B moved in column panels with asynchronous broadcast / gather (the N > 1 step of bench.py: 2 panels on 2 GPUs,
+    4 above)."""
     import torch.multiprocessing as mp
-    m, l, n, P = 128, 192, 256, 2
+    m, l = 128, 192
     out = str(tmp_path / "c.npy")
     mp.spawn(_worker_panels, args=(2, _free_port(), m, l, n, P, out), nprocs=2, join=True)
     ref = g.o_mul_m4rm(g.random_words(m, l, 1), g.random_words(l, n, 2), m, l, n)
