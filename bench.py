@@ -56,6 +56,8 @@ def main():
                     help="column panels of B per step when N > 1 (RCCL/compute overlap); 0 = 2 panels on 2 GPUs, 4 above "
                          "(measured per-rank products: thin panels cost Strassen efficiency, 32768x65536x32768 takes 13.0 ms "
                          "but 4 x 32768x65536x16384 take 31 ms; from 4 GPUs on the transfer is the longer leg)")
+    ap.add_argument("--bcast", default="broadcast", choices=["broadcast", "allgather"],
+                    help="how a panel of B reaches the ranks: one broadcast, or scatter from rank 0 + all-gather")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--check", action="store_true", help="spot-check rows of C against the oracle after timing")
     ap.add_argument("--density", default="half", choices=["half", "sparse", "ones"],
@@ -142,7 +144,8 @@ def main():
 
     def step():
         if world > 1:
-            sharded.step_pipelined(A, Bp_t, Cp_t, Cfull_t, Bp, Cp, algo=args.algo, levels=args.levels, stream=stream)
+            sharded.step_pipelined(A, Bp_t, Cp_t, Cfull_t, Bp, Cp, algo=args.algo, levels=args.levels, stream=stream,
+                                   bcast=args.bcast)
         else:
             device.mul(A, B, C=C, algo=args.algo, param=args.levels, stream=stream)
 
@@ -229,7 +232,8 @@ def main():
                 n, n, n, "Strassen(%d levels)-over-M4RM" % levels if levels else "M4RM only"),
             "n": n, "algo": args.algo, "strassen_levels": levels,
             "parallelism": "row-block shard of A over %d GPU(s)%s" % (
-                world, ", B in %d column panels: RCCL broadcast(panel p+1) / gather(C panel p-1) overlap the product of panel p" % P
+                world, ", B in %d column panels: RCCL %s(panel p+1) / gather(C panel p-1) overlap the product of panel p" % (
+                    P, "broadcast" if args.bcast == "broadcast" else "scatter+all_gather")
                 if world > 1 else ""),
         },
         "roofline": {

@@ -67,8 +67,43 @@ def fill_block(M, seed, row0, col_word0, full_ncols, stream=None):
                "gf2_dmat_fill_random_block")
 
 
+class _Chain:
+    """Several asynchronous collectives that complete in order: wait() on the last one is enough on GPUs (one
+    communication stream), gloo wants every handle waited."""
+
+    def __init__(self, works):
+        self.works = works
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+
+
+def distribute_panel(b_panel, mode="broadcast", group=None):
+    """Start moving one column panel of B from rank 0 to every rank; returns a handle with .wait().
+
+    "broadcast": one dist.broadcast (a pipeline along RCCL's rings).
+    "allgather": rank 0 scatters row shards of the panel (its links to all peers in parallel), then every rank
+    all-gathers the shards (uses all seven xGMI links of every GPU instead of one chain).
+    Both leave the same bytes in b_panel on every rank."""
+    import torch.distributed as dist
+    if mode == "broadcast":
+        return dist.broadcast(b_panel, src=0, group=group, async_op=True)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    shards = list(b_panel.chunk(world, dim=0))
+    assert len(shards) == world and all(s.shape == shards[0].shape for s in shards), "panel rows must divide by the world size"
+    mine = shards[rank]
+    w1 = dist.scatter(mine, scatter_list=shards if rank == 0 else None, src=0, group=group, async_op=True)
+    src = mine
+    if dist.get_backend(group) != "nccl":  # gloo runs asynchronous operations in no particular order, and dislikes aliased buffers
+        w1.wait()
+        src = mine.clone()
+    w2 = dist.all_gather(shards, src, group=group, async_op=True)
+    return _Chain([w1, w2])
+
+
 def mul_row_sharded_pipelined(a_block, b_panels, c_panels, c_full_panels, ncols_inner, ncols_panel, local_mul=None,
-                              group=None, **kw):
+                              group=None, bcast="broadcast", **kw):
     """Row-sharded product with B moved in column panels ("tiles"): panel p+1 is on the wire while panel p is being
     multiplied, and the gather of C panel p overlaps the product of panel p+1.
 
@@ -88,7 +123,7 @@ def mul_row_sharded_pipelined(a_block, b_panels, c_panels, c_full_panels, ncols_
             if c_full_panels is not None:
                 c_full_panels[p].copy_(c_panels[p])
         return
-    bcasts = [dist.broadcast(b_panels[p], src=0, group=group, async_op=True) for p in range(P)]
+    bcasts = [distribute_panel(b_panels[p], bcast, group) for p in range(P)]
     gathers = []
     for p in range(P):
         bcasts[p].wait()  # orders the consumer (current stream on GPUs) behind the arrival of panel p
@@ -99,11 +134,11 @@ def mul_row_sharded_pipelined(a_block, b_panels, c_panels, c_full_panels, ncols_
         w.wait()
 
 
-def step_pipelined(A, Bp_t, Cp_t, Cfull_t, Bp, Cp, algo="auto", levels=0, stream=None):
+def step_pipelined(A, Bp_t, Cp_t, Cfull_t, Bp, Cp, algo="auto", levels=0, stream=None, bcast="broadcast"):
     """bench.py's timed step for N > 1 ranks, B in column panels (DMat wrappers pre-built)."""
     import torch.distributed as dist
     world, rank, P = dist.get_world_size(), dist.get_rank(), len(Bp_t)
-    bcasts = [dist.broadcast(Bp_t[p], src=0, async_op=True) for p in range(P)]
+    bcasts = [distribute_panel(Bp_t[p], bcast) for p in range(P)]
     gathers = []
     for p in range(P):
         bcasts[p].wait()

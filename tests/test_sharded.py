@@ -55,7 +55,7 @@ def _worker(rank, world, port, m, l, n, out_path):
     dist.destroy_process_group()
 
 
-def _worker_panels(rank, world, port, m, l, n, P, out_path):
+def _worker_panels(rank, world, port, m, l, n, P, out_path, bcast="broadcast"):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -82,21 +82,22 @@ def _worker_panels(rank, world, port, m, l, n, P, out_path):
         c_t.copy_(torch.from_numpy(gg.o_mul_m4rm(a, bb, a.shape[0], ncols_inner, ncols_out).view(np.int64)))
 
     for _ in range(2):  # two steps back to back: panels are re-broadcast into the same buffers
-        sharded.mul_row_sharded_pipelined(a_block, b_panels, c_panels, c_full, l, ncp, local_mul=oracle_local_mul)
+        sharded.mul_row_sharded_pipelined(a_block, b_panels, c_panels, c_full, l, ncp, local_mul=oracle_local_mul, bcast=bcast)
     if rank == 0:
         np.save(out_path, np.concatenate([t.numpy().view(np.uint64) for t in c_full], axis=1))
     dist.barrier()
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("bcast", ["broadcast", "allgather"])
 @pytest.mark.parametrize("P,n", [(2, 256), (4, 512)], ids=["2panels", "4panels"])
-def test_pipelined_column_panels_world2_gloo(tmp_path, built, P, n):
+def test_pipelined_column_panels_world2_gloo(tmp_path, built, P, n, bcast):
     """B moved in column panels with asynchronous broadcast / gather (the N > 1 step of bench.py: 2 panels on 2 GPUs,
     4 above)."""
     import torch.multiprocessing as mp
     m, l = 128, 192
     out = str(tmp_path / "c.npy")
-    mp.spawn(_worker_panels, args=(2, _free_port(), m, l, n, P, out), nprocs=2, join=True)
+    mp.spawn(_worker_panels, args=(2, _free_port(), m, l, n, P, out, bcast), nprocs=2, join=True)
     ref = g.o_mul_m4rm(g.random_words(m, l, 1), g.random_words(l, n, 2), m, l, n)
     assert np.array_equal(np.load(out), ref)
 
