@@ -212,12 +212,34 @@ __global__ __launch_bounds__(1024) void gf2_elim_pivot_kernel(const u64 *__restr
     stage[idx] = v;
   }
   __syncthreads();
-  // reduced pivot row = XOR of the staged rows selected by b_trk[k], stored at its column-ordered position
-  for (int idx = tid; idx < np * 64; idx += 1024) {
-    const int k = idx >> 6, wd = idx & 63;
-    u64 acc = 0;
-    for (u64 t = b_trk[k]; t; t &= t - 1) acc ^= stage[__builtin_ctzll(t) * 64 + wd];
-    ptab[f_pos[k] * 64 + wd] = acc;
+  // reduced pivot row k = XOR of the staged rows selected by b_trk[k], stored at its column-ordered position.  Four
+  // Russians over the 64 selector bits in 4-bit groups, 32 words at a time: 16 groups x 16 entries x 32 words = 64 KiB
+  // of (dynamic) LDS, 16 lookups per output word instead of ~32 dependent reads
+  extern __shared__ __attribute__((aligned(16))) u64 t4[];  // [group 16][entry 16][word 32]
+  for (int h = 0; h < 2; ++h) {
+    for (int it = tid; it < 16 * 5 * 32; it += 1024) {  // entry 0 and the single-row entries
+      const int w = it & 31, e5 = (it >> 5) % 5, g = (it >> 5) / 5;
+      const int e = e5 ? 1 << (e5 - 1) : 0;
+      const int k2 = g * 4 + (e5 - 1);
+      t4[(g * 16 + e) * 32 + w] = (e5 && k2 < np) ? stage[k2 * 64 + h * 32 + w] : 0;
+    }
+    __syncthreads();
+    for (int bits = 2; bits <= 4; ++bits) {
+      for (int it = tid; it < 16 * 16 * 32; it += 1024) {
+        const int w = it & 31, e = (it >> 5) & 15, g = it >> 9;
+        if (__popc(e) == bits) t4[(g * 16 + e) * 32 + w] = t4[(g * 16 + (e & (e - 1))) * 32 + w] ^ t4[(g * 16 + (e & -e)) * 32 + w];
+      }
+      __syncthreads();
+    }
+    for (int it = tid; it < np * 32; it += 1024) {
+      const int k = it >> 5, w = it & 31;
+      const u64 t = b_trk[k];
+      u64 acc = 0;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc ^= t4[(g * 16 + (int)((t >> (4 * g)) & 15)) * 32 + w];
+      ptab[f_pos[k] * 64 + h * 32 + w] = acc;
+    }
+    __syncthreads();  // the table is rebuilt for the other half of the words
   }
 }
 
@@ -463,7 +485,12 @@ extern "C" hipError_t gf2k_elim_step(u64 *A, long long lda, int m, long long c0w
                                      u64 *U, long long ldu, int uw, gf2k_elim_state *st, int *pivcols, u64 *ptab,
                                      unsigned char *rowflag, int *blkpiv, hipStream_t s) {
   if (sw + uw > 64 || j >= sw || sw * 64 > GF2K_ELIM_BLOCK_PIVOTS) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(gf2_elim_pivot_kernel, dim3(1), dim3(1024), 0, s, A, lda, m, c0w, sw, j, colmask, U, ldu, uw, st,
+  {  // 64 KiB of dynamic LDS for the tables that combine the reduced pivot rows, on top of ~37 KiB static
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gf2_elim_pivot_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(gf2_elim_pivot_kernel, dim3(1), dim3(1024), 65536, s, A, lda, m, c0w, sw, j, colmask, U, ldu, uw, st,
                      pivcols, ptab, rowflag, blkpiv);
   // 8 rows per wave and pass, 16 waves per workgroup, one workgroup per CU (128 KiB of LDS tables each)
   int grid = (m + 127) / 128;
