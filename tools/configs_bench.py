@@ -27,8 +27,11 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / reps
         alg_bytes = (m * l + l * n + m * n) / 8
+        # bytes the operands occupy in the M4RI layout (rows padded to whole 64-bit words): what a kernel must move at least
+        layout_bytes = 8.0 * (m * ((l + 63) // 64) + l * ((n + 63) // 64) + m * ((n + 63) // 64))
         print(json.dumps({"config": name, "m": m, "l": l, "n": n, "algo": algo, "ms": dt * 1e3,
                           "bit_ops_per_s": 2.0 * m * l * n / dt, "algorithmic_GBps": alg_bytes / dt / 1e9,
+                          "layout_GBps": layout_bytes / dt / 1e9, "layout_frac_of_8TBps": layout_bytes / dt / 8e12,
                           "strassen_levels": dev._lib.lib().gf2_strassen_levels(m, l, n, dev.ALGOS[algo], 0)}), flush=True)
 
     run("2: 4096^3, M4RM kernel only", 4096, 4096, 4096, "m4rm", 200)
