@@ -31,13 +31,41 @@ for it in range(count):
         if not np.array_equal(got, ref):
             bad += 1
             print("MISMATCH product", m, l, n, algo, flush=True)
-    if it % 4 == 0 and m * n < 4_000_000:
-        M = pkg.BinMatrix.from_words(a, l)
-        rank = M.echelonize(full=True)
-        red, orank, _ = g.o_echelonize(a, m, l, full=True)
-        if rank != orank or not np.array_equal(M.to_words(), red):
-            bad += 1
-            print("MISMATCH rref", m, l, flush=True)
+    if it % 4 == 0 and m * l < 6_000_000:
+        # elimination on the product's left operand, on a rank-deficient matrix (a product through a thin middle) and on a
+        # matrix with planted structure (zero column blocks, repeated rows)
+        cands = [a]
+        r = dim(min(m, l))
+        cands.append(g.o_mul_m4rm(g.random_words(m, r, 5 * it), g.random_words(r, l, 5 * it + 1), m, r, l))
+        s_ = a.copy()
+        if s_.shape[1] > 1:
+            s_[:, int(rng.integers(0, s_.shape[1]))] = 0
+        if m > 3:
+            s_[m // 2:] = s_[: m - m // 2]
+        cands.append(s_)
+        for mat in cands:
+            for full in (True, False):
+                M = pkg.BinMatrix.from_words(mat, l)
+                rank = M.echelonize(full=full)
+                red, orank, piv = g.o_echelonize(mat, m, l, full=True)
+                ok = rank == orank
+                if full:
+                    ok = ok and np.array_equal(M.to_words(), red)
+                else:  # same row space: the reduced form of the result is the reduced form
+                    ok = ok and np.array_equal(g.o_echelonize(M.to_words(), m, l, full=True)[0], red)
+                if not ok:
+                    bad += 1
+                    print("MISMATCH echelon", m, l, "full" if full else "upper", flush=True)
+        if m >= l:  # A X = B with B = A X0: the solver must return a solution (free variables 0) and report consistency
+            k = dim(300)
+            x0 = g.random_words(l, k, 7 * it)
+            bmat = g.o_mul_m4rm(cands[1], x0, m, l, k)
+            A2, B2 = pkg.BinMatrix.from_words(cands[1], l), pkg.BinMatrix.from_words(bmat, k)
+            ok = pkg.solve_left(A2, B2)
+            xref, okref = g.o_solve_left(cands[1], m, l, bmat, m, k)
+            if not (ok and okref and np.array_equal(B2.to_words(), xref)):
+                bad += 1
+                print("MISMATCH solve", m, l, k, flush=True)
     if it % 25 == 0:
         print("..", it, "done", flush=True)
 print("fuzz finished:", count, "cases,", bad, "mismatches")
