@@ -422,18 +422,26 @@ __global__ void gf2_elim_begin_block_kernel(gf2k_elim_state *st) {
 }
 
 // last non-zero word (absolute index, words [w_lo, aw)) over the block's pivot rows [r0, r_cur) after the permutation: the
-// trailing product only has to cover the columns up to it (an augmented identity is mostly zero columns for a long time)
+// trailing product only has to cover the columns up to it (an augmented identity is mostly zero columns for a long time).
+// One wave per row, scanning backwards 64 words at a time: a dense row is done after one load.
 __global__ __launch_bounds__(256) void gf2_elim_lastword_kernel(const u64 *__restrict__ A, long long lda, long long aw,
                                                                 long long w_lo, gf2k_elim_state *st) {
   const int r0 = st->r0, rp = st->r_cur - r0;
-  const long long nwd = aw - w_lo, total = (long long)rp * nwd;
+  const int lane = threadIdx.x & 63;
   int best = -1;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const long long r = i / nwd, w = w_lo + i % nwd;
-    if (A[(r0 + r) * lda + w]) best = max(best, (int)w);
+  for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rp; r += gridDim.x * 4) {
+    const u64 *row = A + (long long)(r0 + r) * lda;
+    for (long long hi = aw; hi > w_lo; hi -= 64) {  // words [hi-64, hi)
+      const long long w = hi - 64 + lane;
+      const u64 nz = __ballot(w >= w_lo && row[w] != 0);
+      if (nz) {
+        best = max(best, (int)(hi - 64 + (63 - __builtin_clzll(nz))));
+        break;
+      }
+      if (hi - 64 <= (long long)best) break;  // nothing beyond what another row of this wave already reached
+    }
   }
-  for (int o = 32; o; o >>= 1) best = max(best, __shfl_xor(best, o));
-  if ((threadIdx.x & 63) == 0 && best >= 0) atomicMax(&st->lastword, best);
+  if (lane == 0 && best >= 0) atomicMax(&st->lastword, best);
 }
 
 // pivot row j of the block holds its own original content on the right-hand columns: U'[r0+j][j] ^= 1 turns
@@ -515,7 +523,7 @@ extern "C" hipError_t gf2k_elim_end_block(u64 *A, long long lda, long long aw, l
   hipLaunchKernelGGL(gf2_elim_scatter_kernel, dim3(2 * GF2K_ELIM_BLOCK_PIVOTS), dim3(256), 0, s, A, lda, aw, c0w, U, ldu, uw,
                      st, moves, tmp, tld);
   hipLaunchKernelGGL(gf2_elim_toggle_kernel, dim3(GF2K_ELIM_BLOCK_PIVOTS / 256), dim3(256), 0, s, U, ldu, st);
-  if (w_right < aw) hipLaunchKernelGGL(gf2_elim_lastword_kernel, dim3(1024), dim3(256), 0, s, A, lda, aw, w_right, st);
+  if (w_right < aw) hipLaunchKernelGGL(gf2_elim_lastword_kernel, dim3(512), dim3(256), 0, s, A, lda, aw, w_right, st);
   return hipGetLastError();
 }
 
