@@ -441,7 +441,8 @@ __global__ __launch_bounds__(256) void gf2_elim_lastword_kernel(const u64 *__res
       if (hi - 64 <= (long long)best) break;  // nothing beyond what another row of this wave already reached
     }
   }
-  if (lane == 0 && best >= 0) atomicMax(&st->lastword, best);
+  // most waves find the same last word: look before taking the atomic (2048 atomics on one address cost ~20 us)
+  if (lane == 0 && best >= 0 && best > *reinterpret_cast<volatile int *>(&st->lastword)) atomicMax(&st->lastword, best);
 }
 
 // pivot row j of the block holds its own original content on the right-hand columns: U'[r0+j][j] ^= 1 turns
