@@ -483,6 +483,57 @@ __global__ __launch_bounds__(256) void gf2_any_nonzero_kernel(const u64 *__restr
 }
 
 // ---------------------------------------------------------------------------------------------
+// small matrices: the whole matrix in LDS, textbook Gauss(-Jordan) by one workgroup
+// ---------------------------------------------------------------------------------------------
+// For matrices of at most 1024 rows that fit into LDS (rows x (words | 1) <= 19000 words) the blocked algorithm above is
+// all latency (two launches and ~50 us per 64 columns); here one workgroup keeps the matrix in LDS (odd row stride: a
+// column of words spreads over the banks) and eliminates column by column: ballot for the first row with a 1, swap it up,
+// every other row with a 1 adds the pivot row (one thread per row, the pivot row is a broadcast read).
+__global__ __launch_bounds__(1024) void gf2_elim_small_kernel(u64 *__restrict__ A, long long lda, int m, int ncols, int limit,
+                                                              int full, int *__restrict__ rank_out, int *__restrict__ pivcols) {
+  extern __shared__ __attribute__((aligned(16))) u64 M[];
+  __shared__ int s_first[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int aw = (ncols + 63) >> 6, stride = aw | 1;
+  for (int idx = tid; idx < m * aw; idx += 1024) M[(idx / aw) * stride + idx % aw] = A[(long long)(idx / aw) * lda + idx % aw];
+  __syncthreads();
+  int rank = 0;
+  for (int c = 0; c < limit && rank < m; ++c) {
+    const int cw = c >> 6;
+    const u64 bit = 1ull << (c & 63);
+    const bool mine = tid < m && (M[tid * stride + cw] & bit);
+    const u64 cand = __ballot(mine && tid >= rank);
+    if (lane == 0) s_first[wave] = cand ? wave * 64 + __builtin_ctzll(cand) : 0x7fffffff;
+    __syncthreads();
+    int p = 0x7fffffff;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) p = min(p, s_first[w]);
+    if (p == 0x7fffffff) {  // no pivot in this column (uniform)
+      __syncthreads();      // s_first is rewritten by the next column
+      continue;
+    }
+    if (p != rank) {
+      if (tid >= cw && tid < aw) {  // both rows are zero left of the column
+        const u64 t = M[rank * stride + tid];
+        M[rank * stride + tid] = M[p * stride + tid];
+        M[p * stride + tid] = t;
+      }
+    }
+    __syncthreads();
+    // after the swap row `rank` holds the pivot (row p holds what was in row `rank`): every row looks at its bit again
+    const bool add = tid < m && tid != rank && (M[tid * stride + cw] & bit);
+    if (add && (full || tid > rank)) {
+      for (int w = cw; w < aw; ++w) M[tid * stride + w] ^= M[rank * stride + w];
+    }
+    if (tid == 0) pivcols[rank] = c;
+    ++rank;
+    __syncthreads();
+  }
+  for (int idx = tid; idx < m * aw; idx += 1024) A[(long long)(idx / aw) * lda + idx % aw] = M[(idx / aw) * stride + idx % aw];
+  if (tid == 0) *rank_out = rank;
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
 extern "C" hipError_t gf2k_elim_begin_block(gf2k_elim_state *st, hipStream_t s) {
@@ -494,10 +545,20 @@ extern "C" hipError_t gf2k_elim_step(u64 *A, long long lda, int m, long long c0w
                                      u64 *U, long long ldu, int uw, gf2k_elim_state *st, int *pivcols, u64 *ptab,
                                      unsigned char *rowflag, int *blkpiv, hipStream_t s) {
   if (sw + uw > 64 || j >= sw || sw * 64 > GF2K_ELIM_BLOCK_PIVOTS) return hipErrorInvalidValue;
-  {  // 64 KiB of dynamic LDS for the tables that combine the reduced pivot rows, on top of ~37 KiB static
+  // dynamic LDS limits are per device: set them once per device, not per step (the call costs host time that a chain
+  // of 50 us steps notices)
+  static bool attr_done[64] = {false};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  if (!attr_done[dev & 63]) {
+    // 64 KiB of dynamic LDS for the tables that combine the reduced pivot rows, on top of ~37 KiB static
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gf2_elim_pivot_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gf2_elim_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              kUpdLds);
     if (e != hipSuccess) return e;
+    attr_done[dev & 63] = true;
   }
   hipLaunchKernelGGL(gf2_elim_pivot_kernel, dim3(1), dim3(1024), 65536, s, A, lda, m, c0w, sw, j, colmask, U, ldu, uw, st,
                      pivcols, ptab, rowflag, blkpiv);
@@ -505,13 +566,21 @@ extern "C" hipError_t gf2k_elim_step(u64 *A, long long lda, int m, long long c0w
   int grid = (m + 127) / 128;
   if (grid > 256) grid = 256;
   if (grid < 1) grid = 1;
-  {  // per device, so not cached in a static (same as the tile kernel's launcher)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gf2_elim_update_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kUpdLds);
-    if (e != hipSuccess) return e;
-  }
   hipLaunchKernelGGL(gf2_elim_update_kernel, dim3(grid), dim3(1024), kUpdLds, s, A, lda, m, full, c0w, sw, j, U, ldu, uw, st,
                      ptab, rowflag);
+  return hipGetLastError();
+}
+
+// rows <= 1024 and rows * (words | 1) <= 19000: everything in the LDS of one workgroup (returns hipErrorInvalidValue otherwise)
+extern "C" hipError_t gf2k_elim_small(u64 *A, long long lda, int m, int ncols, int limit, int full, int *rank_out, int *pivcols,
+                                      hipStream_t s) {
+  const int aw = (ncols + 63) / 64, stride = aw | 1;
+  if (m < 1 || m > 1024 || (long long)m * stride > 19000) return hipErrorInvalidValue;
+  const int lds = m * stride * 8;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gf2_elim_small_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(gf2_elim_small_kernel, dim3(1), dim3(1024), lds, s, A, lda, m, ncols, limit, full, rank_out, pivcols);
   return hipGetLastError();
 }
 

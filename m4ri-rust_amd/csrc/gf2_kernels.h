@@ -54,6 +54,9 @@ hipError_t gf2k_elim_step(uint64_t *A, long long lda, int m, long long c0w, int 
 hipError_t gf2k_elim_end_block(uint64_t *A, long long lda, long long aw, long long c0w, uint64_t *U, long long ldu, int uw,
                                gf2k_elim_state *st, unsigned char *rowflag, const int *blkpiv, int *moves, uint64_t *tmp,
                                long long tld, long long w_right, hipStream_t s);
+// whole-matrix-in-LDS elimination for small matrices; hipErrorInvalidValue if the matrix does not qualify
+hipError_t gf2k_elim_small(uint64_t *A, long long lda, int m, int ncols, int limit, int full, int *rank_out, int *pivcols,
+                           hipStream_t s);
 hipError_t gf2k_set_diag(uint64_t *M, long long ld, int n, long long col0, hipStream_t s);
 hipError_t gf2k_scatter_rows(uint64_t *X, long long ldx, const uint64_t *R, long long ldr, int words, const int *pivcols,
                              int rank, hipStream_t s);

@@ -1130,6 +1130,19 @@ int echelonize_dev(gf2_dmat *A, int full, int col_limit, int *rank_out, int *piv
   DevBuf &pv = pivcols_keep ? *pivcols_keep : pivs;
   if (int rc = st.alloc(sizeof(gf2k_elim_state))) return rc;
   if (int rc = pv.alloc((size_t)(max_rank + 64) * sizeof(int))) return rc;
+  // small problems: one workgroup, the whole matrix in LDS.  It costs ~1 us per column it has to look at (it stops when
+  // the rank reaches the row count) against ~0.8 us per column plus ~50 us fixed for the blocked algorithm below, so it
+  // is taken when at most 256 columns can matter (1000 x 64: 94 us against 139; 10 x 10: 60 against 109)
+  const int cols_to_visit = limit < m + 64 ? limit : m + 64;
+  if (m <= 1024 && (long long)m * (aw | 1) <= 19000 && cols_to_visit <= 256 && env_int("M4RI_HIP_ELIM_SMALL", 1)) {
+    HIP_TRY(gf2k_elim_small(A->data, lda, m, ncols, limit, full, reinterpret_cast<int *>(st.p), pv.as<int>(), s));
+    HIP_TRY(hipMemcpyAsync(rank_out, st.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (pivcols_host && *rank_out > 0)
+      HIP_TRY(hipMemcpyAsync(pivcols_host, pv.p, (size_t)*rank_out * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+  }
   if (int rc = U.alloc((size_t)m * uw * sizeof(u64))) return rc;
   if (int rc = ptab.alloc(64 * 64 * sizeof(u64))) return rc;
   if (int rc = tmp.alloc((size_t)2 * GF2K_ELIM_BLOCK_PIVOTS * tld * sizeof(u64))) return rc;
