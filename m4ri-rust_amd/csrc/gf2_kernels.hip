@@ -27,6 +27,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <mutex>
+#include <set>
 #include <type_traits>
 #include <utility>
 #include "gf2_kernels.h"
@@ -1407,10 +1409,23 @@ static inline int grid_for(long long total, int block = 256, int cap = 256 * 8) 
 
 extern "C" int gf2k_m4rm_rows_per_tile(int cfg) { return (cfg == 1 || cfg == 20) ? 256 : 1024; }
 
+// The dynamic-LDS limit of a kernel is per device; hipFuncSetAttribute costs host time that short kernels launched back
+// to back notice, so it is issued once per (kernel, device).
+static hipError_t lds_limit_once(const void *kernel, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<const void *, int>> done;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  std::lock_guard<std::mutex> lk(mu);
+  if (done.count({kernel, dev})) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done.insert({kernel, dev});
+  return e;
+}
+
 template <typename K>
 static hipError_t launch_tile_kernel(K kernel, int threads, const gf2k_mul_args &a, long long nwg, hipStream_t stream) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     kLdsBytes);
+  hipError_t e = lds_limit_once(reinterpret_cast<const void *>(kernel), kLdsBytes);
   if (e != hipSuccess) {
     fprintf(stderr, "gf2k: hipFuncSetAttribute failed: %s\n", hipGetErrorString(e));
     return e;
@@ -1543,8 +1558,7 @@ extern "C" hipError_t gf2k_tallskinny(const u64 *A, long long lda, const u64 *B,
     const size_t lds3 = 128 * 1024 + 4 * 1024;
     hipError_t e3;
 #define GF2_TS3_LAUNCH(NWV)                                                                                              \
-  e3 = hipFuncSetAttribute(reinterpret_cast<const void *>(&gf2_tallskinny3_kernel<NWV, RPT3, NT3>),                      \
-                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);                                       \
+  e3 = lds_limit_once(reinterpret_cast<const void *>(&gf2_tallskinny3_kernel<NWV, RPT3, NT3>), (int)lds3);              \
   if (e3 != hipSuccess) return e3;                                                                                       \
   hipLaunchKernelGGL((gf2_tallskinny3_kernel<NWV, RPT3, NT3>), dim3(grid3), dim3(NT3), lds3, stream, A, lda, B, ldb, C, ldc, m, \
                      l, n, accumulate)
@@ -1561,8 +1575,7 @@ extern "C" hipError_t gf2k_tallskinny(const u64 *A, long long lda, const u64 *B,
   const size_t lds = 128 * 1024 + 8 * 64 * 8;  // tables + staged rows of B (8 words x 64 rows x NW/NW ... = 4 KiB)
   hipError_t e;
 #define GF2_TS_LAUNCH(NWV)                                                                                             \
-  e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gf2_tallskinny_kernel<NWV, RPT, NT>),                            \
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                       \
+  e = lds_limit_once(reinterpret_cast<const void *>(&gf2_tallskinny_kernel<NWV, RPT, NT>), (int)lds);                    \
   if (e != hipSuccess) return e;                                                                                       \
   hipLaunchKernelGGL((gf2_tallskinny_kernel<NWV, RPT, NT>), dim3(grid), dim3(NT), lds, stream, A, lda, B, ldb, C, ldc, m, l, n, \
                      accumulate)
