@@ -610,6 +610,279 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v3(const gf2k_mul_
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// M4RM tile kernel v5: two chunks per lookup step, combined with one three-input XOR (v_bitop3_b32).
+// The v3 kernel spends five VALU instructions per 16-byte lookup (address v_perm_b32 + four v_xor_b32) and the VALU
+// port is what it runs out of.  Here a lane looks its row up in the tables of TWO consecutive chunks and folds both
+// 16-byte results into the accumulator with four v_bitop3_b32 (acc ^= x ^ y): three VALU instructions per lookup.
+// Geometry: tile of 2048 rows x 1024 columns (8 waves x 256 rows; 8 lanes x 16 bytes per row, 8 rows per step).  A
+// 256-byte LDS row holds entry e of the even chunk's table in its lower half and of the odd chunk's table in its upper
+// half ("pair table", 64 KiB; two of them: one looked up, one being built), so a table row of a pair is still ONE
+// ds_write_addtid_b32 (lanes 0..31 hold dwords of the even chunk's rows of B, lanes 32..63 of the odd chunk's).  The 16
+// lanes the LDS serves together are two rows: the lanes of the odd row read the upper half (odd chunk) first and the
+// lower half second, the lanes of the even row the other way round -- 64 different banks in both reads
+// (tools/ubench: 16.0 cycles per ds_read_b128 and SIMD, same as a full 256-byte row; 32.0 without the swap).
+// Rows of B past the inner dimension read as zero through the buffer descriptor's bound, so there is one loop only.
+// ---------------------------------------------------------------------------------------------
+
+// LDS operations that may still be outstanding when step `st_wait` needs the two reads of step `target` (ops complete in
+// order).  Issue order: prologue 2 reads for each step < G; then per step s: [wait], two reads of step s+G (if any),
+// one table write.
+constexpr int v5_wait_count(int st_wait, int target, int G, int STEPS) {
+  int after = 0;      // ops issued after the target's second read
+  bool seen = false;
+  for (int k = 0; k < G && k < STEPS; ++k) {
+    if (seen) after += 2;
+    if (k == target) seen = true;
+  }
+  for (int s = 0; s < st_wait; ++s) {
+    if (s + G < STEPS) {
+      if (seen) after += 2;
+      if (s + G == target) seen = true;
+    }
+    if (seen) after += 1;
+  }
+  return after > 15 ? 15 : after;
+}
+
+static constexpr int kTileWords5 = 16;  // 1024 columns per tile
+
+// DBG != 0: timing-only ablations (wrong results): 2 no barriers, 3 no global loads in the loop, 4 no table writes,
+// 5 no lookups (reads + XORs), 6 no XORs
+template <int WAVES, int RPW, int G, int DBG = 0>
+__global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v5(const gf2k_mul_args p) {
+  constexpr int R = WAVES * RPW;
+  constexpr int STEPS = RPW / 8;
+  constexpr int EPW = 256 / WAVES;  // pair-table rows built per wave
+  constexpr int LOWB = Log2<EPW>::value;
+  static_assert(EPW * WAVES == 256 && G <= STEPS && EPW <= STEPS, "geometry");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int t;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = t % p.tiles_m;
+  t /= p.tiles_m;
+  const int ks = t % p.ksplit;
+  t /= p.ksplit;
+  const int tn = t % p.tiles_n;
+  const int bt = t / p.tiles_n;
+  const u64 *__restrict__ A = p.A + (long long)bt * p.sA;
+  const u64 *__restrict__ B = p.B + (long long)bt * p.sB;
+  const bool part = p.P != nullptr && p.ksplit > 1;
+  u64 *__restrict__ C = part ? p.P + ((long long)bt * p.ksplit + ks) * p.sP : p.C + (long long)bt * p.sC;
+  const long long ldc = part ? p.ldp : p.ldc;
+  const bool accum = !part && p.accumulate;
+
+  const int row0 = tm * R, w0 = tn * kTileWords5;
+  const int widthB = (p.n + 63) >> 6;
+  const u64 maskC = (p.n & 63) ? ((1ull << (p.n & 63)) - 1) : ~0ull;
+  const int nw32 = (p.l + 31) >> 5;
+  const int jbeg = ks * p.kwords;
+  const int jend = min(nw32, jbeg + p.kwords);
+
+  const int g = lane >> 3, qd = lane & 7, h = g & 1;
+  // byte offsets inside a pair-table row: first read / second read, pair table 0 / 1
+  const u32 lo0a = (u32)qd * 16u + (u32)h * 128u, lo0b = lo0a ^ 128u;
+  const u32 lo1a = lo0a | 0x10000u, lo1b = lo0b | 0x10000u;
+  // v_perm_b32 selectors {0, table bit, byte of the A word, lane offset}: the first read takes the even chunk's byte
+  // for even rows and the odd chunk's for odd rows
+  const u32 sel0a = 0x0c020000u | ((4u + (u32)h) << 8), sel0b = sel0a ^ 0x100u;  // bytes 0,1 of the word
+  const u32 sel1a = 0x0c020000u | ((6u + (u32)h) << 8), sel1b = sel1a ^ 0x100u;  // bytes 2,3
+  const int myrow0 = row0 + wave * RPW + g;
+
+  u32 acc[STEPS][4];
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) acc[s][0] = acc[s][1] = acc[s][2] = acc[s][3] = 0;
+
+  // ---- A: 32-bit word j of the row of each step; rows past m read as zero (descriptor bound) ----
+  const u32 ldaB = (u32)p.lda * 8u;
+  const int rows_here = min(p.m - row0, R);
+  const __amdgpu_buffer_rsrc_t rsrcA =
+      __builtin_amdgcn_make_buffer_rsrc((void *)(A + (long long)row0 * p.lda), (short)0, (int)((u32)rows_here * ldaB), 0x00020000);
+  const u32 voffA0 = (u32)(wave * RPW + g) * ldaB;
+  const u32 tailA = (p.l & 31) ? ((1u << (p.l & 31)) - 1u) : 0xffffffffu;
+  u32 aw[STEPS];
+
+  // ---- B: lanes 0..31 hold dword `lane` of the 8 rows of the pair's even chunk, lanes 32..63 of its odd chunk ----
+  const u32 ldbB = (u32)p.ldb * 8u;
+  const int validB = min(128, (widthB - w0) * 8);  // bytes of this tile's columns that exist
+  const u32 voffB = ((int)((lane & 31) * 4) < validB) ? (u32)(lane & 31) * 4u + (u32)(lane >> 5) * 8u * ldbB : 0x80000000u;
+  auto rsrcB_for = [&](int pr) __attribute__((always_inline)) {  // rows [16 pr, 16 pr + 16) of B, cut at l
+    const int rows = min(16, p.l - 16 * pr);
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(B + (long long)pr * 16 * p.ldb + w0), (short)0,
+                                             rows > 0 ? (int)((u32)rows * ldbB) : 0, 0x00020000);
+  };
+
+  // ---- table build: wave w owns rows [EPW*w, EPW*(w+1)) of the pair table, one ds_write_addtid_b32 each ----
+  u32 cur32 = 0;
+  auto build_begin = [&](const u32 (&rr)[8], u32 tbase) __attribute__((always_inline)) {
+    cur32 = 0;
+#pragma unroll
+    for (int b = LOWB; b < 8; ++b)
+      if ((wave >> (b - LOWB)) & 1) cur32 ^= rr[b];
+    const u32 kOff = tbase ? (0x10004u - (u32)(EPW * 256)) : 0u;  // see gf2_m4rm_kernel_v3
+    const u32 m0v = tbase + (u32)wave * (u32)(EPW * 256) - kOff;
+    asm volatile("s_mov_b32 m0, %0" ::"s"(m0v) : "memory");
+  };
+  auto build_write = [&cur32](auto itag, auto ttag) __attribute__((always_inline)) {
+    constexpr int i = decltype(itag)::value;
+    constexpr u32 tbase = decltype(ttag)::value;
+    constexpr unsigned e = (unsigned)i ^ ((unsigned)i >> 1);
+    constexpr u32 kOff = tbase ? (0x10004u - (u32)(EPW * 256)) : 0u;
+    asm volatile("ds_write_addtid_b32 %0 offset:%1" ::"v"(cur32), "n"(kOff + e * 256u) : "memory");
+  };
+
+  // ---- prologue: rows of pair 2*jbeg -> pair table 0, rows of the next pair -> rrB, A column jbeg ----
+  u32 rrA[8], rrB[8];
+  {
+    const __amdgpu_buffer_rsrc_t rs0 = rsrcB_for(2 * jbeg), rs1 = rsrcB_for(2 * jbeg + 1);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      rrA[b] = __builtin_amdgcn_raw_buffer_load_b32(rs0, voffB + (u32)b * ldbB, 0, 0);  // row offset in the VGPR: bound-checked
+      rrB[b] = __builtin_amdgcn_raw_buffer_load_b32(rs1, voffB + (u32)b * ldbB, 0, 0);
+    }
+  }
+  {
+    u32 vo = voffA0;
+    asm volatile("" : "+v"(vo));
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      aw[s] = __builtin_amdgcn_raw_buffer_load_b32(rsrcA, vo, jbeg * 4, 0);
+      vo += 8u * ldaB;
+    }
+  }
+  if (jbeg == nw32 - 1) {
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) aw[s] &= tailA;
+  }
+  build_begin(rrA, 0u);
+  static_for<EPW>([&](auto it) __attribute__((always_inline)) {
+    constexpr int i = decltype(it)::value;
+    if constexpr (i > 0) cur32 ^= rrA[__builtin_ctz(i | 256)];
+    build_write(it, std::integral_constant<u32, 0u>{});
+  });
+  __syncthreads();
+
+  // one pair: look pair `pr` up in pair table PP; build pair pr+1 from `rows` into the other table; fetch the rows of
+  // pair pr+2 into `next` and (second pair of a 32-bit column) the next A column in place
+  // FAST: pair pr+2 lies wholly inside the inner dimension (the row offset may then ride in the scalar offset, which the
+  // descriptor's bound check ignores)
+  auto pair_iter = [&](int pr, auto pptag, auto fast, const u32 (&rows)[8], u32 (&next)[8]) __attribute__((always_inline)) {
+    constexpr int PP = decltype(pptag)::value;
+    const u32 loa = PP ? lo1a : lo0a, lob = PP ? lo1b : lo0b;
+    const u32 sela = PP ? sel1a : sel0a, selb = PP ? sel1b : sel0b;
+    using tnext = std::integral_constant<u32, PP ? 0u : (u32)kTableBytes>;
+    build_begin(rows, tnext::value);
+    const __amdgpu_buffer_rsrc_t rsN = rsrcB_for(pr + 2);
+    const int jn = min((pr >> 1) + 1, nw32 - 1);  // clamped: never past the end of a row
+    u32 voA = voffA0;
+    asm volatile("" : "+v"(voA));
+    u32x4 ta[G], tb[G];
+    auto issue = [&](int st, u32x4 &da, u32x4 &db) __attribute__((always_inline)) {
+      u32 a0, a1;
+      asm volatile("v_perm_b32 %2, %4, %5, %6\n\tds_read_b128 %0, %2\n\tv_perm_b32 %3, %4, %7, %8\n\tds_read_b128 %1, %3"
+                   : "=&v"(da), "=&v"(db), "=&v"(a0), "=&v"(a1)
+                   : "v"(aw[st]), "v"(loa), "v"(sela), "v"(lob), "v"(selb)
+                   : "memory");
+    };
+    if constexpr (DBG != 5) {
+#pragma unroll
+      for (int k = 0; k < G; ++k) issue(k, ta[k], tb[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < G; ++k) ta[k] = tb[k] = u32x4{aw[k], aw[k], aw[k], aw[k]};
+    }
+    static_for<STEPS>([&](auto stag) __attribute__((always_inline)) {
+      constexpr int st = decltype(stag)::value;
+      // one s_waitcnt per pair of steps (it covers the younger step's reads)
+      if constexpr (DBG == 5) {
+      } else if constexpr (st % 2 == 0 || st + 1 >= STEPS) {
+        constexpr int sw = (st % 2 == 0 && st + 1 < STEPS) ? st + 1 : st;
+        constexpr int N = v5_wait_count(st, sw, G, STEPS);
+        if constexpr (sw != st)
+          asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(ta[st % G]), "+v"(tb[st % G]), "+v"(ta[sw % G]), "+v"(tb[sw % G]) : "n"(N) : "memory");
+        else
+          asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(ta[st % G]), "+v"(tb[st % G]) : "n"(N) : "memory");
+      }
+      if constexpr (st < EPW && st > 0) cur32 ^= rows[__builtin_ctz(st | 256)];
+      if constexpr (DBG != 5 && DBG != 6) {
+        asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[st][0]) : "v"(ta[st % G].x), "v"(tb[st % G].x));
+        asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[st][1]) : "v"(ta[st % G].y), "v"(tb[st % G].y));
+        asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[st][2]) : "v"(ta[st % G].z), "v"(tb[st % G].z));
+        asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[st][3]) : "v"(ta[st % G].w), "v"(tb[st % G].w));
+      } else if constexpr (DBG == 6) {
+        asm volatile("" :: "v"(ta[st % G]), "v"(tb[st % G]));
+      }
+      if constexpr (st + G < STEPS && DBG != 5) issue(st + G, ta[st % G], tb[st % G]);
+      if constexpr (st < EPW && DBG != 4) build_write(std::integral_constant<int, st>{}, tnext{});
+      if constexpr (DBG == 3) {
+      } else if constexpr (st < 8) {
+        if constexpr (decltype(fast)::value)
+          next[st] = __builtin_amdgcn_raw_buffer_load_b32(rsN, voffB, st * (int)ldbB, 0);
+        else
+          next[st] = __builtin_amdgcn_raw_buffer_load_b32(rsN, voffB + (u32)st * ldbB, 0, 0);
+      }
+      if constexpr (PP == 1 && DBG != 3) {  // aw[st] was consumed G steps ago: fetch the next column's word in place
+        aw[st] = __builtin_amdgcn_raw_buffer_load_b32(rsrcA, voA, jn * 4, 0);
+        voA += 8u * ldaB;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if constexpr (PP == 1) {
+      if (jn == nw32 - 1 && tailA != 0xffffffffu) {
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) aw[s] &= tailA;
+      }
+    }
+    if constexpr (DBG != 2) __syncthreads();
+  };
+
+  // two separate loops (not one loop with a branch): see gf2_m4rm_kernel_v3
+  int j = jbeg;
+#pragma unroll 1
+  for (; j < jend && (j + 2) * 32 <= p.l; ++j) {
+    pair_iter(2 * j, std::integral_constant<int, 0>{}, std::true_type{}, rrB, rrA);
+    pair_iter(2 * j + 1, std::integral_constant<int, 1>{}, std::true_type{}, rrA, rrB);
+  }
+#pragma unroll 1
+  for (; j < jend; ++j) {  // ragged end
+    pair_iter(2 * j, std::integral_constant<int, 0>{}, std::false_type{}, rrB, rrA);
+    pair_iter(2 * j + 1, std::integral_constant<int, 1>{}, std::false_type{}, rrA, rrB);
+  }
+
+  const int wc = w0 + 2 * qd;
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    const int row = myrow0 + 8 * s;
+    if (row < p.m && wc < widthB) {
+      u64 *dst = C + (long long)row * ldc + wc;
+      u64 v0 = (u64)acc[s][0] | ((u64)acc[s][1] << 32);
+      u64 v1 = (u64)acc[s][2] | ((u64)acc[s][3] << 32);
+      if (wc == widthB - 1) v0 &= maskC;
+      if (wc + 1 == widthB - 1) v1 &= maskC;
+      if (p.ksplit > 1 && !part) {
+        if (v0) atomicXor(reinterpret_cast<unsigned long long *>(dst), (unsigned long long)v0);
+        if (wc + 1 < widthB && v1) atomicXor(reinterpret_cast<unsigned long long *>(dst + 1), (unsigned long long)v1);
+      } else if (wc + 1 < widthB) {
+        if (accum) {
+          const uint4 old = *reinterpret_cast<const uint4 *>(dst);
+          v0 ^= (u64)old.x | ((u64)old.y << 32);
+          v1 ^= (u64)old.z | ((u64)old.w << 32);
+        }
+        *reinterpret_cast<uint4 *>(dst) = make_uint4((u32)v0, (u32)(v0 >> 32), (u32)v1, (u32)(v1 >> 32));
+      } else {
+        if (accum) v0 ^= dst[0];
+        dst[0] = v0;
+      }
+    }
+  }
+}
+
 // C (+)= XOR of the ksplit partial products of a split-K launch (dense, row stride ldp, 16-byte accesses; ldp even)
 __global__ __launch_bounds__(256) void gf2_splitk_reduce_kernel(u64 *__restrict__ C, long long ldc, long long sC,
                                                                 const u64 *__restrict__ P, long long ldp, long long sP,
@@ -1407,7 +1680,7 @@ static inline int grid_for(long long total, int block = 256, int cap = 256 * 8) 
   return (int)g;
 }
 
-extern "C" int gf2k_m4rm_rows_per_tile(int cfg) { return (cfg == 1 || cfg == 20) ? 256 : 1024; }
+extern "C" int gf2k_m4rm_rows_per_tile(int cfg) { return (cfg == 1 || cfg == 20) ? 256 : (cfg == 8 || (cfg >= 80 && cfg < 90)) ? 2048 : 1024; }
 
 // The dynamic-LDS limit of a kernel is per device; hipFuncSetAttribute costs host time that short kernels launched back
 // to back notice, so it is issued once per (kernel, device).
@@ -1441,7 +1714,7 @@ extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {
   if (a.m <= 0 || a.n <= 0 || a.batch <= 0) return hipSuccess;
   const int R = gf2k_m4rm_rows_per_tile(cfg);
   a.tiles_m = (a.m + R - 1) / R;
-  a.tiles_n = (a.n + 2047) / 2048;
+  a.tiles_n = (cfg == 8 || (cfg >= 80 && cfg < 90)) ? (a.n + 1023) / 1024 : (a.n + 2047) / 2048;
   const int nw32 = (a.l + 31) / 32;
   if (cfg == 0 || cfg == 1 || a.ksplit < 1) a.ksplit = 1;  // first-generation kernels have no split-K
   if (a.ksplit > nw32) a.ksplit = nw32 > 0 ? nw32 : 1;
@@ -1462,6 +1735,13 @@ extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {
     case 1: e = launch_tile_kernel(&gf2_m4rm_kernel<4, 64>, 256, a, nwg, stream); break;
     case 7: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4>, 512, a, nwg, stream); break;
     case 20: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<4, 64, 4>, 256, a, nwg, stream); break;
+    case 8: e = launch_tile_kernel(&gf2_m4rm_kernel_v5<8, 256, 4>, 512, a, nwg, stream); break;  // paired chunks, 2048 x 1024 tile
+    case 80: e = launch_tile_kernel(&gf2_m4rm_kernel_v5<8, 256, 6>, 512, a, nwg, stream); break;
+    case 81: e = launch_tile_kernel(&gf2_m4rm_kernel_v5<8, 256, 4, 2>, 512, a, nwg, stream); break;  // timing-only ablations
+    case 82: e = launch_tile_kernel(&gf2_m4rm_kernel_v5<8, 256, 4, 3>, 512, a, nwg, stream); break;
+    case 83: e = launch_tile_kernel(&gf2_m4rm_kernel_v5<8, 256, 4, 4>, 512, a, nwg, stream); break;
+    case 84: e = launch_tile_kernel(&gf2_m4rm_kernel_v5<8, 256, 4, 5>, 512, a, nwg, stream); break;
+    case 85: e = launch_tile_kernel(&gf2_m4rm_kernel_v5<8, 256, 4, 6>, 512, a, nwg, stream); break;
     case 50: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 0, 0, 1>, 512, a, nwg, stream); break;  // packed B
     case 40: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 2>, 512, a, nwg, stream); break;  // no barriers (timing only)
     case 41: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 3>, 512, a, nwg, stream); break;  // no loads in the loop

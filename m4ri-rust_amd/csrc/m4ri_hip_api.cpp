@@ -352,23 +352,38 @@ static int env_int(const char *name, int dflt) {
 }
 
 // ---- launch geometry of the tile kernel (shared by the launcher and the level chooser) ----
-// kernel variants (gf2_kernels.hip): 7 = v3 1024x2048 tile (8 waves), 20 = v3 256x2048 tile (4 waves);
-// M4RI_HIP_M4RM_CFG overrides (0/1 = first-generation kernels, kept for A/B runs)
+// kernel variants (gf2_kernels.hip): 8 = v5 2048 x 1024 tile, two chunks per lookup step (8 waves); 7 = v3 1024 x 2048 tile
+// (8 waves); 20 = v3 256 x 2048 tile (4 waves).  M4RI_HIP_M4RM_CFG overrides (0/1 = first-generation kernels, kept for
+// A/B runs)
+struct TileGeom {
+  int rows, cols;
+  double cyc_per_chunk;  // measured cycles per 8 bits of the inner dimension and tile, 2.4 GHz
+};
+static TileGeom tile_geom(int cfg) {
+  if (cfg == 8 || (cfg >= 80 && cfg < 90)) return {2048, 1024, 2110.0};
+  if (cfg == 20 || cfg == 1) return {256, 2048, 1300.0};
+  return {1024, 2048, 2350.0};
+}
+static long long tiles_of(const TileGeom &g, int m, int n) {
+  return (long long)((m + g.rows - 1) / g.rows) * ((n + g.cols - 1) / g.cols);
+}
+
 static int m4rm_cfg_for(int m, int n, int batch) {
-  (void)n;
   (void)batch;
   static const int forced = env_int("M4RI_HIP_M4RM_CFG", -1);
   if (forced >= 0) return forced;
-  return m <= 256 ? 20 : 7;
+  if (m <= 256) return 20;
+  // same tile area, the paired kernel is ~10 % faster per tile: it wins unless its tall tiles leave more of the grid empty
+  const TileGeom g8 = tile_geom(8), g7 = tile_geom(7);
+  return (double)tiles_of(g8, m, n) * g8.cyc_per_chunk <= (double)tiles_of(g7, m, n) * g7.cyc_per_chunk ? 8 : 7;
 }
 
 // split-K factor: when a product has too few tiles to fill 256 CUs, the inner dimension is cut into slices of
-// at least 8 x 32 bits; the slices' partial sums are combined with atomic XOR
+// at least 128 bits; the slices' partial products are combined by a second kernel
 static int m4rm_ksplit_for(int m, int l, int n, int batch) {
   static const int forced = env_int("M4RI_HIP_M4RM_KSPLIT", 0);
   if (forced > 0) return forced;
-  const int R = m <= 256 ? 256 : 1024;
-  const long long wg = (long long)((m + R - 1) / R) * ((n + 2047) / 2048) * batch;
+  const long long wg = tiles_of(tile_geom(m4rm_cfg_for(m, n, batch)), m, n) * batch;
   if (wg >= 192) return 1;
   const int nw32 = (l + 31) / 32;
   long long ks = 256 / wg;  // one round of workgroups: 256 long slices beat 512 short ones (8192x65536x16384: 2.25 vs 2.52 ms)
@@ -378,13 +393,12 @@ static int m4rm_ksplit_for(int m, int l, int n, int batch) {
 
 // modelled duration of one (batched) tile-kernel launch: rounds of 256 workgroups, each `chunks` table steps
 static double m4rm_time_model(int m, int l, int n, int batch) {
-  const int R = m <= 256 ? 256 : 1024;
-  const double cyc_per_chunk = R == 1024 ? 2350.0 : 1300.0;  // measured, 2.4 GHz
+  const TileGeom g = tile_geom(m4rm_cfg_for(m, n, batch));
   const int ks = m4rm_ksplit_for(m, l, n, batch);
-  const double wg = (double)((m + R - 1) / R) * ((n + 2047) / 2048) * batch * ks;
+  const double wg = (double)tiles_of(g, m, n) * batch * ks;
   const double chunks = std::ceil((l + 31) / 32 / (double)ks) * 4.0;
   const double rounds = std::ceil(wg / 256.0);
-  return rounds * (chunks * cyc_per_chunk + 6000.0) / 2.4e9 + 3e-6;
+  return rounds * (chunks * g.cyc_per_chunk + 6000.0) / 2.4e9 + 3e-6;
 }
 
 // Levels whose operands are materialised in the arena: the passes fuse two Strassen levels at a time
@@ -467,8 +481,8 @@ static int mul_m4rm_plain(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int
     return 0;
   }
   // buffer descriptors of the tile kernel carry 32-bit byte counts: one tile of A rows must stay below 4 GiB
-  if ((long long)A->ld * 8 * 1024 >= (1ll << 32) || (long long)B->ld * 8 * 8 >= (1ll << 32))
-    return fail_msg("gf2_mul_dev: row stride too large for the tile kernel (more than ~33 million columns)");
+  if ((long long)A->ld * 8 * 2048 >= (1ll << 32) || (long long)B->ld * 8 * 16 >= (1ll << 31))
+    return fail_msg("gf2_mul_dev: row stride too large for the tile kernel (more than ~16 million columns)");
   gf2k_mul_args a{};
   a.A = A->data;
   a.B = B->data;

@@ -106,6 +106,30 @@ __global__ __launch_bounds__(1024) void k(unsigned long long *out, u32 *sink, in
       asm volatile("s_waitcnt lgkmcnt(4)\nv_xor_b32 %0, %0, %10\nv_xor_b32 %1, %1, %10\nv_xor_b32 %2, %2, %10\nv_xor_b32 %3, %3, %10\nv_mov_b32_sdwa %11, %10 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0\nds_read_b128 %4, %11\nv_xor_b32 %0, %0, %10\nv_xor_b32 %1, %1, %10\nv_xor_b32 %2, %2, %10\nv_xor_b32 %3, %3, %10\nv_mov_b32_sdwa %11, %10 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1\nds_read_b128 %5, %11\ns_waitcnt lgkmcnt(4)\nv_xor_b32 %0, %0, %10\nv_xor_b32 %1, %1, %10\nv_xor_b32 %2, %2, %10\nv_xor_b32 %3, %3, %10\nv_mov_b32_sdwa %11, %10 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\nds_read_b128 %6, %11\nv_xor_b32 %0, %0, %10\nv_xor_b32 %1, %1, %10\nv_xor_b32 %2, %2, %10\nv_xor_b32 %3, %3, %10\nv_mov_b32_sdwa %11, %10 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3\nds_read_b128 %7, %11\ns_waitcnt lgkmcnt(4)\nv_xor_b32 %0, %0, %10\nv_xor_b32 %1, %1, %10\nv_xor_b32 %2, %2, %10\nv_xor_b32 %3, %3, %10\nv_mov_b32_sdwa %11, %10 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0\nds_read_b128 %8, %11\nv_xor_b32 %0, %0, %10\nv_xor_b32 %1, %1, %10\nv_xor_b32 %2, %2, %10\nv_xor_b32 %3, %3, %10\nv_mov_b32_sdwa %11, %10 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1\nds_read_b128 %9, %11\ns_waitcnt lgkmcnt(4)\nv_xor_b32 %0, %0, %10\nv_xor_b32 %1, %1, %10\nv_xor_b32 %2, %2, %10\nv_xor_b32 %3, %3, %10\nv_mov_b32_sdwa %11, %10 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\nds_read_b128 %4, %11\nv_xor_b32 %0, %0, %10\nv_xor_b32 %1, %1, %10\nv_xor_b32 %2, %2, %10\nv_xor_b32 %3, %3, %10\nv_mov_b32_sdwa %11, %10 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3\nds_read_b128 %5, %11\ns_waitcnt lgkmcnt(4)\nv_xor_b32 %0, %0, %10\nv_xor_b32 %1, %1, %10\nv_xor_b32 %2, %2, %10\nv_xor_b32 %3, %3, %10\nv_mov_b32_sdwa %11, %10 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0\nds_read_b128 %6, %11\nv_xor_b32 %0, %0, %10\nv_xor_b32 %1, %1, %10\nv_xor_b32 %2, %2, %10\nv_xor_b32 %3, %3, %10\nv_mov_b32_sdwa %11, %10 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1\nds_read_b128 %7, %11\ns_waitcnt lgkmcnt(4)\nv_xor_b32 %0, %0, %10\nv_xor_b32 %1, %1, %10\nv_xor_b32 %2, %2, %10\nv_xor_b32 %3, %3, %10\nv_mov_b32_sdwa %11, %10 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\nds_read_b128 %8, %11\nv_xor_b32 %0, %0, %10\nv_xor_b32 %1, %1, %10\nv_xor_b32 %2, %2, %10\nv_xor_b32 %3, %3, %10\nv_mov_b32_sdwa %11, %10 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3\nds_read_b128 %9, %11"
           : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(a[8]), "+v"(t0)
           : "v"(a[9]) : "memory");
+    } else if constexpr (MODE == 18) {  // 64 v_bitop3_b32 (three-input XOR)
+      asm volatile(
+#define B8 "v_bitop3_b32 %0, %0, %4, %5 bitop3:0x96\n v_bitop3_b32 %1, %1, %4, %5 bitop3:0x96\n v_bitop3_b32 %2, %2, %4, %5 bitop3:0x96\n v_bitop3_b32 %3, %3, %4, %5 bitop3:0x96\n" \
+           "v_bitop3_b32 %0, %0, %5, %4 bitop3:0x96\n v_bitop3_b32 %1, %1, %5, %4 bitop3:0x96\n v_bitop3_b32 %2, %2, %5, %4 bitop3:0x96\n v_bitop3_b32 %3, %3, %5, %4 bitop3:0x96\n"
+          B8 B8 B8 B8 B8 B8 B8 B8
+          : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "v"(a[8]), "v"(a[9]));
+    } else if constexpr (MODE == 19 || MODE == 20 || MODE == 21) {
+      // 16 ds_read_b128 with a random 256-byte LDS row per 8-lane group.  19: the two groups of 16 consecutive lanes read
+      // different 128-byte halves; 20: the same half (two-way conflicts expected); 21: 16 lanes share one row (today's tile kernel)
+      const u32 grp = MODE == 21 ? (threadIdx.x >> 4) : (threadIdx.x >> 3);
+      const u32 e0 = (grp * 2654435761u >> 13) & 0xff, e1 = (grp * 40503u + 977u) & 0xff;
+      const u32 half = MODE == 19 ? ((lane >> 3) & 1) * 128u : 0u;
+      const u32 slot = MODE == 21 ? (lane & 15) * 16u : (lane & 7) * 16u + half;
+      const u32 ad0 = e0 * 256u + slot, ad1 = e1 * 256u + (MODE == 19 ? (slot ^ 128u) : slot);
+      asm volatile(R4 R4 R4 R4 "s_waitcnt lgkmcnt(0)\n" : "+v"(r0), "+v"(r1) : "v"(ad0), "v"(ad1));
+    } else if constexpr (MODE == 22) {  // 8 paired lookups: 2 perm, 2 read, 4 bitop3 each (64 instr + 8 waits)
+      asm volatile(
+#define L2 "v_perm_b32 %12, %8, %10, %11\n ds_read_b128 %13, %12\n" \
+           "v_perm_b32 %12, %9, %10, %11\n ds_read_b128 %14, %12\n" \
+           "s_waitcnt lgkmcnt(0)\n" \
+           "v_bitop3_b32 %0, %0, %8, %9 bitop3:0x96\n v_bitop3_b32 %1, %1, %8, %9 bitop3:0x96\n v_bitop3_b32 %2, %2, %8, %9 bitop3:0x96\n v_bitop3_b32 %3, %3, %8, %9 bitop3:0x96\n"
+          L2 L2 L2 L2 L2 L2 L2 L2
+          : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+          : "v"(a[8] & 0xff), "v"(a[9] & 0xff), "v"(t0), "s"(sel), "v"(a[12]), "v"(r0), "v"(r1) : "memory");
     } else if constexpr (MODE == 15 || MODE == 16 || MODE == 17) {
       // 56 v_xor with 8 loads interleaved (one per 7 xor): MODE 15 dword/lane coalesced, 16 dwordx4/lane, 17 no loads (8 more xor)
       const unsigned *gp = (const unsigned *)sink + 1024 + (threadIdx.x & 63) * (MODE == 16 ? 4 : 1);
@@ -142,17 +166,21 @@ template <int MODE>
 void run(const char *name, int ninstr, int threads) {
   unsigned long long *out; u32 *sink;
   CK(hipMalloc(&out, 8)); CK(hipMalloc(&sink, 1 << 20)); CK(hipMemset(sink, 0, 1 << 20));
-  const int iters = 2000;
+  const int iters = getenv("UB_ITERS") ? atoi(getenv("UB_ITERS")) : 2000;
   hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(threads), 65536, 0, out, sink, iters);
   CK(hipDeviceSynchronize());
   CK(hipMemset(out, 0, 8));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  CK(hipEventRecord(e0, 0));
   hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(threads), 65536, 0, out, sink, iters);
+  CK(hipEventRecord(e1, 0));
   CK(hipDeviceSynchronize());
+  float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
   unsigned long long c; CK(hipMemcpy(&c, out, 8, hipMemcpyDeviceToHost));
   const double per_body = (double)c / iters;
   const int wps = threads / 256;  // waves per SIMD
-  printf("%-34s waves/SIMD=%d  cycles/body=%8.1f  cycles/instr/wave=%6.2f  cycles/instr/SIMD=%6.2f\n", name, wps ? wps : 1,
-         per_body, per_body / ninstr, per_body / ninstr / (wps ? wps : 1));
+  printf("%-34s waves/SIMD=%d  cycles/body=%8.1f  cycles/instr/wave=%6.2f  cycles/instr/SIMD=%6.2f  clock~%.2f GHz\n", name, wps ? wps : 1,
+         per_body, per_body / ninstr, per_body / ninstr / (wps ? wps : 1), (double)c / (ms * 1e6));
 }
 
 int main() {
@@ -172,6 +200,11 @@ int main() {
     run<14>("12 lookups sdwa, wait/2 (78)", 78, threads);
     run<12>("12 lookups + 12 addtid (96)", 96, threads);
     run<13>("12 lookups + 12 addtid wait/2 (90)", 90, threads);
+    run<18>("64 v_bitop3_b32 (xor3)", 64, threads);
+    run<21>("16 ds_read_b128, 16 lanes per row", 16, threads);
+    run<19>("16 ds_read_b128, 8 lanes/row, halves", 16, threads);
+    run<20>("16 ds_read_b128, 8 lanes/row, same half", 16, threads);
+    run<22>("8 x (2 perm, 2 read, 4 xor3) + 8 waits", 72, threads);
     run<17>("64 v_xor (ref)", 64, threads);
     run<15>("56 v_xor + 8 global_load_dword", 64, threads);
     run<16>("56 v_xor + 2 global_load_dwordx4", 58, threads);
