@@ -883,6 +883,285 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v5(const gf2k_mul_
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// M4RM tile kernel v6: the paired lookups of v5 with ONE ROW PER LANE.  In v5 the eight lanes that share a row all fetch
+// the same word of A (32 buffer loads per wave and 32 bits of the inner dimension, a cache line of A touched 32 times);
+// here lane L of a wave owns rows {64 r + L} of the wave's 256 rows and walks the eight 16-byte column pieces of its row
+// itself, in the lane-dependent order piece = k ^ (L & 7) (static register indices: acc[r][k] simply holds piece
+// k ^ (L & 7), sorted out when C is stored).  The 16 lanes the LDS serves together then read 8 different pieces x 2
+// different halves of a pair-table row: conflict-free whatever their table entries are.  A is fetched as one 8-byte
+// load per row and 64 bits of the inner dimension (4 loads per wave instead of 64), double buffered in registers.
+// Same tile (2048 x 1024), pair tables, table build and wait accounting as v5.
+// The inner dimension is walked in blocks of 128 bits; the launcher makes slices start at even 32-bit words.
+// ---------------------------------------------------------------------------------------------
+template <int WAVES, int G, int DBG = 0>
+__global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v6(const gf2k_mul_args p) {
+  constexpr int RPW = 256, RG = 4;  // rows per wave, row groups of 64
+  constexpr int R = WAVES * RPW;
+  constexpr int STEPS = 32;         // (row group, piece) pairs per wave and chunk pair
+  constexpr int EPW = 256 / WAVES;
+  constexpr int LOWB = Log2<EPW>::value;
+  static_assert(EPW * WAVES == 256 && G <= STEPS && EPW <= STEPS, "geometry");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int t;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = t % p.tiles_m;
+  t /= p.tiles_m;
+  const int ks = t % p.ksplit;
+  t /= p.ksplit;
+  const int tn = t % p.tiles_n;
+  const int bt = t / p.tiles_n;
+  const u64 *__restrict__ A = p.A + (long long)bt * p.sA;
+  const u64 *__restrict__ B = p.B + (long long)bt * p.sB;
+  const bool part = p.P != nullptr && p.ksplit > 1;
+  u64 *__restrict__ C = part ? p.P + ((long long)bt * p.ksplit + ks) * p.sP : p.C + (long long)bt * p.sC;
+  const long long ldc = part ? p.ldp : p.ldc;
+  const bool accum = !part && p.accumulate;
+
+  const int row0 = tm * R, w0 = tn * kTileWords5;
+  const int widthB = (p.n + 63) >> 6;
+  const u64 maskC = (p.n & 63) ? ((1ull << (p.n & 63)) - 1) : ~0ull;
+  const int nw32 = (p.l + 31) >> 5;
+  const int jbeg = ks * p.kwords;  // even (launcher)
+  const int jend = min(nw32, jbeg + p.kwords);
+
+  const int l7 = lane & 7, h = (lane >> 3) & 1;
+  // lo[k]: byte 0 = offset of the first read inside a pair-table row, byte 1 = of the second read (other half),
+  // byte 2 = 0, byte 3 = 1 (pair table select)
+  u32 lo[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const u32 sa = (u32)((k ^ l7) * 16 + h * 128);
+    lo[k] = sa | ((sa ^ 128u) << 8) | 0x01000000u;
+  }
+  // selectors {0, table byte of lo, byte of the A word, offset byte of lo}; pp = pair inside the 32-bit word
+  const u32 sel0a = 0x0c020000u | ((4u + (u32)h) << 8) | 0u, sel0b = 0x0c020000u | ((5u - (u32)h) << 8) | 1u;
+  const u32 sel1a = 0x0c030000u | ((6u + (u32)h) << 8) | 0u, sel1b = 0x0c030000u | ((7u - (u32)h) << 8) | 1u;
+
+  u32 acc[STEPS][4];
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) acc[s][0] = acc[s][1] = acc[s][2] = acc[s][3] = 0;
+
+  // ---- A: 64 bits of row (64 r + lane) per load; rows past m read as zero (descriptor bound) ----
+  const u32 ldaB = (u32)p.lda * 8u;
+  const int rows_here = min(p.m - row0, R);
+  const __amdgpu_buffer_rsrc_t rsrcA =
+      __builtin_amdgcn_make_buffer_rsrc((void *)(A + (long long)row0 * p.lda), (short)0, (int)((u32)rows_here * ldaB), 0x00020000);
+  const u32 voffA0 = (u32)(wave * RPW + lane) * ldaB;
+  const u32 tailA = (p.l & 31) ? ((1u << (p.l & 31)) - 1u) : 0xffffffffu;
+  const int jlast = (nw32 - 1) & ~1;  // last 64-bit slab that exists
+  u32 awX[RG][2], awY[RG][2];
+  auto loadA = [&](u32 (&dst)[RG][2], int j) __attribute__((always_inline)) {  // slab of words j, j+1 (j even)
+    const int jl = min(j, jlast);
+    u32 vo = voffA0;
+    asm volatile("" : "+v"(vo));
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+      const u32x2v v = __builtin_amdgcn_raw_buffer_load_b64(rsrcA, vo, jl * 4, 0);
+      dst[r][0] = v.x;
+      dst[r][1] = v.y;
+      vo += 64u * ldaB;
+    }
+  };
+  // words outside [jbeg, jend) contribute nothing; the last word of the inner dimension loses its padding bits
+  auto maskA = [&](u32 (&dst)[RG][2], int j) __attribute__((always_inline)) {
+    const u32 m0 = j >= jend ? 0u : (j == nw32 - 1 ? tailA : 0xffffffffu);
+    const u32 m1 = j + 1 >= jend ? 0u : (j + 1 == nw32 - 1 ? tailA : 0xffffffffu);
+    if ((m0 & m1) != 0xffffffffu) {
+#pragma unroll
+      for (int r = 0; r < RG; ++r) {
+        dst[r][0] &= m0;
+        dst[r][1] &= m1;
+      }
+    }
+  };
+
+  // ---- B: lanes 0..31 hold dword `lane` of the 8 rows of the pair's even chunk, lanes 32..63 of its odd chunk ----
+  const u32 ldbB = (u32)p.ldb * 8u;
+  const int validB = min(128, (widthB - w0) * 8);
+  const u32 voffB = ((int)((lane & 31) * 4) < validB) ? (u32)(lane & 31) * 4u + (u32)(lane >> 5) * 8u * ldbB : 0x80000000u;
+  auto rsrcB_for = [&](int pr) __attribute__((always_inline)) {  // rows [16 pr, 16 pr + 16) of B, cut at l
+    const int rows = min(16, p.l - 16 * pr);
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(B + (long long)pr * 16 * p.ldb + w0), (short)0,
+                                             rows > 0 ? (int)((u32)rows * ldbB) : 0, 0x00020000);
+  };
+
+  u32 cur32 = 0;
+  auto build_begin = [&](const u32 (&rr)[8], u32 tbase) __attribute__((always_inline)) {
+    cur32 = 0;
+#pragma unroll
+    for (int b = LOWB; b < 8; ++b)
+      if ((wave >> (b - LOWB)) & 1) cur32 ^= rr[b];
+    const u32 kOff = tbase ? (0x10004u - (u32)(EPW * 256)) : 0u;  // see gf2_m4rm_kernel_v3
+    const u32 m0v = tbase + (u32)wave * (u32)(EPW * 256) - kOff;
+    asm volatile("s_mov_b32 m0, %0" ::"s"(m0v) : "memory");
+  };
+  auto build_write = [&cur32](auto itag, auto ttag) __attribute__((always_inline)) {
+    constexpr int i = decltype(itag)::value;
+    constexpr u32 tbase = decltype(ttag)::value;
+    constexpr unsigned e = (unsigned)i ^ ((unsigned)i >> 1);
+    constexpr u32 kOff = tbase ? (0x10004u - (u32)(EPW * 256)) : 0u;
+    asm volatile("ds_write_addtid_b32 %0 offset:%1" ::"v"(cur32), "n"(kOff + e * 256u) : "memory");
+  };
+
+  // ---- prologue ----
+  u32 rrA[8], rrB[8];
+  {
+    const __amdgpu_buffer_rsrc_t rs0 = rsrcB_for(2 * jbeg), rs1 = rsrcB_for(2 * jbeg + 1);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      rrA[b] = __builtin_amdgcn_raw_buffer_load_b32(rs0, voffB + (u32)b * ldbB, 0, 0);
+      rrB[b] = __builtin_amdgcn_raw_buffer_load_b32(rs1, voffB + (u32)b * ldbB, 0, 0);
+    }
+  }
+  loadA(awX, jbeg);
+  maskA(awX, jbeg);
+  build_begin(rrA, 0u);
+  static_for<EPW>([&](auto it) __attribute__((always_inline)) {
+    constexpr int i = decltype(it)::value;
+    if constexpr (i > 0) cur32 ^= rrA[__builtin_ctz(i | 256)];
+    build_write(it, std::integral_constant<u32, 0u>{});
+  });
+  __syncthreads();
+
+  // one pair: look pair `pr` (word W of the slab in `aw`, pair PP of the word) up; build pair pr+1 from `rows` into the
+  // other table; fetch the rows of pair pr+2 into `next`; the first pair of a slab also fetches the next slab of A
+  auto pair_iter = [&](int pr, auto wtag, auto pptag, const u32 (&aw)[RG][2], u32 (&awn)[RG][2], const u32 (&rows)[8],
+                       u32 (&next)[8]) __attribute__((always_inline)) {
+    constexpr int PP = decltype(pptag)::value, W = decltype(wtag)::value;
+    const u32 sela = PP ? sel1a : sel0a, selb = PP ? sel1b : sel0b;
+    u32 lk[8];  // (copied: an asm operand of the nested lambda does not capture the enclosing function's array)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) lk[k] = lo[k];
+    using tnext = std::integral_constant<u32, PP ? 0u : (u32)kTableBytes>;
+    build_begin(rows, tnext::value);
+    const __amdgpu_buffer_rsrc_t rsN = rsrcB_for(pr + 2);
+    const int jnext = min((pr >> 2) * 2 + 2, jlast);  // next slab, clamped: never past the end of a row
+    u32 voA = voffA0;
+    asm volatile("" : "+v"(voA));
+    u32x4 ta[G], tb[G];
+    auto issue = [&](int st, u32x4 &da, u32x4 &db) __attribute__((always_inline)) {
+      u32 a0, a1;
+      asm volatile("v_perm_b32 %2, %4, %5, %6\n\tds_read_b128 %0, %2\n\tv_perm_b32 %3, %4, %5, %7\n\tds_read_b128 %1, %3"
+                   : "=&v"(da), "=&v"(db), "=&v"(a0), "=&v"(a1)
+                   : "v"(aw[st >> 3][W]), "v"(lk[st & 7]), "v"(sela), "v"(selb)
+                   : "memory");
+    };
+    if constexpr (DBG != 5) {
+#pragma unroll
+      for (int k = 0; k < G; ++k) issue(k, ta[k], tb[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < G; ++k) ta[k] = tb[k] = u32x4{aw[0][W], aw[1][W], aw[2][W], aw[3][W]};
+    }
+    static_for<STEPS>([&](auto stag) __attribute__((always_inline)) {
+      constexpr int st = decltype(stag)::value;
+      if constexpr (DBG == 5) {
+      } else if constexpr (st % 2 == 0 || st + 1 >= STEPS) {
+        constexpr int sw = (st % 2 == 0 && st + 1 < STEPS) ? st + 1 : st;
+        constexpr int N = v5_wait_count(st, sw, G, STEPS);
+        if constexpr (sw != st)
+          asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(ta[st % G]), "+v"(tb[st % G]), "+v"(ta[sw % G]), "+v"(tb[sw % G]) : "n"(N) : "memory");
+        else
+          asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(ta[st % G]), "+v"(tb[st % G]) : "n"(N) : "memory");
+      }
+      if constexpr (st < EPW && st > 0) cur32 ^= rows[__builtin_ctz(st | 256)];
+      if constexpr (DBG != 5 && DBG != 6) {
+        asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[st][0]) : "v"(ta[st % G].x), "v"(tb[st % G].x));
+        asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[st][1]) : "v"(ta[st % G].y), "v"(tb[st % G].y));
+        asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[st][2]) : "v"(ta[st % G].z), "v"(tb[st % G].z));
+        asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[st][3]) : "v"(ta[st % G].w), "v"(tb[st % G].w));
+      } else if constexpr (DBG == 6) {
+        asm volatile("" ::"v"(ta[st % G]), "v"(tb[st % G]));
+      }
+      if constexpr (st + G < STEPS && DBG != 5) issue(st + G, ta[st % G], tb[st % G]);
+      if constexpr (st < EPW && DBG != 4) build_write(std::integral_constant<int, st>{}, tnext{});
+      if constexpr (DBG == 3) {
+      } else if constexpr (st < 8) {
+        next[st] = __builtin_amdgcn_raw_buffer_load_b32(rsN, voffB + (u32)st * ldbB, 0, 0);
+      } else if constexpr (W == 0 && PP == 0 && st >= 8 && st < 8 + RG) {  // next slab of A into the other buffer
+        const u32x2v v = __builtin_amdgcn_raw_buffer_load_b64(rsrcA, voA, jnext * 4, 0);
+        awn[st - 8][0] = v.x;
+        awn[st - 8][1] = v.y;
+        voA += 64u * ldaB;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if constexpr (DBG != 2) __syncthreads();
+  };
+  auto slab_iter = [&](int j, const u32 (&aw)[RG][2], u32 (&awn)[RG][2]) __attribute__((always_inline)) {
+    pair_iter(2 * j + 0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, aw, awn, rrB, rrA);
+    pair_iter(2 * j + 1, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, aw, awn, rrA, rrB);
+    pair_iter(2 * j + 2, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, aw, awn, rrB, rrA);
+    pair_iter(2 * j + 3, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, aw, awn, rrA, rrB);
+    maskA(awn, j + 2);
+  };
+
+#pragma unroll 1
+  for (int j = jbeg; j < jend; j += 4) {  // 128 bits of the inner dimension: slab X, then slab Y (all zero if past the slice)
+    slab_iter(j, awX, awY);
+    slab_iter(j + 2, awY, awX);
+  }
+
+  // ---- epilogue: a lane holds whole rows, so direct stores would be 64 scattered 16-byte pieces per instruction.  The
+  // tables are dead now (the last pair ended with a barrier): every wave transposes its rows through its own 16 KiB of
+  // LDS, 128 rows at a time, and stores them with 8 lanes per row (128 contiguous bytes). ----
+  {
+    typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+    const u32 wbase = (u32)wave * 16384u;
+    const int prow = lane >> 3, pq = lane & 7;
+    const int wc = w0 + 2 * pq;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int s = (2 * half + rr) * 8 + k;
+          const u32 off = wbase + (u32)(rr * 64 + lane) * 128u + (u32)((k ^ l7) * 16);
+          *reinterpret_cast<lds_u32x4 *>(off) = u32x4{acc[s][0], acc[s][1], acc[s][2], acc[s][3]};
+        }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const u32x4 v = *reinterpret_cast<lds_cu32x4 *>(wbase + (u32)i * 1024u + (u32)lane * 16u);
+        const int row = row0 + wave * RPW + half * 128 + i * 8 + prow;
+        if (row < p.m && wc < widthB) {
+          u64 *dst = C + (long long)row * ldc + wc;
+          u64 v0 = (u64)v.x | ((u64)v.y << 32);
+          u64 v1 = (u64)v.z | ((u64)v.w << 32);
+          if (wc == widthB - 1) v0 &= maskC;
+          if (wc + 1 == widthB - 1) v1 &= maskC;
+          if (p.ksplit > 1 && !part) {
+            if (v0) atomicXor(reinterpret_cast<unsigned long long *>(dst), (unsigned long long)v0);
+            if (wc + 1 < widthB && v1) atomicXor(reinterpret_cast<unsigned long long *>(dst + 1), (unsigned long long)v1);
+          } else if (wc + 1 < widthB) {
+            if (accum) {
+              const uint4 old = *reinterpret_cast<const uint4 *>(dst);
+              v0 ^= (u64)old.x | ((u64)old.y << 32);
+              v1 ^= (u64)old.z | ((u64)old.w << 32);
+            }
+            *reinterpret_cast<uint4 *>(dst) = make_uint4((u32)v0, (u32)(v0 >> 32), (u32)v1, (u32)(v1 >> 32));
+          } else {
+            if (accum) v0 ^= dst[0];
+            dst[0] = v0;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
 // C (+)= XOR of the ksplit partial products of a split-K launch (dense, row stride ldp, 16-byte accesses; ldp even)
 __global__ __launch_bounds__(256) void gf2_splitk_reduce_kernel(u64 *__restrict__ C, long long ldc, long long sC,
                                                                 const u64 *__restrict__ P, long long ldp, long long sP,
@@ -1719,6 +1998,7 @@ extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {
   if (cfg == 0 || cfg == 1 || a.ksplit < 1) a.ksplit = 1;  // first-generation kernels have no split-K
   if (a.ksplit > nw32) a.ksplit = nw32 > 0 ? nw32 : 1;
   a.kwords = (nw32 + a.ksplit - 1) / a.ksplit;
+  if (cfg == 8 || (cfg > 80 && cfg < 90)) a.kwords = (a.kwords + 1) & ~1;  // v6 reads A in 64-bit slabs: slices start at even words
   a.ksplit = a.kwords > 0 ? (nw32 + a.kwords - 1) / a.kwords : 1;  // no empty slices
   if (a.ksplit <= 1 || cfg == 0 || cfg == 1 || (a.ldp & 1)) a.P = nullptr;
   if (a.ksplit > 1 && !a.accumulate && !a.P) {  // slices are combined with atomic XOR: start from zero
@@ -1735,13 +2015,14 @@ extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {
     case 1: e = launch_tile_kernel(&gf2_m4rm_kernel<4, 64>, 256, a, nwg, stream); break;
     case 7: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4>, 512, a, nwg, stream); break;
     case 20: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<4, 64, 4>, 256, a, nwg, stream); break;
-    case 8: e = launch_tile_kernel(&gf2_m4rm_kernel_v5<8, 256, 4>, 512, a, nwg, stream); break;  // paired chunks, 2048 x 1024 tile
-    case 80: e = launch_tile_kernel(&gf2_m4rm_kernel_v5<8, 256, 6>, 512, a, nwg, stream); break;
-    case 81: e = launch_tile_kernel(&gf2_m4rm_kernel_v5<8, 256, 4, 2>, 512, a, nwg, stream); break;  // timing-only ablations
-    case 82: e = launch_tile_kernel(&gf2_m4rm_kernel_v5<8, 256, 4, 3>, 512, a, nwg, stream); break;
-    case 83: e = launch_tile_kernel(&gf2_m4rm_kernel_v5<8, 256, 4, 4>, 512, a, nwg, stream); break;
-    case 84: e = launch_tile_kernel(&gf2_m4rm_kernel_v5<8, 256, 4, 5>, 512, a, nwg, stream); break;
-    case 85: e = launch_tile_kernel(&gf2_m4rm_kernel_v5<8, 256, 4, 6>, 512, a, nwg, stream); break;
+    case 8: e = launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 4>, 512, a, nwg, stream); break;  // paired chunks, one row per lane
+    case 80: e = launch_tile_kernel(&gf2_m4rm_kernel_v5<8, 256, 4>, 512, a, nwg, stream); break;  // paired chunks, 8 lanes per row
+    case 81: e = launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 6>, 512, a, nwg, stream); break;
+    case 82: e = launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 3>, 512, a, nwg, stream); break;
+    case 86: e = launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 4, 2>, 512, a, nwg, stream); break;  // timing only: no barriers
+    case 87: e = launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 4, 3>, 512, a, nwg, stream); break;  // timing only: no loads in the loop
+    case 88: e = launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 4, 4>, 512, a, nwg, stream); break;  // timing only: no table writes
+    case 89: e = launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 4, 6>, 512, a, nwg, stream); break;  // timing only: no XORs
     case 50: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 0, 0, 1>, 512, a, nwg, stream); break;  // packed B
     case 40: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 2>, 512, a, nwg, stream); break;  // no barriers (timing only)
     case 41: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 3>, 512, a, nwg, stream); break;  // no loads in the loop

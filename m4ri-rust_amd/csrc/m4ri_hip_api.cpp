@@ -352,7 +352,7 @@ static int env_int(const char *name, int dflt) {
 }
 
 // ---- launch geometry of the tile kernel (shared by the launcher and the level chooser) ----
-// kernel variants (gf2_kernels.hip): 8 = v5 2048 x 1024 tile, two chunks per lookup step (8 waves); 7 = v3 1024 x 2048 tile
+// kernel variants (gf2_kernels.hip): 8 = v6 2048 x 1024 tile, two chunks per lookup step, one row per lane (8 waves); 7 = v3 1024 x 2048 tile
 // (8 waves); 20 = v3 256 x 2048 tile (4 waves).  M4RI_HIP_M4RM_CFG overrides (0/1 = first-generation kernels, kept for
 // A/B runs)
 struct TileGeom {
@@ -360,7 +360,7 @@ struct TileGeom {
   double cyc_per_chunk;  // measured cycles per 8 bits of the inner dimension and tile, 2.4 GHz
 };
 static TileGeom tile_geom(int cfg) {
-  if (cfg == 8 || (cfg >= 80 && cfg < 90)) return {2048, 1024, 2110.0};
+  if (cfg == 8 || (cfg >= 80 && cfg < 90)) return {2048, 1024, 1790.0};
   if (cfg == 20 || cfg == 1) return {256, 2048, 1300.0};
   return {1024, 2048, 2350.0};
 }
@@ -373,7 +373,7 @@ static int m4rm_cfg_for(int m, int n, int batch) {
   static const int forced = env_int("M4RI_HIP_M4RM_CFG", -1);
   if (forced >= 0) return forced;
   if (m <= 256) return 20;
-  // same tile area, the paired kernel is ~10 % faster per tile: it wins unless its tall tiles leave more of the grid empty
+  // same tile area, the paired kernel is ~30 % faster per tile: it wins unless its tall tiles leave more of the grid empty
   const TileGeom g8 = tile_geom(8), g7 = tile_geom(7);
   return (double)tiles_of(g8, m, n) * g8.cyc_per_chunk <= (double)tiles_of(g7, m, n) * g7.cyc_per_chunk ? 8 : 7;
 }
