@@ -23,6 +23,8 @@ struct gf2k_mul_args {
   // row stride ldp) and gf2k_m4rm combines the slices into C with a second kernel; nullptr: atomic XOR into C
   uint64_t *P;
   long long ldp, sP;
+  // A is stored row-group packed (gf2k_strassen_split2 with side 2): u64 index ((r / 64) * lda + c) * 64 + r % 64; m % 64 == 0
+  int a_packed;
 };
 
 // Device-side record of a blocked elimination (gf2_elim.hip): the kernels of a step read their ranges from it, so a
@@ -62,6 +64,7 @@ hipError_t gf2k_scatter_rows(uint64_t *X, long long ldx, const uint64_t *R, long
                              int rank, hipStream_t s);
 hipError_t gf2k_any_nonzero(const uint64_t *M, long long ld, int row_lo, int rows, int words, int *flag, hipStream_t s);
 int gf2k_m4rm_rows_per_tile(int cfg);
+int gf2k_m4rm_cols_per_tile(int cfg);
 hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream);
 hipError_t gf2k_dbg_sec(unsigned long long *out8);
 int gf2k_packB_chunks(int l);

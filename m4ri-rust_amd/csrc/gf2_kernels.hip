@@ -894,7 +894,8 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v5(const gf2k_mul_
 // Same tile (2048 x 1024), pair tables, table build and wait accounting as v5.
 // The inner dimension is walked in blocks of 128 bits; the launcher makes slices start at even 32-bit words.
 // ---------------------------------------------------------------------------------------------
-template <int WAVES, int G, int DBG = 0>
+// APACK: A is given in the row-group-packed layout written by gf2_strassen_split2_kernel (side 2): m % 64 == 0
+template <int WAVES, int G, int DBG = 0, int APACK = 0>
 __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v6(const gf2k_mul_args p) {
   constexpr int RPW = 256, RG = 4;  // rows per wave, row groups of 64
   constexpr int R = WAVES * RPW;
@@ -951,9 +952,12 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v6(const gf2k_mul_
   // ---- A: 64 bits of row (64 r + lane) per load; rows past m read as zero (descriptor bound) ----
   const u32 ldaB = (u32)p.lda * 8u;
   const int rows_here = min(p.m - row0, R);
+  // packed: group g of 64 rows starts at byte g * 64 * ldaB, lane = row inside the group, 512 bytes per 64-bit column
   const __amdgpu_buffer_rsrc_t rsrcA =
-      __builtin_amdgcn_make_buffer_rsrc((void *)(A + (long long)row0 * p.lda), (short)0, (int)((u32)rows_here * ldaB), 0x00020000);
-  const u32 voffA0 = (u32)(wave * RPW + lane) * ldaB;
+      APACK ? __builtin_amdgcn_make_buffer_rsrc((void *)A, (short)0, (int)((u32)p.m * ldaB), 0x00020000)
+            : __builtin_amdgcn_make_buffer_rsrc((void *)(A + (long long)row0 * p.lda), (short)0, (int)((u32)rows_here * ldaB), 0x00020000);
+  const u32 voffA0 = APACK ? (u32)(row0 + wave * RPW) * ldaB + (u32)lane * 8u : (u32)(wave * RPW + lane) * ldaB;
+  constexpr int kAColB = APACK ? 256 : 4;  // bytes per 32-bit column index in the scalar offset (packed: 512 per 64-bit slab)
   const u32 tailA = (p.l & 31) ? ((1u << (p.l & 31)) - 1u) : 0xffffffffu;
   const int jlast = (nw32 - 1) & ~1;  // last 64-bit slab that exists
   u32 awX[RG][2], awY[RG][2];
@@ -963,7 +967,7 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v6(const gf2k_mul_
     asm volatile("" : "+v"(vo));
 #pragma unroll
     for (int r = 0; r < RG; ++r) {
-      const u32x2v v = __builtin_amdgcn_raw_buffer_load_b64(rsrcA, vo, jl * 4, 0);
+      const u32x2v v = __builtin_amdgcn_raw_buffer_load_b64(rsrcA, vo, jl * kAColB, 0);
       dst[r][0] = v.x;
       dst[r][1] = v.y;
       vo += 64u * ldaB;
@@ -1084,9 +1088,9 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v6(const gf2k_mul_
       if constexpr (st < EPW && DBG != 4) build_write(std::integral_constant<int, st>{}, tnext{});
       if constexpr (DBG == 3) {
       } else if constexpr (st < 8) {
-        next[st] = __builtin_amdgcn_raw_buffer_load_b32(rsN, voffB + (u32)st * ldbB, 0, 0);
-      } else if constexpr (W == 0 && PP == 0 && st >= 8 && st < 8 + RG) {  // next slab of A into the other buffer
-        const u32x2v v = __builtin_amdgcn_raw_buffer_load_b64(rsrcA, voA, jnext * 4, 0);
+        if constexpr (DBG != 8) next[st] = __builtin_amdgcn_raw_buffer_load_b32(rsN, voffB + (u32)st * ldbB, 0, 0);
+      } else if constexpr (W == 0 && PP == 0 && st >= 8 && st < 8 + RG && DBG != 7) {  // next slab of A into the other buffer
+        const u32x2v v = __builtin_amdgcn_raw_buffer_load_b64(rsrcA, DBG == 9 ? (u32)(wave * RPW + (st - 8) * 64) * ldaB + (u32)lane * 8u : voA, jnext * kAColB, 0);
         awn[st - 8][0] = v.x;
         awn[st - 8][1] = v.y;
         voA += 64u * ldaB;
@@ -1134,6 +1138,296 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v6(const gf2k_mul_
       for (int i = 0; i < 16; ++i) {
         const u32x4 v = *reinterpret_cast<lds_cu32x4 *>(wbase + (u32)i * 1024u + (u32)lane * 16u);
         const int row = row0 + wave * RPW + half * 128 + i * 8 + prow;
+        if (row < p.m && wc < widthB) {
+          u64 *dst = C + (long long)row * ldc + wc;
+          u64 v0 = (u64)v.x | ((u64)v.y << 32);
+          u64 v1 = (u64)v.z | ((u64)v.w << 32);
+          if (wc == widthB - 1) v0 &= maskC;
+          if (wc + 1 == widthB - 1) v1 &= maskC;
+          if (p.ksplit > 1 && !part) {
+            if (v0) atomicXor(reinterpret_cast<unsigned long long *>(dst), (unsigned long long)v0);
+            if (wc + 1 < widthB && v1) atomicXor(reinterpret_cast<unsigned long long *>(dst + 1), (unsigned long long)v1);
+          } else if (wc + 1 < widthB) {
+            if (accum) {
+              const uint4 old = *reinterpret_cast<const uint4 *>(dst);
+              v0 ^= (u64)old.x | ((u64)old.y << 32);
+              v1 ^= (u64)old.z | ((u64)old.w << 32);
+            }
+            *reinterpret_cast<uint4 *>(dst) = make_uint4((u32)v0, (u32)(v0 >> 32), (u32)v1, (u32)(v1 >> 32));
+          } else {
+            if (accum) v0 ^= dst[0];
+            dst[0] = v0;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// M4RM tile kernel v7: FOUR chunks (one 32-bit word of the inner dimension) per table generation, tile of 4096 rows x 512
+// columns.  Same work per lookup as v6 (one v_perm_b32, one ds_read_b128, two v_bitop3_b32 per 16 bytes), but a table row
+// (one ds_write_addtid_b32: 4 chunks x 64 bytes) and a fetched row of B now serve 4096 rows of A instead of 2048: half
+// the table writes, half the B loads and half the barriers per unit of work.
+// A 256-byte LDS row holds entry e of the four chunks' tables side by side (16 slots of 16 bytes: slot = 4 chunk + piece).
+// Lane L owns rows {64 r + L}, r < 8, of its wave's 512 rows; in step (r, k) it reads, for c = 0..3, slot
+// 4 (c ^ cl) + (k ^ l3) with cl = (L >> 2) & 3, l3 = L & 3: the 16 lanes served together hit 16 different slots, acc[r][k]
+// holds piece k ^ l3 of the row's 64 bytes, and the four reads of a step belong to four different chunks (byte c ^ cl of
+// the A word selects the entry).
+// ---------------------------------------------------------------------------------------------
+constexpr int v7_wait_count(int st_wait, int target, int G, int STEPS, int RPS) {
+  int after = 0;
+  bool seen = false;
+  for (int k = 0; k < G && k < STEPS; ++k) {
+    if (seen) after += RPS;
+    if (k == target) seen = true;
+  }
+  for (int s = 0; s < st_wait; ++s) {
+    if (s + G < STEPS) {
+      if (seen) after += RPS;
+      if (s + G == target) seen = true;
+    }
+    if (seen) after += 1;
+  }
+  return after > 15 ? 15 : after;
+}
+
+static constexpr int kTileWords7 = 8;  // 512 columns per tile
+
+template <int WAVES, int G, int DBG = 0>
+__global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v7(const gf2k_mul_args p) {
+  constexpr int RPW = 512, RG = 8;
+  constexpr int R = WAVES * RPW;
+  constexpr int STEPS = 32;  // (row group, piece)
+  constexpr int EPW = 256 / WAVES;
+  constexpr int LOWB = Log2<EPW>::value;
+  static_assert(EPW * WAVES == 256 && G <= STEPS && EPW <= STEPS, "geometry");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int t;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = t % p.tiles_m;
+  t /= p.tiles_m;
+  const int ks = t % p.ksplit;
+  t /= p.ksplit;
+  const int tn = t % p.tiles_n;
+  const int bt = t / p.tiles_n;
+  const u64 *__restrict__ A = p.A + (long long)bt * p.sA;
+  const u64 *__restrict__ B = p.B + (long long)bt * p.sB;
+  const bool part = p.P != nullptr && p.ksplit > 1;
+  u64 *__restrict__ C = part ? p.P + ((long long)bt * p.ksplit + ks) * p.sP : p.C + (long long)bt * p.sC;
+  const long long ldc = part ? p.ldp : p.ldc;
+  const bool accum = !part && p.accumulate;
+
+  const int row0 = tm * R, w0 = tn * kTileWords7;
+  const int widthB = (p.n + 63) >> 6;
+  const u64 maskC = (p.n & 63) ? ((1ull << (p.n & 63)) - 1) : ~0ull;
+  const int nw32 = (p.l + 31) >> 5;
+  const int jbeg = ks * p.kwords;  // even (launcher)
+  const int jend = min(nw32, jbeg + p.kwords);
+
+  const int l3 = lane & 3, cl = (lane >> 2) & 3;
+  // lo[c >> 1][k]: byte 0 = slot offset of read c even, byte 1 = of read c odd, byte 2 = 0, byte 3 = 1 (table select)
+  u32 lo[2][4];
+#pragma unroll
+  for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const u32 s0 = (u32)((((2 * c2) ^ cl) * 4 + (k ^ l3)) * 16), s1 = (u32)((((2 * c2 + 1) ^ cl) * 4 + (k ^ l3)) * 16);
+      lo[c2][k] = s0 | (s1 << 8) | 0x01000000u;
+    }
+  // sel[W][c] = {0, table byte of lo (2 + W), byte c ^ cl of the A word, slot byte c & 1 of lo}
+  u32 sel[2][4];
+#pragma unroll
+  for (int w = 0; w < 2; ++w)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sel[w][c] = 0x0c000000u | ((2u + (u32)w) << 16) | ((4u + (u32)(c ^ cl)) << 8) | (u32)(c & 1);
+
+  u32 acc[STEPS][4];
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) acc[s][0] = acc[s][1] = acc[s][2] = acc[s][3] = 0;
+
+  // ---- A: 64 bits of row (64 r + lane) per load, reloaded in place; rows past m read as zero (descriptor bound) ----
+  const u32 ldaB = (u32)p.lda * 8u;
+  const int rows_here = min(p.m - row0, R);
+  const __amdgpu_buffer_rsrc_t rsrcA =
+      __builtin_amdgcn_make_buffer_rsrc((void *)(A + (long long)row0 * p.lda), (short)0, (int)((u32)rows_here * ldaB), 0x00020000);
+  const u32 voffA0 = (u32)(wave * RPW + lane) * ldaB;
+  const u32 tailA = (p.l & 31) ? ((1u << (p.l & 31)) - 1u) : 0xffffffffu;
+  const int jlast = (nw32 - 1) & ~1;
+  u32 aw[RG][2];
+  auto maskA = [&](int j) __attribute__((always_inline)) {  // slab of words j, j+1 just loaded
+    const u32 m0 = j >= jend ? 0u : (j == nw32 - 1 ? tailA : 0xffffffffu);
+    const u32 m1 = j + 1 >= jend ? 0u : (j + 1 == nw32 - 1 ? tailA : 0xffffffffu);
+    if ((m0 & m1) != 0xffffffffu) {
+#pragma unroll
+      for (int r = 0; r < RG; ++r) {
+        aw[r][0] &= m0;
+        aw[r][1] &= m1;
+      }
+    }
+  };
+
+  // ---- B: lane L holds dword L & 15 of the 8 rows of chunk L >> 4 of the quad ----
+  const u32 ldbB = (u32)p.ldb * 8u;
+  const int validB = min(64, (widthB - w0) * 8);
+  const u32 voffB = ((int)((lane & 15) * 4) < validB) ? (u32)(lane & 15) * 4u + (u32)(lane >> 4) * 8u * ldbB : 0x80000000u;
+  auto rsrcB_for = [&](int q) __attribute__((always_inline)) {  // rows [32 q, 32 q + 32) of B, cut at l
+    const int rows = min(32, p.l - 32 * q);
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(B + (long long)q * 32 * p.ldb + w0), (short)0,
+                                             rows > 0 ? (int)((u32)rows * ldbB) : 0, 0x00020000);
+  };
+
+  u32 cur32 = 0;
+  auto build_begin = [&](const u32 (&rr)[8], u32 tbase) __attribute__((always_inline)) {
+    cur32 = 0;
+#pragma unroll
+    for (int b = LOWB; b < 8; ++b)
+      if ((wave >> (b - LOWB)) & 1) cur32 ^= rr[b];
+    const u32 kOff = tbase ? (0x10004u - (u32)(EPW * 256)) : 0u;  // see gf2_m4rm_kernel_v3
+    const u32 m0v = tbase + (u32)wave * (u32)(EPW * 256) - kOff;
+    asm volatile("s_mov_b32 m0, %0" ::"s"(m0v) : "memory");
+  };
+  auto build_write = [&cur32](auto itag, auto ttag) __attribute__((always_inline)) {
+    constexpr int i = decltype(itag)::value;
+    constexpr u32 tbase = decltype(ttag)::value;
+    constexpr unsigned e = (unsigned)i ^ ((unsigned)i >> 1);
+    constexpr u32 kOff = tbase ? (0x10004u - (u32)(EPW * 256)) : 0u;
+    asm volatile("ds_write_addtid_b32 %0 offset:%1" ::"v"(cur32), "n"(kOff + e * 256u) : "memory");
+  };
+
+  // ---- prologue ----
+  u32 rrA[8], rrB[8];
+  {
+    const __amdgpu_buffer_rsrc_t rs0 = rsrcB_for(jbeg), rs1 = rsrcB_for(jbeg + 1);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      rrA[b] = __builtin_amdgcn_raw_buffer_load_b32(rs0, voffB + (u32)b * ldbB, 0, 0);
+      rrB[b] = __builtin_amdgcn_raw_buffer_load_b32(rs1, voffB + (u32)b * ldbB, 0, 0);
+    }
+  }
+  {
+    const int jl = min(jbeg, jlast);
+    u32 vo = voffA0;
+    asm volatile("" : "+v"(vo));
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+      const u32x2v v = __builtin_amdgcn_raw_buffer_load_b64(rsrcA, vo, jl * 4, 0);
+      aw[r][0] = v.x;
+      aw[r][1] = v.y;
+      vo += 64u * ldaB;
+    }
+  }
+  maskA(jbeg);
+  build_begin(rrA, 0u);
+  static_for<EPW>([&](auto it) __attribute__((always_inline)) {
+    constexpr int i = decltype(it)::value;
+    if constexpr (i > 0) cur32 ^= rrA[__builtin_ctz(i | 256)];
+    build_write(it, std::integral_constant<u32, 0u>{});
+  });
+  __syncthreads();
+
+  // one quad: look word W of the slab (quad q) up in table W; build quad q+1 from `rows` into the other table; fetch the
+  // rows of quad q+2 into `next`; the second quad of a slab reloads each row group's slab of A after its last use
+  auto quad_iter = [&](int q, auto wtag, u32 (&awp)[RG][2], const u32 (&rows)[8], u32 (&next)[8]) __attribute__((always_inline)) {
+    constexpr int W = decltype(wtag)::value;
+    u32 lk[2][4], sk[4];  // (copied: an asm operand of the nested lambda does not capture the enclosing function's arrays)
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) lk[c2][k] = lo[c2][k];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sk[c] = sel[W][c];
+    using tnext = std::integral_constant<u32, W ? 0u : (u32)kTableBytes>;
+    build_begin(rows, tnext::value);
+    const __amdgpu_buffer_rsrc_t rsN = rsrcB_for(q + 2);
+    const int jnext = min((q & ~1) + 2, jlast);  // next slab, clamped: never past the end of a row
+    u32 voA = voffA0;
+    asm volatile("" : "+v"(voA));
+    u32x4 t0[G], t1[G], t2[G], t3[G];
+    auto issue = [&](int st, u32x4 &d0, u32x4 &d1, u32x4 &d2, u32x4 &d3) __attribute__((always_inline)) {
+      u32 a0, a1;
+      asm volatile("v_perm_b32 %4, %6, %7, %9\n\tds_read_b128 %0, %4\n\tv_perm_b32 %5, %6, %7, %10\n\tds_read_b128 %1, %5\n\t"
+                   "v_perm_b32 %4, %6, %8, %11\n\tds_read_b128 %2, %4\n\tv_perm_b32 %5, %6, %8, %12\n\tds_read_b128 %3, %5"
+                   : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(a0), "=&v"(a1)
+                   : "v"(awp[st >> 2][W]), "v"(lk[0][st & 3]), "v"(lk[1][st & 3]), "v"(sk[0]), "v"(sk[1]), "v"(sk[2]), "v"(sk[3])
+                   : "memory");
+    };
+    if constexpr (DBG != 5) {
+#pragma unroll
+      for (int k = 0; k < G; ++k) issue(k, t0[k], t1[k], t2[k], t3[k]);
+    }
+    static_for<STEPS>([&](auto stag) __attribute__((always_inline)) {
+      constexpr int st = decltype(stag)::value;
+      constexpr int N = v7_wait_count(st, st, G, STEPS, 4);
+      if constexpr (DBG != 5)
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(t0[st % G]), "+v"(t1[st % G]), "+v"(t2[st % G]), "+v"(t3[st % G]) : "n"(N) : "memory");
+      if constexpr (st < EPW && st > 0) cur32 ^= rows[__builtin_ctz(st | 256)];
+      if constexpr (DBG != 5 && DBG != 6) {
+        asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[st][0]) : "v"(t0[st % G].x), "v"(t1[st % G].x));
+        asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[st][1]) : "v"(t0[st % G].y), "v"(t1[st % G].y));
+        asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[st][2]) : "v"(t0[st % G].z), "v"(t1[st % G].z));
+        asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[st][3]) : "v"(t0[st % G].w), "v"(t1[st % G].w));
+        asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[st][0]) : "v"(t2[st % G].x), "v"(t3[st % G].x));
+        asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[st][1]) : "v"(t2[st % G].y), "v"(t3[st % G].y));
+        asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[st][2]) : "v"(t2[st % G].z), "v"(t3[st % G].z));
+        asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[st][3]) : "v"(t2[st % G].w), "v"(t3[st % G].w));
+      }
+      if constexpr (st + G < STEPS && DBG != 5) issue(st + G, t0[st % G], t1[st % G], t2[st % G], t3[st % G]);
+      if constexpr (st < EPW && DBG != 4) build_write(std::integral_constant<int, st>{}, tnext{});
+      if constexpr (DBG == 3) {
+      } else {
+        if constexpr (st < 8) next[st] = __builtin_amdgcn_raw_buffer_load_b32(rsN, voffB + (u32)st * ldbB, 0, 0);
+        // the reads of step st + G (issued above) are the last users of row group (st + G) >> 2 when (st + G) & 3 == 3
+        if constexpr (W == 1 && ((st + G) & 3) == 3 && st + G < STEPS) {
+          constexpr int r = (st + G) >> 2;
+          const u32x2v v = __builtin_amdgcn_raw_buffer_load_b64(rsrcA, voA + (u32)r * 64u * ldaB, jnext * 4, 0);
+          awp[r][0] = v.x;
+          awp[r][1] = v.y;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if constexpr (W == 1) maskA((q & ~1) + 2);
+    if constexpr (DBG != 2) __syncthreads();
+  };
+
+#pragma unroll 1
+  for (int j = jbeg; j < jend; j += 2) {
+    quad_iter(j, std::integral_constant<int, 0>{}, aw, rrB, rrA);
+    quad_iter(j + 1, std::integral_constant<int, 1>{}, aw, rrA, rrB);
+  }
+
+  // ---- epilogue: transpose through LDS (tables are dead), 128 rows x 64 bytes per wave at a time, 4 lanes per row ----
+  {
+    typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+    const u32 wbase = (u32)wave * 8192u;
+    const int prow = lane >> 2, pq = lane & 3;
+    const int wc = w0 + 2 * pq;
+#pragma unroll
+    for (int quarter = 0; quarter < 4; ++quarter) {
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int s = (2 * quarter + rr) * 4 + k;
+          const u32 off = wbase + (u32)(rr * 64 + lane) * 64u + (u32)((k ^ l3) * 16);
+          *reinterpret_cast<lds_u32x4 *>(off) = u32x4{acc[s][0], acc[s][1], acc[s][2], acc[s][3]};
+        }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const u32x4 v = *reinterpret_cast<lds_cu32x4 *>(wbase + (u32)i * 1024u + (u32)lane * 16u);
+        const int row = row0 + wave * RPW + quarter * 128 + i * 16 + prow;
         if (row < p.m && wc < widthB) {
           u64 *dst = C + (long long)row * ldc + wc;
           u64 v0 = (u64)v.x | ((u64)v.y << 32);
@@ -1830,10 +2124,16 @@ __device__ __forceinline__ void strassen_combo(const uint4 (&x)[4], uint4 (&o)[7
   }
 }
 
+// side: 0 = A operand, 1 = B operand, 2 = A operand with ROW-GROUP-PACKED output for gf2_m4rm_kernel_v6<.., APACK>: word c of
+// row r of an output operand goes to u64 index ((r / 64) * w + c) * 64 + r % 64, i.e. the 64 rows of a group lie side by
+// side for every 64-bit column (one 8-byte load per lane of the tile kernel = 512 contiguous bytes).  The threads of a
+// wave then take the 64 rows of a group (h % 64 == 0), so that these 8-byte stores are contiguous.
 __global__ __launch_bounds__(256) void gf2_strassen_split2_kernel(u64 *__restrict__ dst, long long ldd, long long dstStride,
                                                                   const u64 *__restrict__ src, long long lds_,
-                                                                  long long srcStride, int h, int w, int side) {
+                                                                  long long srcStride, int h, int w, int side_) {
   // h, w: rows / words of one OUTPUT operand (a quarter of the source in each dimension)
+  const bool pack = side_ == 2;
+  const int side = pack ? 0 : side_;
   const int b = blockIdx.z;
   const u64 *X = src + (long long)b * srcStride;
   u64 *Y = dst + (long long)b * 49 * dstStride;
@@ -1841,7 +2141,15 @@ __global__ __launch_bounds__(256) void gf2_strassen_split2_kernel(u64 *__restric
   const long long total = (long long)h * pairs;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
-    const int r = (int)(idx / pairs), c = (int)(idx % pairs) * 2;
+    int r, c;
+    if (pack) {
+      const long long rest = idx >> 6;
+      r = (int)(rest / pairs) * 64 + (int)(idx & 63);
+      c = (int)(rest % pairs) * 2;
+    } else {
+      r = (int)(idx / pairs);
+      c = (int)(idx % pairs) * 2;
+    }
     // level-1 combination applied to each of the four inner positions (ir, ic)
     uint4 l1[4][7];
 #pragma unroll
@@ -1855,14 +2163,22 @@ __global__ __launch_bounds__(256) void gf2_strassen_split2_kernel(u64 *__restric
       }
       strassen_combo(x, l1[ip], side);
     }
+    const long long pk = ((long long)(r >> 6) * w + c) * 64 + (r & 63);
 #pragma unroll
     for (int q1 = 0; q1 < 7; ++q1) {
       const uint4 x[4] = {l1[0][q1], l1[1][q1], l1[2][q1], l1[3][q1]};
       uint4 o[7];
       strassen_combo(x, o, side);
 #pragma unroll
-      for (int q2 = 0; q2 < 7; ++q2)
-        *reinterpret_cast<uint4 *>(Y + (long long)(7 * q1 + q2) * dstStride + (long long)r * ldd + c) = o[q2];
+      for (int q2 = 0; q2 < 7; ++q2) {
+        u64 *Yq = Y + (long long)(7 * q1 + q2) * dstStride;
+        if (pack) {
+          Yq[pk] = (u64)o[q2].x | ((u64)o[q2].y << 32);
+          Yq[pk + 64] = (u64)o[q2].z | ((u64)o[q2].w << 32);
+        } else {
+          *reinterpret_cast<uint4 *>(Yq + (long long)r * ldd + c) = o[q2];
+        }
+      }
     }
   }
 }
@@ -1959,7 +2275,12 @@ static inline int grid_for(long long total, int block = 256, int cap = 256 * 8) 
   return (int)g;
 }
 
-extern "C" int gf2k_m4rm_rows_per_tile(int cfg) { return (cfg == 1 || cfg == 20) ? 256 : (cfg == 8 || (cfg >= 80 && cfg < 90)) ? 2048 : 1024; }
+static bool cfg_is_v7(int cfg) { return cfg == 9 || (cfg >= 90 && cfg < 100); }
+static bool cfg_is_v56(int cfg) { return cfg == 8 || (cfg >= 80 && cfg < 90); }
+extern "C" int gf2k_m4rm_rows_per_tile(int cfg) {
+  return (cfg == 1 || cfg == 20) ? 256 : cfg_is_v7(cfg) ? 4096 : cfg_is_v56(cfg) ? 2048 : 1024;
+}
+extern "C" int gf2k_m4rm_cols_per_tile(int cfg) { return cfg_is_v7(cfg) ? 512 : cfg_is_v56(cfg) ? 1024 : 2048; }
 
 // The dynamic-LDS limit of a kernel is per device; hipFuncSetAttribute costs host time that short kernels launched back
 // to back notice, so it is issued once per (kernel, device).
@@ -1991,14 +2312,16 @@ static hipError_t launch_tile_kernel(K kernel, int threads, const gf2k_mul_args 
 // cfg: 0 = v1 8x128, 1 = v1 4x64 (small m), 2.. = pipelined variants (see kbench)
 extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {
   if (a.m <= 0 || a.n <= 0 || a.batch <= 0) return hipSuccess;
+  if (a.a_packed && (cfg != 8 || (a.m & 63))) return hipErrorInvalidValue;  // only the v6 kernel reads the packed layout
   const int R = gf2k_m4rm_rows_per_tile(cfg);
   a.tiles_m = (a.m + R - 1) / R;
-  a.tiles_n = (cfg == 8 || (cfg >= 80 && cfg < 90)) ? (a.n + 1023) / 1024 : (a.n + 2047) / 2048;
+  const int TC = gf2k_m4rm_cols_per_tile(cfg);
+  a.tiles_n = (a.n + TC - 1) / TC;
   const int nw32 = (a.l + 31) / 32;
   if (cfg == 0 || cfg == 1 || a.ksplit < 1) a.ksplit = 1;  // first-generation kernels have no split-K
   if (a.ksplit > nw32) a.ksplit = nw32 > 0 ? nw32 : 1;
   a.kwords = (nw32 + a.ksplit - 1) / a.ksplit;
-  if (cfg == 8 || (cfg > 80 && cfg < 90)) a.kwords = (a.kwords + 1) & ~1;  // v6 reads A in 64-bit slabs: slices start at even words
+  if (cfg == 8 || (cfg > 80 && cfg < 90) || cfg_is_v7(cfg)) a.kwords = (a.kwords + 1) & ~1;  // v6 reads A in 64-bit slabs: slices start at even words
   a.ksplit = a.kwords > 0 ? (nw32 + a.kwords - 1) / a.kwords : 1;  // no empty slices
   if (a.ksplit <= 1 || cfg == 0 || cfg == 1 || (a.ldp & 1)) a.P = nullptr;
   if (a.ksplit > 1 && !a.accumulate && !a.P) {  // slices are combined with atomic XOR: start from zero
@@ -2015,7 +2338,15 @@ extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {
     case 1: e = launch_tile_kernel(&gf2_m4rm_kernel<4, 64>, 256, a, nwg, stream); break;
     case 7: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4>, 512, a, nwg, stream); break;
     case 20: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<4, 64, 4>, 256, a, nwg, stream); break;
-    case 8: e = launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 4>, 512, a, nwg, stream); break;  // paired chunks, one row per lane
+    case 8:  // paired chunks, one row per lane
+      e = a.a_packed ? launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 4, 0, 1>, 512, a, nwg, stream)
+                     : launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 4>, 512, a, nwg, stream);
+      break;
+    case 9: e = launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2>, 512, a, nwg, stream); break;  // four chunks per table, 4096 x 512 tile
+    case 90: e = launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 3>, 512, a, nwg, stream); break;
+    case 92: e = launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2, 2>, 512, a, nwg, stream); break;  // timing only: no barriers
+    case 93: e = launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2, 3>, 512, a, nwg, stream); break;  // timing only: no loads in the loop
+    case 94: e = launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2, 4>, 512, a, nwg, stream); break;  // timing only: no table writes
     case 80: e = launch_tile_kernel(&gf2_m4rm_kernel_v5<8, 256, 4>, 512, a, nwg, stream); break;  // paired chunks, 8 lanes per row
     case 81: e = launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 6>, 512, a, nwg, stream); break;
     case 82: e = launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 3>, 512, a, nwg, stream); break;
@@ -2023,6 +2354,9 @@ extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {
     case 87: e = launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 4, 3>, 512, a, nwg, stream); break;  // timing only: no loads in the loop
     case 88: e = launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 4, 4>, 512, a, nwg, stream); break;  // timing only: no table writes
     case 89: e = launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 4, 6>, 512, a, nwg, stream); break;  // timing only: no XORs
+    case 85: e = launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 4, 9>, 512, a, nwg, stream); break;  // timing only: coalesced (wrong) A loads
+    case 83: e = launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 4, 7>, 512, a, nwg, stream); break;  // timing only: no A loads in the loop
+    case 84: e = launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 4, 8>, 512, a, nwg, stream); break;  // timing only: no B loads in the loop
     case 50: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 0, 0, 1>, 512, a, nwg, stream); break;  // packed B
     case 40: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 2>, 512, a, nwg, stream); break;  // no barriers (timing only)
     case 41: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 3>, 512, a, nwg, stream); break;  // no loads in the loop
@@ -2030,7 +2364,7 @@ extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {
     case 44: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 6>, 512, a, nwg, stream); break;  // no B loads in the loop
     case 45: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 7>, 512, a, nwg, stream); break;  // no A loads in the loop
     case 43: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 5>, 512, a, nwg, stream); break;  // none of the three
-    case 9: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 6, 1>, 512, a, nwg, stream); break;  // section stamps
+    case 49: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 6, 1>, 512, a, nwg, stream); break;  // section stamps
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess || !a.P) return e;

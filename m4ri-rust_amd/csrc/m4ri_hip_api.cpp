@@ -542,6 +542,11 @@ static int mul_strassen(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int a
   SideStream *side = nullptr;
   if (nchunks > 1)
     if (int r = side_stream(s, 2 * nchunks, &side)) return r;
+  // leaf operands of A in the row-group-packed layout of the paired tile kernel (its A loads become contiguous): written by
+  // the last split pass when that pass is a fused two-level one
+  static const int apack_on = env_int("M4RI_HIP_APACK", 1);
+  const bool a_packed = apack_on && mats.back() - (mats.size() > 1 ? mats[mats.size() - 2] : 0) == 2 && ((m >> L) & 63) == 0 &&
+                        m4rm_cfg_for(m >> L, n >> L, (int)pow7(L)) == 8;
   auto run = [&]() -> int {
     // operand trees: level i holds 7^i operands of (m/2^i x l/2^i) and (l/2^i x n/2^i)
     int prev = 0;
@@ -563,7 +568,8 @@ static int mul_strassen(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int a
           HIP_TRY(gf2k_strassen_split(dAp, li / 64, dA, srcA + k0 * strA, ldsA, strA, mi, li / 64, 0, k1 - k0, s));
           HIP_TRY(gf2k_strassen_split(dBp, ni / 64, dB, srcB + k0 * strB, ldsB, strB, li, ni / 64, 1, k1 - k0, s));
         } else {
-          HIP_TRY(gf2k_strassen_split2(dAp, li / 64, dA, srcA + k0 * strA, ldsA, strA, mi, li / 64, 0, k1 - k0, s));
+          HIP_TRY(gf2k_strassen_split2(dAp, li / 64, dA, srcA + k0 * strA, ldsA, strA, mi, li / 64, (i == last && a_packed) ? 2 : 0,
+                                       k1 - k0, s));
           HIP_TRY(gf2k_strassen_split2(dBp, ni / 64, dB, srcB + k0 * strB, ldsB, strB, li, ni / 64, 1, k1 - k0, s));
         }
         if (i == last) {  // leaf products of this chunk
@@ -583,6 +589,7 @@ static int mul_strassen(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int a
           a.n = nL;
           a.batch = (k1 - k0) * cpp;
           a.accumulate = 0;
+          a.a_packed = a_packed ? 1 : 0;
           a.ksplit = m4rm_ksplit_for(mL, lL, nL, a.batch);
           hipStream_t ls = s;
           if (side) {

@@ -46,7 +46,7 @@ int main(int argc, char **argv) {
     const double macs = (double)n * n * n * batch;
     printf("cfg %d  n=%d batch=%d  %s  %.3f ms  %.2f Tbitmac/s  lds-read %.1f TB/s\n", cfg, n, batch,
            h == 0 ? "OK " : "MISMATCH", ms, macs / ms / 1e9, macs / 64 / ms / 1e9);
-    if (cfg == 9) {
+    if (cfg == 49) {
       unsigned long long d[8]; CK(gf2k_dbg_sec(d));
       for (int w = 0; w < 2; ++w)
         printf("   wave %s: per chunk: steps %.0f  loads %.0f  barrier %.0f cycles (%llu chunks)\n", w ? "last" : "0", (double)d[4*w]/d[4*w+3], (double)d[4*w+1]/d[4*w+3], (double)d[4*w+2]/d[4*w+3], d[4*w+3]);
