@@ -1196,7 +1196,7 @@ constexpr int v7_wait_count(int st_wait, int target, int G, int STEPS, int RPS) 
 
 static constexpr int kTileWords7 = 8;  // 512 columns per tile
 
-template <int WAVES, int G, int DBG = 0>
+template <int WAVES, int G, int DBG = 0, int APACK = 0>
 __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v7(const gf2k_mul_args p) {
   constexpr int RPW = 512, RG = 8;
   constexpr int R = WAVES * RPW;
@@ -1258,8 +1258,10 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v7(const gf2k_mul_
   const u32 ldaB = (u32)p.lda * 8u;
   const int rows_here = min(p.m - row0, R);
   const __amdgpu_buffer_rsrc_t rsrcA =
-      __builtin_amdgcn_make_buffer_rsrc((void *)(A + (long long)row0 * p.lda), (short)0, (int)((u32)rows_here * ldaB), 0x00020000);
-  const u32 voffA0 = (u32)(wave * RPW + lane) * ldaB;
+      APACK ? __builtin_amdgcn_make_buffer_rsrc((void *)A, (short)0, (int)((u32)p.m * ldaB), 0x00020000)
+            : __builtin_amdgcn_make_buffer_rsrc((void *)(A + (long long)row0 * p.lda), (short)0, (int)((u32)rows_here * ldaB), 0x00020000);
+  const u32 voffA0 = APACK ? (u32)(row0 + wave * RPW) * ldaB + (u32)lane * 8u : (u32)(wave * RPW + lane) * ldaB;
+  constexpr int kAColB = APACK ? 256 : 4;
   const u32 tailA = (p.l & 31) ? ((1u << (p.l & 31)) - 1u) : 0xffffffffu;
   const int jlast = (nw32 - 1) & ~1;
   u32 aw[RG][2];
@@ -1319,7 +1321,7 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v7(const gf2k_mul_
     asm volatile("" : "+v"(vo));
 #pragma unroll
     for (int r = 0; r < RG; ++r) {
-      const u32x2v v = __builtin_amdgcn_raw_buffer_load_b64(rsrcA, vo, jl * 4, 0);
+      const u32x2v v = __builtin_amdgcn_raw_buffer_load_b64(rsrcA, vo, jl * kAColB, 0);
       aw[r][0] = v.x;
       aw[r][1] = v.y;
       vo += 64u * ldaB;
@@ -1388,7 +1390,7 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v7(const gf2k_mul_
         // the reads of step st + G (issued above) are the last users of row group (st + G) >> 2 when (st + G) & 3 == 3
         if constexpr (W == 1 && ((st + G) & 3) == 3 && st + G < STEPS) {
           constexpr int r = (st + G) >> 2;
-          const u32x2v v = __builtin_amdgcn_raw_buffer_load_b64(rsrcA, voA + (u32)r * 64u * ldaB, jnext * 4, 0);
+          const u32x2v v = __builtin_amdgcn_raw_buffer_load_b64(rsrcA, voA + (u32)r * 64u * ldaB, jnext * kAColB, 0);
           awp[r][0] = v.x;
           awp[r][1] = v.y;
         }
@@ -2312,7 +2314,7 @@ static hipError_t launch_tile_kernel(K kernel, int threads, const gf2k_mul_args 
 // cfg: 0 = v1 8x128, 1 = v1 4x64 (small m), 2.. = pipelined variants (see kbench)
 extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {
   if (a.m <= 0 || a.n <= 0 || a.batch <= 0) return hipSuccess;
-  if (a.a_packed && (cfg != 8 || (a.m & 63))) return hipErrorInvalidValue;  // only the v6 kernel reads the packed layout
+  if (a.a_packed && ((cfg != 8 && cfg != 9) || (a.m & 63))) return hipErrorInvalidValue;  // only v6 / v7 read the packed layout
   const int R = gf2k_m4rm_rows_per_tile(cfg);
   a.tiles_m = (a.m + R - 1) / R;
   const int TC = gf2k_m4rm_cols_per_tile(cfg);
@@ -2342,7 +2344,10 @@ extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {
       e = a.a_packed ? launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 4, 0, 1>, 512, a, nwg, stream)
                      : launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 4>, 512, a, nwg, stream);
       break;
-    case 9: e = launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2>, 512, a, nwg, stream); break;  // four chunks per table, 4096 x 512 tile
+    case 9:  // four chunks per table, 4096 x 512 tile
+      e = a.a_packed ? launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2, 0, 1>, 512, a, nwg, stream)
+                     : launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2>, 512, a, nwg, stream);
+      break;
     case 90: e = launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 3>, 512, a, nwg, stream); break;
     case 92: e = launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2, 2>, 512, a, nwg, stream); break;  // timing only: no barriers
     case 93: e = launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2, 3>, 512, a, nwg, stream); break;  // timing only: no loads in the loop

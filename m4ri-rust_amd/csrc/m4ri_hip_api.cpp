@@ -352,15 +352,16 @@ static int env_int(const char *name, int dflt) {
 }
 
 // ---- launch geometry of the tile kernel (shared by the launcher and the level chooser) ----
-// kernel variants (gf2_kernels.hip): 8 = v6 2048 x 1024 tile, two chunks per lookup step, one row per lane (8 waves); 7 = v3 1024 x 2048 tile
-// (8 waves); 20 = v3 256 x 2048 tile (4 waves).  M4RI_HIP_M4RM_CFG overrides (0/1 = first-generation kernels, kept for
-// A/B runs)
+// kernel variants (gf2_kernels.hip): 8 = v6 2048 x 1024 tile, two chunks per lookup step, one row per lane; 9 = v7 4096 x 512
+// tile, four chunks per table (only ahead of v6 when A comes row-group packed from the Strassen split); 7 = v3 1024 x 2048
+// tile; 20 = v3 256 x 2048 tile (4 waves).  M4RI_HIP_M4RM_CFG overrides (0/1 = first-generation kernels, kept for A/B runs)
 struct TileGeom {
   int rows, cols;
   double cyc_per_chunk;  // measured cycles per 8 bits of the inner dimension and tile, 2.4 GHz
 };
-static TileGeom tile_geom(int cfg) {
-  if (cfg == 8 || (cfg >= 80 && cfg < 90)) return {2048, 1024, 1790.0};
+static TileGeom tile_geom(int cfg, bool packed = false) {
+  if (cfg == 9 || (cfg >= 90 && cfg < 100)) return {4096, 512, packed ? 1520.0 : 1800.0};
+  if (cfg == 8 || (cfg >= 80 && cfg < 90)) return {2048, 1024, packed ? 1620.0 : 1790.0};
   if (cfg == 20 || cfg == 1) return {256, 2048, 1300.0};
   return {1024, 2048, 2350.0};
 }
@@ -368,22 +369,32 @@ static long long tiles_of(const TileGeom &g, int m, int n) {
   return (long long)((m + g.rows - 1) / g.rows) * ((n + g.cols - 1) / g.cols);
 }
 
-static int m4rm_cfg_for(int m, int n, int batch) {
+// `packed`: A may be handed over row-group packed (Strassen leaves); only variants 8 and 9 read that layout, so the caller
+// checks the answer and asks again with packed = false if it got another one
+static int m4rm_cfg_for(int m, int n, int batch, bool packed = false) {
   (void)batch;
   static const int forced = env_int("M4RI_HIP_M4RM_CFG", -1);
   if (forced >= 0) return forced;
   if (m <= 256) return 20;
-  // same tile area, the paired kernel is ~30 % faster per tile: it wins unless its tall tiles leave more of the grid empty
-  const TileGeom g8 = tile_geom(8), g7 = tile_geom(7);
-  return (double)tiles_of(g8, m, n) * g8.cyc_per_chunk <= (double)tiles_of(g7, m, n) * g7.cyc_per_chunk ? 8 : 7;
+  // same tile area: the kernel with the smaller (tiles x cycles per tile) wins, i.e. the paired kernels unless their tall
+  // tiles leave more of the grid empty
+  int best = 7;
+  double cost = (double)tiles_of(tile_geom(7), m, n) * tile_geom(7).cyc_per_chunk;
+  const double c8 = (double)tiles_of(tile_geom(8), m, n) * tile_geom(8, packed).cyc_per_chunk;
+  if (c8 <= cost) best = 8, cost = c8;
+  if (packed) {
+    const double c9 = (double)tiles_of(tile_geom(9), m, n) * tile_geom(9, true).cyc_per_chunk;
+    if (c9 < cost) best = 9, cost = c9;
+  }
+  return best;
 }
 
 // split-K factor: when a product has too few tiles to fill 256 CUs, the inner dimension is cut into slices of
 // at least 128 bits; the slices' partial products are combined by a second kernel
-static int m4rm_ksplit_for(int m, int l, int n, int batch) {
+static int m4rm_ksplit_for(int m, int l, int n, int batch, int cfg) {
   static const int forced = env_int("M4RI_HIP_M4RM_KSPLIT", 0);
   if (forced > 0) return forced;
-  const long long wg = tiles_of(tile_geom(m4rm_cfg_for(m, n, batch)), m, n) * batch;
+  const long long wg = tiles_of(tile_geom(cfg), m, n) * batch;
   if (wg >= 192) return 1;
   const int nw32 = (l + 31) / 32;
   long long ks = 256 / wg;  // one round of workgroups: 256 long slices beat 512 short ones (8192x65536x16384: 2.25 vs 2.52 ms)
@@ -392,9 +403,11 @@ static int m4rm_ksplit_for(int m, int l, int n, int batch) {
 }
 
 // modelled duration of one (batched) tile-kernel launch: rounds of 256 workgroups, each `chunks` table steps
-static double m4rm_time_model(int m, int l, int n, int batch) {
-  const TileGeom g = tile_geom(m4rm_cfg_for(m, n, batch));
-  const int ks = m4rm_ksplit_for(m, l, n, batch);
+static double m4rm_time_model(int m, int l, int n, int batch, bool packed) {
+  int cfg = m4rm_cfg_for(m, n, batch, packed);
+  if (cfg != 8 && cfg != 9 && packed) cfg = m4rm_cfg_for(m, n, batch, packed = false);
+  const TileGeom g = tile_geom(cfg, packed);
+  const int ks = m4rm_ksplit_for(m, l, n, batch, cfg);
   const double wg = (double)tiles_of(g, m, n) * batch * ks;
   const double chunks = std::ceil((l + 31) / 32 / (double)ks) * 4.0;
   const double rounds = std::ceil(wg / 256.0);
@@ -409,6 +422,14 @@ static std::vector<int> strassen_materialised(int L) {
   if (L & 1) v.push_back(lv = 1);
   while (lv < L) v.push_back(lv += 2);
   return v;
+}
+
+// Does the last split pass of an L-level product write the A leaves row-group packed?  (It must be a fused two-level pass
+// and the leaf rows a multiple of 64; M4RI_HIP_APACK=0 switches the layout off.)
+static bool strassen_packs_a(int m, int L) {
+  static const int apack_on = env_int("M4RI_HIP_APACK", 1);
+  if (!apack_on || L < 2) return false;
+  return ((m >> L) & 63) == 0;  // L >= 2: the last materialised step is always a fused one (strassen_materialised)
 }
 
 static size_t pow7(int i) {
@@ -438,7 +459,7 @@ static int pick_levels(int m, int l, int n, int req, int leaf_min) {
       best = L;
       continue;
     }
-    double t = m4rm_time_model(m >> L, l >> L, n >> L, (int)pow7(L));
+    double t = m4rm_time_model(m >> L, l >> L, n >> L, (int)pow7(L), strassen_packs_a(m, L));
     int prev = 0;
     for (int i : strassen_materialised(L)) {
       const int k = i - prev;
@@ -495,7 +516,8 @@ static int mul_m4rm_plain(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int
   a.n = n;
   a.batch = 1;
   a.accumulate = accumulate;
-  a.ksplit = m4rm_ksplit_for(m, l, n, 1);
+  const int cfg = m4rm_cfg_for(m, n, 1);
+  a.ksplit = m4rm_ksplit_for(m, l, n, 1, cfg);
   if (a.ksplit > 1) {  // slices store partial products that a second kernel combines (atomic XOR costs about 3x as much)
     static const long long cap = (long long)env_int("M4RI_HIP_SPLITK_WS_MIB", 512) << 20;
     a.ldp = (words_of(n) + 1) & ~1ll;
@@ -504,7 +526,7 @@ static int mul_m4rm_plain(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int
     void *ws = nullptr;
     if (bytes <= cap && stream_workspace(s, (size_t)bytes, &ws, 1) == 0) a.P = static_cast<u64 *>(ws);
   }
-  return launch_m4rm(a, m4rm_cfg_for(m, n, 1), s);
+  return launch_m4rm(a, cfg, s);
 }
 
 static int mul_strassen(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int accumulate, int L, hipStream_t s,
@@ -544,9 +566,9 @@ static int mul_strassen(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int a
     if (int r = side_stream(s, 2 * nchunks, &side)) return r;
   // leaf operands of A in the row-group-packed layout of the paired tile kernel (its A loads become contiguous): written by
   // the last split pass when that pass is a fused two-level one
-  static const int apack_on = env_int("M4RI_HIP_APACK", 1);
-  const bool a_packed = apack_on && mats.back() - (mats.size() > 1 ? mats[mats.size() - 2] : 0) == 2 && ((m >> L) & 63) == 0 &&
-                        m4rm_cfg_for(m >> L, n >> L, (int)pow7(L)) == 8;
+  int leaf_cfg = m4rm_cfg_for(m >> L, n >> L, (int)pow7(L), strassen_packs_a(m, L));
+  const bool a_packed = strassen_packs_a(m, L) && (leaf_cfg == 8 || leaf_cfg == 9);
+  if (!a_packed) leaf_cfg = m4rm_cfg_for(m >> L, n >> L, (int)pow7(L), false);
   auto run = [&]() -> int {
     // operand trees: level i holds 7^i operands of (m/2^i x l/2^i) and (l/2^i x n/2^i)
     int prev = 0;
@@ -590,14 +612,14 @@ static int mul_strassen(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int a
           a.batch = (k1 - k0) * cpp;
           a.accumulate = 0;
           a.a_packed = a_packed ? 1 : 0;
-          a.ksplit = m4rm_ksplit_for(mL, lL, nL, a.batch);
+          a.ksplit = m4rm_ksplit_for(mL, lL, nL, a.batch, leaf_cfg);
           hipStream_t ls = s;
           if (side) {
             ls = side->s2;
             HIP_TRY(hipEventRecord(side->ev[2 * c], s));
             HIP_TRY(hipStreamWaitEvent(ls, side->ev[2 * c], 0));
           }
-          if (int r = launch_m4rm(a, m4rm_cfg_for(mL, nL, a.batch), ls)) return r;
+          if (int r = launch_m4rm(a, leaf_cfg, ls)) return r;
           if (side) HIP_TRY(hipEventRecord(side->ev[2 * c + 1], ls));
         }
       }
