@@ -246,6 +246,25 @@ def test_dev_strassen_equals_m4rm_large(dev, n, levels):
     assert np.array_equal(P1.to_words()[rows], ref)
 
 
+@pytest.mark.parametrize("m,l,n,levels", [(5120, 1536, 2560, 2), (1280, 2048, 1024, 2), (8704, 4096, 3072, 3), (4096, 8192, 512, 2)])
+def test_strassen_packed_leaves(dev, m, l, n, levels):
+    """With >= 2 levels the last split pass hands the A leaves to the tile kernel in its row-group-packed layout (64 rows side
+    by side per 64-bit column).  Leaf heights that are multiples of 64 but not of the tile height, few-column leaves and an
+    odd level count (single-level pass first): all must equal plain M4RM and the oracle on sampled rows."""
+    A, B = dev.DMat.random(m, l, 11), dev.DMat.random(l, n, 12)
+    P0 = dev.mul(A, B, algo="m4rm")
+    P1 = dev.mul(A, B, algo="strassen", param=levels)
+    assert dev.equal(P0, P1)
+    C = dev.DMat.random(m, n, 13)
+    c0 = C.to_words().copy()
+    dev.mul(A, B, C, accumulate=True, algo="strassen", param=levels)
+    assert np.array_equal(C.to_words(), c0 ^ P0.to_words())
+    rows = np.array([0, 63, 64, m // 2 + 1, m - 65, m - 1])
+    a = g.random_words(m, l, 11)[rows]
+    ref = g.o_mul_m4rm(np.ascontiguousarray(a), g.random_words(l, n, 12), len(rows), l, n)
+    assert np.array_equal(P1.to_words()[rows], ref)
+
+
 def test_dev_properties_full_size(dev):
     """Size-independent properties at a BASELINE config size (32768): linearity in B and
     associativity with a vector, (A*B)*x == A*(B*x)."""
