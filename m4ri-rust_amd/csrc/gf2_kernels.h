@@ -23,7 +23,7 @@ struct gf2k_mul_args {
   // row stride ldp) and gf2k_m4rm combines the slices into C with a second kernel; nullptr: atomic XOR into C
   uint64_t *P;
   long long ldp, sP;
-  // A is stored row-group packed (gf2k_strassen_split2 with side 2): u64 index ((r / 64) * lda + c) * 64 + r % 64; m % 64 == 0
+  // A is stored row-group packed (gf2k_strassen_split2 with side 2): u64 index ((r / 64) * lda + c) * 64 + r % 64, ceil(m / 64) * 64 rows
   int a_packed;
 };
 
@@ -65,6 +65,8 @@ hipError_t gf2k_scatter_rows(uint64_t *X, long long ldx, const uint64_t *R, long
 hipError_t gf2k_any_nonzero(const uint64_t *M, long long ld, int row_lo, int rows, int words, int *flag, hipStream_t s);
 int gf2k_m4rm_rows_per_tile(int cfg);
 int gf2k_m4rm_cols_per_tile(int cfg);
+// row-group-packed copy of A for gf2k_mul_args::a_packed: dst holds ceil(m/64)*64 rows of wp (even, >= w) words
+hipError_t gf2k_packA(uint64_t *dst, long long wp, const uint64_t *src, long long lds_, int m, int w, hipStream_t stream);
 hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream);
 hipError_t gf2k_dbg_sec(unsigned long long *out8);
 int gf2k_packB_chunks(int l);

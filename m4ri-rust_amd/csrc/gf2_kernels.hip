@@ -954,7 +954,7 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v6(const gf2k_mul_
   const int rows_here = min(p.m - row0, R);
   // packed: group g of 64 rows starts at byte g * 64 * ldaB, lane = row inside the group, 512 bytes per 64-bit column
   const __amdgpu_buffer_rsrc_t rsrcA =
-      APACK ? __builtin_amdgcn_make_buffer_rsrc((void *)A, (short)0, (int)((u32)p.m * ldaB), 0x00020000)
+      APACK ? __builtin_amdgcn_make_buffer_rsrc((void *)A, (short)0, (int)((u32)((p.m + 63) & ~63) * ldaB), 0x00020000)
             : __builtin_amdgcn_make_buffer_rsrc((void *)(A + (long long)row0 * p.lda), (short)0, (int)((u32)rows_here * ldaB), 0x00020000);
   const u32 voffA0 = APACK ? (u32)(row0 + wave * RPW) * ldaB + (u32)lane * 8u : (u32)(wave * RPW + lane) * ldaB;
   constexpr int kAColB = APACK ? 256 : 4;  // bytes per 32-bit column index in the scalar offset (packed: 512 per 64-bit slab)
@@ -1258,7 +1258,7 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v7(const gf2k_mul_
   const u32 ldaB = (u32)p.lda * 8u;
   const int rows_here = min(p.m - row0, R);
   const __amdgpu_buffer_rsrc_t rsrcA =
-      APACK ? __builtin_amdgcn_make_buffer_rsrc((void *)A, (short)0, (int)((u32)p.m * ldaB), 0x00020000)
+      APACK ? __builtin_amdgcn_make_buffer_rsrc((void *)A, (short)0, (int)((u32)((p.m + 63) & ~63) * ldaB), 0x00020000)
             : __builtin_amdgcn_make_buffer_rsrc((void *)(A + (long long)row0 * p.lda), (short)0, (int)((u32)rows_here * ldaB), 0x00020000);
   const u32 voffA0 = APACK ? (u32)(row0 + wave * RPW) * ldaB + (u32)lane * 8u : (u32)(wave * RPW + lane) * ldaB;
   constexpr int kAColB = APACK ? 256 : 4;
@@ -1455,6 +1455,23 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v7(const gf2k_mul_
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
+  }
+}
+
+// A (m x w words, row stride lds_) -> row-group-packed copy for the APACK tile kernels: word c of row r at u64 index
+// ((r / 64) * wp + c) * 64 + r % 64 (wp even, >= w); rows past m and words past w are written as zeros.  A wave takes the 64
+// rows of a group: 8-byte reads of 64 rows, contiguous 512-byte writes.
+__global__ __launch_bounds__(256) void gf2_packA_kernel(u64 *__restrict__ dst, long long wp, const u64 *__restrict__ src,
+                                                        long long lds_, int m, int w) {
+  const long long pairs = wp >> 1, total = (long long)((m + 63) >> 6) * pairs * 64;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const long long rest = idx >> 6;
+    const int g = (int)(rest / pairs), c = (int)(rest % pairs) * 2, rl = (int)(idx & 63);
+    const long long r = (long long)g * 64 + rl;
+    const u64 v0 = (r < m && c < w) ? src[r * lds_ + c] : 0, v1 = (r < m && c + 1 < w) ? src[r * lds_ + c + 1] : 0;
+    const long long pk = ((long long)g * wp + c) * 64 + rl;
+    dst[pk] = v0;
+    dst[pk + 64] = v1;
   }
 }
 
@@ -2314,7 +2331,7 @@ static hipError_t launch_tile_kernel(K kernel, int threads, const gf2k_mul_args 
 // cfg: 0 = v1 8x128, 1 = v1 4x64 (small m), 2.. = pipelined variants (see kbench)
 extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {
   if (a.m <= 0 || a.n <= 0 || a.batch <= 0) return hipSuccess;
-  if (a.a_packed && ((cfg != 8 && cfg != 9) || (a.m & 63))) return hipErrorInvalidValue;  // only v6 / v7 read the packed layout
+  if (a.a_packed && cfg != 8 && cfg != 9) return hipErrorInvalidValue;  // only v6 / v7 read the packed layout
   const int R = gf2k_m4rm_rows_per_tile(cfg);
   a.tiles_m = (a.m + R - 1) / R;
   const int TC = gf2k_m4rm_cols_per_tile(cfg);
@@ -2377,6 +2394,14 @@ extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {
   const long long total = (long long)a.m * ((words + 1) / 2) * a.batch;
   hipLaunchKernelGGL(gf2_splitk_reduce_kernel, dim3(grid_for(total)), dim3(256), 0, stream, a.C, a.ldc, a.sC, a.P, a.ldp, a.sP,
                      a.ksplit, a.m, words, a.batch, a.accumulate);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t gf2k_packA(u64 *dst, long long wp, const u64 *src, long long lds_, int m, int w, hipStream_t stream) {
+  if (m <= 0 || w <= 0) return hipSuccess;
+  if (wp < w || (wp & 1)) return hipErrorInvalidValue;
+  const long long total = (long long)((m + 63) >> 6) * (wp >> 1) * 64;
+  hipLaunchKernelGGL(gf2_packA_kernel, dim3(grid_for(total)), dim3(256), 0, stream, dst, wp, src, lds_, m, w);
   return hipGetLastError();
 }
 

@@ -200,7 +200,7 @@ struct StreamWs {
 std::mutex g_ws_mu;
 std::map<std::tuple<int, hipStream_t, int>, StreamWs> g_ws;
 
-// slot 0: Strassen operand arena / transposed operand of the naive entry; slot 1: split-K partial products
+// slot 0: Strassen operand arena / transposed operand of the naive entry; slot 1: split-K partial products; slot 2: packed A
 int stream_workspace(hipStream_t s, size_t bytes, void **out, int slot = 0) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
@@ -501,14 +501,34 @@ static int mul_m4rm_plain(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int
     HIP_TRY(gf2k_va(A->data, A->ld, B->data, B->ld, C->data, C->ld, m, l, n, s));
     return 0;
   }
+  // A tall product first copies A into the row-group-packed layout (one extra pass over A, ~0.2 ms per GiB) so that the
+  // paired tile kernels fetch it with contiguous loads: worth it as soon as the product has a few column tiles
+  static const int plain_pack = env_int("M4RI_HIP_PLAIN_APACK", 1);
+  const long long wp = (words_of(l) + 1) & ~1ll, prow = ((long long)m + 63) & ~63ll;
+  int cfg = m4rm_cfg_for(m, n, 1);
+  const u64 *Aptr = A->data;
+  long long lda = A->ld;
+  bool packed = false;
+  if (plain_pack && m >= 2048 && n >= 1024 && prow * wp * 8 < (1ll << 32)) {
+    const int cp = m4rm_cfg_for(m, n, 1, true);
+    void *pa = nullptr;
+    if ((cp == 8 || cp == 9) && stream_workspace(s, (size_t)(prow * wp * 8), &pa, 2) == 0) {
+      HIP_TRY(gf2k_packA(static_cast<u64 *>(pa), wp, A->data, A->ld, m, words_of(l), s));
+      Aptr = static_cast<const u64 *>(pa);
+      lda = wp;
+      cfg = cp;
+      packed = true;
+    }
+  }
   // buffer descriptors of the tile kernel carry 32-bit byte counts: one tile of A rows must stay below 4 GiB
-  if ((long long)A->ld * 8 * 2048 >= (1ll << 32) || (long long)B->ld * 8 * 16 >= (1ll << 31))
+  if ((!packed && (long long)A->ld * 8 * 2048 >= (1ll << 32)) || (long long)B->ld * 8 * 32 >= (1ll << 31))
     return fail_msg("gf2_mul_dev: row stride too large for the tile kernel (more than ~16 million columns)");
   gf2k_mul_args a{};
-  a.A = A->data;
+  a.A = Aptr;
+  a.a_packed = packed ? 1 : 0;
   a.B = B->data;
   a.C = C->data;
-  a.lda = A->ld;
+  a.lda = lda;
   a.ldb = B->ld;
   a.ldc = C->ld;
   a.m = m;
@@ -516,7 +536,6 @@ static int mul_m4rm_plain(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int
   a.n = n;
   a.batch = 1;
   a.accumulate = accumulate;
-  const int cfg = m4rm_cfg_for(m, n, 1);
   a.ksplit = m4rm_ksplit_for(m, l, n, 1, cfg);
   if (a.ksplit > 1) {  // slices store partial products that a second kernel combines (atomic XOR costs about 3x as much)
     static const long long cap = (long long)env_int("M4RI_HIP_SPLITK_WS_MIB", 512) << 20;
