@@ -1861,31 +1861,33 @@ __global__ __launch_bounds__(NT) void gf2_tallskinny3_kernel(const u64 *__restri
           for (int i = 0; i < ND; ++i) d[i] = __builtin_amdgcn_perm(d[i], d[i], bsel);
           const u32 xl = rs ? xl1 : xl0;
 #pragma unroll
-          for (int c = 0; c < TPR; ++c) {
+          for (int c = 0; c < TPR; c += 2) {
             // LDS byte address {0, row set, selecting byte, skewed table offset} in one v_perm_b32 (bytes 0, 2, 3 from the
-            // lane's table offset, byte 1 = byte c&3 of the permuted dword); integer -> LDS pointer, no base to add
+            // lane's table offset, byte 1 = byte c&3 of the permuted dword); integer -> LDS pointer, no base to add.
+            // Two chunks per step: their entries are folded into the accumulators with one three-input XOR per dword.
             const u32 off = __builtin_amdgcn_perm(d[c >> 2], xl ^ (u32)(c * 8 * NW), 0x03020000u | ((4u + (c & 3)) << 8));
+            const u32 off1 = __builtin_amdgcn_perm(d[(c + 1) >> 2], xl ^ (u32)((c + 1) * 8 * NW), 0x03020000u | ((4u + ((c + 1) & 3)) << 8));
             if constexpr (NW == 1) {
-              const u32x2v v = *reinterpret_cast<lds_cu32x2 *>(off);
-              asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][0]) : "v"(v.x));
-              asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][1]) : "v"(v.y));
+              const u32x2v v = *reinterpret_cast<lds_cu32x2 *>(off), w = *reinterpret_cast<lds_cu32x2 *>(off1);
+              asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][0]) : "v"(v.x), "v"(w.x));
+              asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][1]) : "v"(v.y), "v"(w.y));
             } else if constexpr (NW == 2) {
-              const u32x4 v = *reinterpret_cast<lds_cu32x4 *>(off);
-              asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][0]) : "v"(v.x));
-              asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][1]) : "v"(v.y));
-              asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][2]) : "v"(v.z));
-              asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][3]) : "v"(v.w));
+              const u32x4 v = *reinterpret_cast<lds_cu32x4 *>(off), w = *reinterpret_cast<lds_cu32x4 *>(off1);
+              asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][0]) : "v"(v.x), "v"(w.x));
+              asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][1]) : "v"(v.y), "v"(w.y));
+              asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][2]) : "v"(v.z), "v"(w.z));
+              asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][3]) : "v"(v.w), "v"(w.w));
             } else {
-              const u32x4 v = *reinterpret_cast<lds_cu32x4 *>(off);
-              const u32x4 v2 = *reinterpret_cast<lds_cu32x4 *>(off ^ 16u);
-              asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][0]) : "v"(v.x));
-              asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][1]) : "v"(v.y));
-              asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][2]) : "v"(v.z));
-              asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][3]) : "v"(v.w));
-              asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][4]) : "v"(v2.x));
-              asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][5]) : "v"(v2.y));
-              asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][6]) : "v"(v2.z));
-              asm("v_xor_b32 %0, %1, %0" : "+v"(acc[r][7]) : "v"(v2.w));
+              const u32x4 v = *reinterpret_cast<lds_cu32x4 *>(off), w = *reinterpret_cast<lds_cu32x4 *>(off1);
+              const u32x4 v2 = *reinterpret_cast<lds_cu32x4 *>(off ^ 16u), w2 = *reinterpret_cast<lds_cu32x4 *>(off1 ^ 16u);
+              asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][0]) : "v"(v.x), "v"(w.x));
+              asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][1]) : "v"(v.y), "v"(w.y));
+              asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][2]) : "v"(v.z), "v"(w.z));
+              asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][3]) : "v"(v.w), "v"(w.w));
+              asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][4]) : "v"(v2.x), "v"(w2.x));
+              asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][5]) : "v"(v2.y), "v"(w2.y));
+              asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][6]) : "v"(v2.z), "v"(w2.z));
+              asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][7]) : "v"(v2.w), "v"(w2.w));
             }
           }
           // last row set of the last group that holds bits of the inner dimension (uniform)
@@ -2331,7 +2333,7 @@ static hipError_t launch_tile_kernel(K kernel, int threads, const gf2k_mul_args 
 // cfg: 0 = v1 8x128, 1 = v1 4x64 (small m), 2.. = pipelined variants (see kbench)
 extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {
   if (a.m <= 0 || a.n <= 0 || a.batch <= 0) return hipSuccess;
-  if (a.a_packed && cfg != 8 && cfg != 9) return hipErrorInvalidValue;  // only v6 / v7 read the packed layout
+  if (a.a_packed && cfg != 8 && !cfg_is_v7(cfg)) return hipErrorInvalidValue;  // only v6 / v7 read the packed layout
   const int R = gf2k_m4rm_rows_per_tile(cfg);
   a.tiles_m = (a.m + R - 1) / R;
   const int TC = gf2k_m4rm_cols_per_tile(cfg);
@@ -2365,10 +2367,11 @@ extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {
       e = a.a_packed ? launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2, 0, 1>, 512, a, nwg, stream)
                      : launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2>, 512, a, nwg, stream);
       break;
-    case 90: e = launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 3>, 512, a, nwg, stream); break;
-    case 92: e = launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2, 2>, 512, a, nwg, stream); break;  // timing only: no barriers
-    case 93: e = launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2, 3>, 512, a, nwg, stream); break;  // timing only: no loads in the loop
-    case 94: e = launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2, 4>, 512, a, nwg, stream); break;  // timing only: no table writes
+    // timing-only ablations of v7 on packed A (wrong results by design)
+    case 92: e = a.a_packed ? launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2, 2, 1>, 512, a, nwg, stream) : hipErrorInvalidValue; break;  // no barriers
+    case 93: e = a.a_packed ? launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2, 3, 1>, 512, a, nwg, stream) : hipErrorInvalidValue; break;  // no loads in the loop
+    case 94: e = a.a_packed ? launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2, 4, 1>, 512, a, nwg, stream) : hipErrorInvalidValue; break;  // no table writes
+    case 95: e = a.a_packed ? launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2, 6, 1>, 512, a, nwg, stream) : hipErrorInvalidValue; break;  // no XORs
     case 80: e = launch_tile_kernel(&gf2_m4rm_kernel_v5<8, 256, 4>, 512, a, nwg, stream); break;  // paired chunks, 8 lanes per row
     case 81: e = launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 6>, 512, a, nwg, stream); break;
     case 82: e = launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 3>, 512, a, nwg, stream); break;

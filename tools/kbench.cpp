@@ -28,12 +28,21 @@ int main(int argc, char **argv) {
   uint32_t *Bp; CK(hipMalloc(&Bp, (size_t)bpBlocks * 2048 * batch));
   CK(gf2k_packB(Bp, bpBlocks * 512, B, ld, words, n, n, batch, 0));
   a.Bp = Bp; a.sBp = bpBlocks; a.bp_nc = nc;
+  // APACK=1: A row-group packed (gf2k_packA), as the Strassen split / the plain-product prologue hand it to v6 / v7
+  uint64_t *Apk = nullptr;
+  if (getenv("APACK") && atoi(getenv("APACK"))) {
+    CK(hipMalloc(&Apk, words * 8 * batch));
+    for (int b = 0; b < batch; ++b) CK(gf2k_packA(Apk + b * words, ld, A + b * words, ld, n, (int)ld, 0));
+  }
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   a.C = Cref;
   CK(gf2k_m4rm(a, 0, 0)); CK(hipDeviceSynchronize());
   for (int i = 4; i < argc; ++i) {
     const int cfg = atoi(argv[i]);
     a.C = C;
+    const bool pk = Apk && (cfg == 8 || cfg == 9 || (cfg >= 90 && cfg < 100));
+    a.A = pk ? Apk : A;
+    a.a_packed = pk ? 1 : 0;
     CK(hipMemset(C, 0xff, words * 8 * batch));
     CK(gf2k_m4rm(a, cfg, 0)); CK(hipDeviceSynchronize());
     CK(hipMemset(diff, 0, 4));
