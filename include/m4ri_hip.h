@@ -178,8 +178,8 @@ int gf2_echelonize_dev(gf2_dmat *A, int full, int ncols_limit, int *rank, int *p
 /* Ainv = A^-1 for square A; *singular = 1 (Ainv untouched) if A has no inverse.  Synchronous. */
 int gf2_inverse_dev(gf2_dmat *Ainv, gf2_dmat const *A, int *singular, void *stream);
 
-/* Strassen levels the cost model picks for this shape (0 = plain M4RM); a product uses fewer if the operand arena of
- * that many levels does not fit into free device memory */
+/* Strassen levels a product of this shape would use right now (0 = plain M4RM): the cost model's choice, lowered until the
+ * operand arena of that many levels fits into free device memory (without a device: the cost model's choice) */
 int gf2_strassen_levels(int m, int l, int n, int algo, int param);
 /* bytes of scratch a product of this shape needs (Strassen operands, packed copies);
  * the library keeps one cached arena per device and grows it on demand. */

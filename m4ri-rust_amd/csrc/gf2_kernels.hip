@@ -18,6 +18,10 @@
 //    by a byte of A with one conflict-free ds_read_b128 and XORs it into its accumulators.  The table
 //    row is exactly one LDS bank row (64 banks x 4 B), so any mix of entries is conflict free.
 //    The LDS byte address is formed by ONE v_perm_b32: {0, table-select, A byte, lane offset}.
+//    Generations: gf2_m4rm_kernel (first), _v3 (instruction-count minimal; used for m <= 1024), _v5 (two chunks per lookup
+//    step folded with v_bitop3_b32, 2048 x 1024 tile), _v6 (v5 with one row of A per lane; default for plain products),
+//    _v7 (four chunks per table generation, 4096 x 512 tile; default on row-group-packed A, i.e. Strassen leaves and
+//    packed plain products).
 //  * few-tile products cut the inner dimension into slices (split-K); gf2_splitk_reduce_kernel XORs the partial tiles.
 //  * products with n <= 256 and many rows (batches of matrix x vector products) have their own Four-Russians kernels
 //    with tables over ALL of B in LDS (gf2_tallskinny_kernel, gf2_tallskinny3_kernel); n <= 8 uses an AND/popcount

@@ -712,6 +712,33 @@ static int check_mul_dims(const gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *
 // (another host thread enqueueing on the SAME stream in between would reuse the arena under them).
 static std::mutex g_enqueue_mu;
 
+// The operand arena of L levels must fit: what the driver reports free plus what this library already holds (its block
+// cache and this stream's current arena are handed back before a larger one is allocated).
+static int cap_levels_by_memory(int m, int l, int n, int L, hipStream_t s) {
+  if (L <= 0) return L;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+    (void)hipGetLastError();
+    return L;
+  }
+  size_t mine = 0;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    auto it = g_ws.find(std::make_tuple(dev, s, 0));
+    if (it != g_ws.end()) mine += it->second.bytes;
+  }
+  {
+    DevPool &pool = g_pools[dev & 15];
+    std::lock_guard<std::mutex> lk(pool.mu);
+    mine += pool.cached;
+  }
+  const size_t avail = (size_t)((free_b + mine) * 0.95);
+  while (L > 0 && strassen_ws_words(m, l, n, L) * sizeof(u64) > avail) --L;
+  return L;
+}
+
 static int mul_dispatch(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int accumulate, int algo, int param,
                         hipStream_t s, bool sync_free) {
   std::unique_lock<std::mutex> lk(g_enqueue_mu, std::defer_lock);
@@ -729,30 +756,7 @@ static int mul_dispatch(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int a
     case GF2_ALGO_STRASSEN: {
       static const int leaf_min = env_int("M4RI_HIP_STRASSEN_LEAF_MIN", 2048);
       int L = pick_levels(A->nrows, A->ncols, B->ncols, param, leaf_min);
-      // the operand arena of L levels must fit: what the driver reports free plus what this library already holds
-      // (its block cache and this stream's current arena are handed back before a larger one is allocated)
-      if (L > 0) {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-          size_t mine = 0;
-          int dev = 0;
-          (void)hipGetDevice(&dev);
-          {
-            std::lock_guard<std::mutex> lk(g_ws_mu);
-            auto it = g_ws.find(std::make_tuple(dev, s, 0));
-            if (it != g_ws.end()) mine += it->second.bytes;
-          }
-          {
-            DevPool &pool = g_pools[dev & 15];
-            std::lock_guard<std::mutex> lk(pool.mu);
-            mine += pool.cached;
-          }
-          const size_t avail = (size_t)((free_b + mine) * 0.95);
-          while (L > 0 && strassen_ws_words(A->nrows, A->ncols, B->ncols, L) * sizeof(u64) > avail) --L;
-        } else {
-          (void)hipGetLastError();
-        }
-      }
+      L = cap_levels_by_memory(A->nrows, A->ncols, B->ncols, L, s);
       return mul_strassen(C, A, B, accumulate, L, s, sync_free);
     }
     default:
@@ -877,7 +881,11 @@ extern "C" int gf2_dmat_fill_random(gf2_dmat *M, uint64_t seed, void *stream) {
 extern "C" int gf2_strassen_levels(int m, int l, int n, int algo, int param) {
   if (algo != GF2_ALGO_AUTO && algo != GF2_ALGO_STRASSEN) return 0;
   static const int leaf_min = env_int("M4RI_HIP_STRASSEN_LEAF_MIN", 2048);
-  return pick_levels(m, l, n, param, leaf_min);
+  int L = pick_levels(m, l, n, param, leaf_min);
+  int ndev = 0;
+  if (L > 0 && hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) L = cap_levels_by_memory(m, l, n, L, nullptr);
+  else (void)hipGetLastError();
+  return L;
 }
 
 // host rows -> device. Our mzd_t are single-block with a constant rowstride (mzd_host.cpp), windows included.
