@@ -238,7 +238,8 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "gf2_m4rm_kernel (batch of %d leaf products %dx%dx%d)" % (batch, mi, li, ni),
+            # v7 on row-group-packed A (>= 2 Strassen levels, or a packed plain product), v6 / v3 otherwise
+            "kernel": "M4RM tile kernel gf2_m4rm_kernel_v7/_v6 (batch of %d leaf products %dx%dx%d)" % (batch, mi, li, ni),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "frac_of_measured_copy": achieved / HBM_COPY_GBS,
