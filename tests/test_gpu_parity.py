@@ -265,6 +265,26 @@ def test_strassen_packed_leaves(dev, m, l, n, levels):
     assert np.array_equal(P1.to_words()[rows], ref)
 
 
+def test_packed_tile_paths_ragged(dev):
+    """m >= 2048 and n >= 1024: the plain product packs A and runs the paired tile kernels (one row per lane, 2048 x 1024 or
+    4096 x 512 tiles).  Ragged rows, inner dimensions from a few bits to a few thousand, ragged column tiles, accumulate:
+    bit-exact against the oracle (tools/fuzz_tiles.py is the long form)."""
+    rng = np.random.default_rng(21)
+    shapes = [(2048, 1, 1024), (2049, 31, 1025), (4097, 33, 1100), (2500, 64, 2049), (6000, 65, 1536), (9300, 129, 1030),
+              (4096, 1000, 4096), (5003, 2111, 3001)]
+    shapes += [(int(rng.integers(2048, 9000)), int(rng.integers(1, 2500)), int(rng.integers(1024, 5000))) for _ in range(4)]
+    for it, (m, l, n) in enumerate(shapes):
+        a, b = g.random_words(m, l, 500 + it), g.random_words(l, n, 600 + it)
+        ref = g.o_mul_m4rm(a, b, m, l, n)
+        A, B = dev.DMat.from_words(a, l), dev.DMat.from_words(b, n)
+        assert np.array_equal(dev.mul(A, B, algo="m4rm").to_words(), ref), (m, l, n)
+        assert np.array_equal(dev.mul(A, B, algo="auto").to_words(), ref), (m, l, n)
+        c0 = g.random_words(m, n, 700 + it)
+        C = dev.DMat.from_words(c0, n)
+        dev.mul(A, B, C, accumulate=True, algo="m4rm")
+        assert np.array_equal(C.to_words(), c0 ^ ref), (m, l, n)
+
+
 def test_dev_properties_full_size(dev):
     """Size-independent properties at a BASELINE config size (32768): linearity in B and
     associativity with a vector, (A*B)*x == A*(B*x)."""
