@@ -579,7 +579,7 @@ static int mul_strassen(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int a
   const int last = mats.back(), lastprev = mats.size() > 1 ? mats[mats.size() - 2] : 0;
   const int parents = (int)pow7(lastprev), cpp = (int)pow7(last - lastprev);  // children (leaves) per parent node
   const int overlap_on = env_int("M4RI_HIP_STRASSEN_OVERLAP", 0);
-  const int nchunks = (overlap_on && parents >= 7) ? 7 : 1;
+  const int nchunks = (overlap_on && parents >= 7) ? (overlap_on == 1 ? 7 : (overlap_on < parents ? overlap_on : parents)) : 1;
   SideStream *side = nullptr;
   if (nchunks > 1)
     if (int r = side_stream(s, 2 * nchunks, &side)) return r;
@@ -786,9 +786,12 @@ extern "C" int gf2_mul_nt_dev(gf2_dmat *C, gf2_dmat const *A, gf2_dmat const *Bt
 
 extern "C" size_t gf2_mul_workspace_bytes(int m, int l, int n, int algo, int param) {
   if (algo == GF2_ALGO_NAIVE) return n <= 64 ? (size_t)n * ((words_of(l) + 1) & ~1) * 8 : 0;
-  if (algo == GF2_ALGO_M4RM) return 0;
+  // a tall plain product packs A (mul_m4rm_plain) and may cut the inner dimension into slices with partial tiles
+  const size_t packed_a = (m >= 2048 && n >= 1024) ? (size_t)((m + 63) & ~63) * (size_t)((words_of(l) + 1) & ~1) * 8 : 0;
+  if (algo == GF2_ALGO_M4RM) return packed_a;
   static const int leaf_min = env_int("M4RI_HIP_STRASSEN_LEAF_MIN", 2048);
-  return strassen_ws_words(m, l, n, pick_levels(m, l, n, param, leaf_min)) * sizeof(u64);
+  const int L = pick_levels(m, l, n, param, leaf_min);
+  return L > 0 ? strassen_ws_words(m, l, n, L) * sizeof(u64) : packed_a;
 }
 
 extern "C" int gf2_add_dev(gf2_dmat *C, gf2_dmat const *A, gf2_dmat const *B, void *stream) {
