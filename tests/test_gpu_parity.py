@@ -285,6 +285,18 @@ def test_packed_tile_paths_ragged(dev):
         assert np.array_equal(C.to_words(), c0 ^ ref), (m, l, n)
 
 
+def test_packed_plain_product_2gib_operand(dev):
+    """A plain product whose packed copy of A is ~2 GiB (the tile kernels' 32-bit buffer descriptors run up to their sign bit):
+    linearity in B, and a 2000-row window of A (below the packing threshold, other kernel path) gives the same rows."""
+    m, l, n = 131072, 131072 - 64, 1024 + 37
+    A, B, B2 = dev.DMat.random(m, l, 1), dev.DMat.random(l, n, 2), dev.DMat.random(l, n, 3)
+    C1 = dev.mul(A, B, algo="m4rm")
+    assert dev.equal(dev.mul(A, dev.add(B, B2), algo="m4rm"), dev.add(C1, dev.mul(A, B2, algo="m4rm")))
+    r0, rows = 70000, 2000
+    Aw = dev.DMat.from_words(A.to_words()[r0:r0 + rows], l)
+    assert np.array_equal(dev.mul(Aw, B, algo="m4rm").to_words(), C1.to_words()[r0:r0 + rows])
+
+
 def test_dev_properties_full_size(dev):
     """Size-independent properties at a BASELINE config size (32768): linearity in B and
     associativity with a vector, (A*B)*x == A*(B*x)."""
