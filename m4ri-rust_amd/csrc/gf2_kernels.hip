@@ -1902,6 +1902,130 @@ __global__ __launch_bounds__(NT) void gf2_tallskinny3_kernel(const u64 *__restri
   }
 }
 
+// tall-skinny kernel for n <= 64 (8-byte table entries) with conflict-free lookups and no byte permutation.
+// The first kernel's lookups of 8-byte entries collide in the LDS banks (32 lanes, 32 random bank pairs: ~3.5 lanes on the
+// busiest pair); the skewed kernel avoids that by spreading the lanes over 32 tables, which costs a byte permutation of every
+// row.  Here the skew stays inside one 64-bit word of the row -- lane L visits its 8 chunks in the order c ^ (L & 7), and the
+// selecting byte comes out of the two dwords of the word with ONE v_perm_b32 whose selector is per lane -- and the other
+// factor 4 comes from four COPIES of every table: a 256-byte LDS row holds entry e of 8 chunks x 4 copies (slot = 4 chunk +
+// copy, copy = (L >> 3) & 3), so the 32 lanes the LDS serves together read 32 different slots whatever their entries are.
+// A "generation" = the tables of one 64-bit word of the inner dimension = 64 KiB; two generations are resident (one being
+// looked up while the next is built), rows of the table are written with one ds_write_addtid_b32 each (lane = dword of the
+// row), Gray-code order, like the tile kernels.  One lane per row of A, RPT rows per lane, two chunks per three-input XOR.
+// ---------------------------------------------------------------------------------------------
+template <int RPT, int NT>
+__global__ __launch_bounds__(NT) void gf2_tallskinny4_kernel(const u64 *__restrict__ A, long long lda, const u64 *__restrict__ B,
+                                                              long long ldb, u64 *__restrict__ C, long long ldc, int m, int l,
+                                                              int n, int accumulate) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  constexpr int WAVES = NT / 64, EPW = 256 / WAVES, LOWB = Log2<EPW>::value;
+  static_assert(EPW * WAVES == 256 && EPW >= 1, "geometry");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wl = (l + 63) >> 6;
+  const u64 maskL = (l & 63) ? ((1ull << (l & 63)) - 1) : ~0ull;
+  const u64 maskC = (n & 63) ? ((1ull << (n & 63)) - 1) : ~0ull;
+  const long long row_base = (long long)blockIdx.x * (NT * RPT);
+  // lookups: chunk order c ^ s, copy r4
+  const int s = lane & 7, r4 = (lane >> 3) & 3;
+  u32 selc[8], loc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int cs = c ^ s;
+    selc[c] = 0x0c0c000cu | ((u32)cs << 8);  // {0, 0, byte cs of the 64-bit word, 0}: v_perm_b32(high dword, low dword, sel)
+    loc[c] = (u32)((cs * 4 + r4) * 8);
+  }
+  // build: lane = dword of the 256-byte table row: slot = lane >> 1 = 4 chunk + copy, dword lane & 1 of the 8-byte entry
+  const int bch = lane >> 3, bhalf = lane & 1;
+
+  u32 acc[RPT][2];
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) acc[r][0] = acc[r][1] = 0;
+
+  // barrier that waits for this wave's LDS operations only: the loads of A stay in flight across it
+  auto lds_barrier = []() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  u64 *bstage = reinterpret_cast<u64 *>(lds + 128 * 1024);  // the 256 rows of B of a block of four generations (2 KiB)
+
+  for (int w0 = 0; w0 < wl; w0 += 4) {  // four 64-bit words of the inner dimension = four generations
+    u64 aw[RPT][4];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      const long long row = min(row_base + (long long)r * NT + tid, (long long)m - 1);  // clamped: stores are guarded
+      const u64 *ap = A + row * lda;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        u64 x = ap[min(w0 + q, wl - 1)];
+        if (w0 + q >= wl) x = 0;
+        if (w0 + q == wl - 1) x &= maskL;
+        aw[r][q] = x;
+      }
+    }
+    // the block's rows of B -> LDS (coalesced; the build reads them as broadcasts).  The barrier after the first build
+    // below makes them visible... to the first build itself they must be visible already: one barrier here.
+    lds_barrier();  // every wave is done with the previous block's rows
+    if (tid < 256) {
+      const long long brow = (long long)w0 * 64 + tid;
+      bstage[tid] = brow < l ? B[brow * ldb] : 0;
+    }
+    lds_barrier();
+    static_for<4>([&](auto gtag) __attribute__((always_inline)) {
+      constexpr int g = decltype(gtag)::value;
+      constexpr u32 tbase = (g & 1) ? 65536u : 0u;  // w0 is a multiple of 4: generation w0 + g lives in buffer g & 1
+      if (w0 + g < wl) {                            // uniform
+        // ---- build the generation: wave w owns entries [EPW w, EPW (w + 1)) ----
+        u32 rr[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) rr[b] = reinterpret_cast<const u32 *>(bstage + g * 64 + bch * 8 + b)[bhalf];
+        u32 cur = 0;
+#pragma unroll
+        for (int b = LOWB; b < 8; ++b)
+          if ((wave >> (b - LOWB)) & 1) cur ^= rr[b];
+        {
+          constexpr u32 kOff = tbase ? (0x10004u - (u32)(EPW * 256)) : 0u;  // see gf2_m4rm_kernel_v3
+          const u32 m0v = tbase + (u32)wave * (u32)(EPW * 256) - kOff;
+          asm volatile("s_mov_b32 m0, %0" ::"s"(m0v) : "memory");
+          static_for<EPW>([&](auto itag) __attribute__((always_inline)) {
+            constexpr int i = decltype(itag)::value;
+            constexpr unsigned e = (unsigned)i ^ ((unsigned)i >> 1);
+            if constexpr (i > 0) cur ^= rr[__builtin_ctz(i | 256)];
+            asm volatile("ds_write_addtid_b32 %0 offset:%1" ::"v"(cur), "n"(kOff + e * 256u) : "memory");
+          });
+        }
+        lds_barrier();  // the generation is complete; every wave has also finished the lookups of generation - 2 in this buffer
+        // ---- lookups ----
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+          const u32 a0 = (u32)aw[r][g], a1 = (u32)(aw[r][g] >> 32);
+          u32 lo = acc[r][0], hi = acc[r][1];  // (locals: an asm operand inside this lambda cannot name the enclosing function's array)
+#pragma unroll
+          for (int c = 0; c < 8; c += 2) {
+            const u32 o0 = __builtin_amdgcn_perm(a1, a0, selc[c]) | loc[c];
+            const u32 o1 = __builtin_amdgcn_perm(a1, a0, selc[c + 1]) | loc[c + 1];
+            const u32x2v x = *reinterpret_cast<lds_cu32x2 *>(o0), y = *reinterpret_cast<lds_cu32x2 *>(o1);
+            asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(lo) : "v"(x.x), "v"(y.x));
+            asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(hi) : "v"(x.y), "v"(y.y));
+          }
+          acc[r][0] = lo;
+          acc[r][1] = hi;
+        }
+      }
+      // the next generation lives in the other buffer (also when this one was skipped: w0 + g >= wl only at the very end)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) loc[c] ^= 65536u;
+    });
+  }
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) {
+    const long long row = row_base + (long long)r * NT + tid;
+    if (row < m) {
+      u64 v = ((u64)acc[r][0] | ((u64)acc[r][1] << 32)) & maskC;
+      u64 *d = C + row * ldc;
+      if (accumulate) v ^= *d;
+      *d = v;
+    }
+  }
+}
+
 // v*A kernel: C (m x n) (+)= A (m x l) * B (l x n) for a handful of rows m <= 8 (_mzd_mul_va,
 // mzd.rs:175-181 and `&v * &A`, binary_matrix.rs:552-563).  Streams B once; the inner dimension
 // is split over blockIdx.y and partial sums are combined with 64-bit atomic XOR.
@@ -2500,6 +2624,16 @@ extern "C" hipError_t gf2k_tallskinny(const u64 *A, long long lda, const u64 *B,
       GF2_TS3_LAUNCH(4);
     }
 #undef GF2_TS3_LAUNCH
+    return hipGetLastError();
+  }
+  if (nw == 1 && forced_gen != 1) {  // replicated-table kernel (conflict-free 8-byte lookups)
+    constexpr int RPT4 = 4, NT4 = 1024;
+    const unsigned grid4 = (unsigned)(((long long)m + NT4 * RPT4 - 1) / (NT4 * RPT4));
+    const size_t lds4 = 128 * 1024 + 2048;
+    hipError_t e4 = lds_limit_once(reinterpret_cast<const void *>(&gf2_tallskinny4_kernel<RPT4, NT4>), (int)lds4);
+    if (e4 != hipSuccess) return e4;
+    hipLaunchKernelGGL((gf2_tallskinny4_kernel<RPT4, NT4>), dim3(grid4), dim3(NT4), lds4, stream, A, lda, B, ldb, C, ldc, m, l, n,
+                       accumulate);
     return hipGetLastError();
   }
   constexpr int RPT = 4, NT = 1024;
