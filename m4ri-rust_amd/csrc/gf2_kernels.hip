@@ -1902,49 +1902,57 @@ __global__ __launch_bounds__(NT) void gf2_tallskinny3_kernel(const u64 *__restri
   }
 }
 
-// tall-skinny kernel for n <= 64 (8-byte table entries) with conflict-free lookups and no byte permutation.
-// The first kernel's lookups of 8-byte entries collide in the LDS banks (32 lanes, 32 random bank pairs: ~3.5 lanes on the
-// busiest pair); the skewed kernel avoids that by spreading the lanes over 32 tables, which costs a byte permutation of every
-// row.  Here the skew stays inside one 64-bit word of the row -- lane L visits its 8 chunks in the order c ^ (L & 7), and the
-// selecting byte comes out of the two dwords of the word with ONE v_perm_b32 whose selector is per lane -- and the other
-// factor 4 comes from four COPIES of every table: a 256-byte LDS row holds entry e of 8 chunks x 4 copies (slot = 4 chunk +
-// copy, copy = (L >> 3) & 3), so the 32 lanes the LDS serves together read 32 different slots whatever their entries are.
+// tall-skinny kernel with conflict-free lookups and no byte permutation ("generation" kernel; n <= 256).
+// The first kernel's lookups collide in the LDS banks (8-byte entries: 32 lanes on 32 random bank pairs, ~3.5 lanes on the
+// busiest); the skewed kernel avoids that by spreading the lanes over 32 / NW tables, which costs a byte permutation of every
+// row and reloads A after every table build.  Here the skew stays inside one 64-bit word of the row -- lane L visits its 8
+// chunks in the order c ^ (L & 7), and the selecting byte comes out of the two dwords of the word with ONE v_perm_b32 whose
+// selector is per lane -- and whatever is missing to fill a 256-byte LDS row comes from COPIES of every table: the row holds
+// entry e of 8 chunks x (4 / NW) copies x 8 NW bytes (slot = copies * chunk + copy), so the lanes the LDS serves together
+// read different slots whatever their entries are (NW = 4: one copy, the two 16-byte halves of an entry are read in opposite
+// order by lanes 8..15 of every 16, as in the skewed kernel).
 // A "generation" = the tables of one 64-bit word of the inner dimension = 64 KiB; two generations are resident (one being
-// looked up while the next is built), rows of the table are written with one ds_write_addtid_b32 each (lane = dword of the
-// row), Gray-code order, like the tile kernels.  One lane per row of A, RPT rows per lane, two chunks per three-input XOR.
+// looked up while the next is built, ONE barrier per generation, and that barrier waits for LDS operations only, so the loads
+// of A issued at the top stay in flight across the builds); rows of the table are written with one ds_write_addtid_b32 each
+// (lane = dword of the row), Gray-code order, like the tile kernels; the rows of B of four generations are staged in LDS.
+// One lane per row of A, RPT rows per lane, two chunks per three-input XOR.
 // ---------------------------------------------------------------------------------------------
-template <int RPT, int NT>
+template <int NW, int RPT, int NT>
 __global__ __launch_bounds__(NT) void gf2_tallskinny4_kernel(const u64 *__restrict__ A, long long lda, const u64 *__restrict__ B,
                                                               long long ldb, u64 *__restrict__ C, long long ldc, int m, int l,
                                                               int n, int accumulate) {
   extern __shared__ __align__(16) unsigned char lds[];
   constexpr int WAVES = NT / 64, EPW = 256 / WAVES, LOWB = Log2<EPW>::value;
-  static_assert(EPW * WAVES == 256 && EPW >= 1, "geometry");
+  constexpr int COPIES = 4 / NW, EB = 8 * NW;  // copies of a table in an LDS row, bytes per entry
+  static_assert(EPW * WAVES == 256 && EPW >= 1 && (NW == 1 || NW == 2 || NW == 4), "geometry");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wl = (l + 63) >> 6;
+  const int wl = (l + 63) >> 6, wn = (n + 63) >> 6;
   const u64 maskL = (l & 63) ? ((1ull << (l & 63)) - 1) : ~0ull;
   const u64 maskC = (n & 63) ? ((1ull << (n & 63)) - 1) : ~0ull;
   const long long row_base = (long long)blockIdx.x * (NT * RPT);
-  // lookups: chunk order c ^ s, copy r4
-  const int s = lane & 7, r4 = (lane >> 3) & 3;
+  // lookups: chunk order c ^ s, copy cp; NW = 4: lanes with hsw read the upper 16 bytes of an entry first
+  const int s = lane & 7, cp = (lane >> 3) & (COPIES - 1);
+  const int hsw = NW == 4 ? (lane >> 3) & 1 : 0;
   u32 selc[8], loc[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     const int cs = c ^ s;
     selc[c] = 0x0c0c000cu | ((u32)cs << 8);  // {0, 0, byte cs of the 64-bit word, 0}: v_perm_b32(high dword, low dword, sel)
-    loc[c] = (u32)((cs * 4 + r4) * 8);
+    loc[c] = (u32)((cs * COPIES + cp) * EB + hsw * 16);
   }
-  // build: lane = dword of the 256-byte table row: slot = lane >> 1 = 4 chunk + copy, dword lane & 1 of the 8-byte entry
-  const int bch = lane >> 3, bhalf = lane & 1;
+  // build: lane = dword of the 256-byte table row: slot = lane / (2 NW) = COPIES * chunk + copy, dword lane % (2 NW) of the entry
+  const int bch = (lane / (2 * NW)) / COPIES, bdw = lane % (2 * NW);
 
-  u32 acc[RPT][2];
+  u32 acc[RPT][2 * NW];
 #pragma unroll
-  for (int r = 0; r < RPT; ++r) acc[r][0] = acc[r][1] = 0;
+  for (int r = 0; r < RPT; ++r)
+#pragma unroll
+    for (int w = 0; w < 2 * NW; ++w) acc[r][w] = 0;
 
   // barrier that waits for this wave's LDS operations only: the loads of A stay in flight across it
   auto lds_barrier = []() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-  u64 *bstage = reinterpret_cast<u64 *>(lds + 128 * 1024);  // the 256 rows of B of a block of four generations (2 KiB)
+  u64 *bstage = reinterpret_cast<u64 *>(lds + 128 * 1024);  // the 256 rows of B of a block of four generations (2 NW KiB)
 
   for (int w0 = 0; w0 < wl; w0 += 4) {  // four 64-bit words of the inner dimension = four generations
     u64 aw[RPT][4];
@@ -1960,12 +1968,11 @@ __global__ __launch_bounds__(NT) void gf2_tallskinny4_kernel(const u64 *__restri
         aw[r][q] = x;
       }
     }
-    // the block's rows of B -> LDS (coalesced; the build reads them as broadcasts).  The barrier after the first build
-    // below makes them visible... to the first build itself they must be visible already: one barrier here.
-    lds_barrier();  // every wave is done with the previous block's rows
-    if (tid < 256) {
-      const long long brow = (long long)w0 * 64 + tid;
-      bstage[tid] = brow < l ? B[brow * ldb] : 0;
+    lds_barrier();  // every wave is done with the previous block's rows of B
+    for (int idx = tid; idx < 256 * NW; idx += NT) {
+      const long long brow = (long long)w0 * 64 + idx / NW;
+      const int w = idx % NW;
+      bstage[idx] = (brow < l && w < wn) ? B[brow * ldb + w] : 0;
     }
     lds_barrier();
     static_for<4>([&](auto gtag) __attribute__((always_inline)) {
@@ -1975,7 +1982,7 @@ __global__ __launch_bounds__(NT) void gf2_tallskinny4_kernel(const u64 *__restri
         // ---- build the generation: wave w owns entries [EPW w, EPW (w + 1)) ----
         u32 rr[8];
 #pragma unroll
-        for (int b = 0; b < 8; ++b) rr[b] = reinterpret_cast<const u32 *>(bstage + g * 64 + bch * 8 + b)[bhalf];
+        for (int b = 0; b < 8; ++b) rr[b] = reinterpret_cast<const u32 *>(bstage + (g * 64 + bch * 8 + b) * NW)[bdw];
         u32 cur = 0;
 #pragma unroll
         for (int b = LOWB; b < 8; ++b)
@@ -1996,20 +2003,37 @@ __global__ __launch_bounds__(NT) void gf2_tallskinny4_kernel(const u64 *__restri
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
           const u32 a0 = (u32)aw[r][g], a1 = (u32)(aw[r][g] >> 32);
-          u32 lo = acc[r][0], hi = acc[r][1];  // (locals: an asm operand inside this lambda cannot name the enclosing function's array)
+          u32 ac[2 * NW];  // (locals: an asm operand inside this lambda cannot name the enclosing function's array)
+#pragma unroll
+          for (int w = 0; w < 2 * NW; ++w) ac[w] = acc[r][w];
 #pragma unroll
           for (int c = 0; c < 8; c += 2) {
             const u32 o0 = __builtin_amdgcn_perm(a1, a0, selc[c]) | loc[c];
             const u32 o1 = __builtin_amdgcn_perm(a1, a0, selc[c + 1]) | loc[c + 1];
-            const u32x2v x = *reinterpret_cast<lds_cu32x2 *>(o0), y = *reinterpret_cast<lds_cu32x2 *>(o1);
-            asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(lo) : "v"(x.x), "v"(y.x));
-            asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(hi) : "v"(x.y), "v"(y.y));
+            if constexpr (NW == 1) {
+              const u32x2v x = *reinterpret_cast<lds_cu32x2 *>(o0), y = *reinterpret_cast<lds_cu32x2 *>(o1);
+              asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(ac[0]) : "v"(x.x), "v"(y.x));
+              asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(ac[1]) : "v"(x.y), "v"(y.y));
+            } else {
+              const u32x4 x = *reinterpret_cast<lds_cu32x4 *>(o0), y = *reinterpret_cast<lds_cu32x4 *>(o1);
+              asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(ac[0]) : "v"(x.x), "v"(y.x));
+              asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(ac[1]) : "v"(x.y), "v"(y.y));
+              asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(ac[2]) : "v"(x.z), "v"(y.z));
+              asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(ac[3]) : "v"(x.w), "v"(y.w));
+              if constexpr (NW == 4) {
+                const u32x4 x2 = *reinterpret_cast<lds_cu32x4 *>(o0 ^ 16u), y2 = *reinterpret_cast<lds_cu32x4 *>(o1 ^ 16u);
+                asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(ac[4]) : "v"(x2.x), "v"(y2.x));
+                asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(ac[5]) : "v"(x2.y), "v"(y2.y));
+                asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(ac[6]) : "v"(x2.z), "v"(y2.z));
+                asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(ac[7]) : "v"(x2.w), "v"(y2.w));
+              }
+            }
           }
-          acc[r][0] = lo;
-          acc[r][1] = hi;
+#pragma unroll
+          for (int w = 0; w < 2 * NW; ++w) acc[r][w] = ac[w];
         }
       }
-      // the next generation lives in the other buffer (also when this one was skipped: w0 + g >= wl only at the very end)
+      // the next generation lives in the other buffer
 #pragma unroll
       for (int c = 0; c < 8; ++c) loc[c] ^= 65536u;
     });
@@ -2018,10 +2042,21 @@ __global__ __launch_bounds__(NT) void gf2_tallskinny4_kernel(const u64 *__restri
   for (int r = 0; r < RPT; ++r) {
     const long long row = row_base + (long long)r * NT + tid;
     if (row < m) {
-      u64 v = ((u64)acc[r][0] | ((u64)acc[r][1] << 32)) & maskC;
-      u64 *d = C + row * ldc;
-      if (accumulate) v ^= *d;
-      *d = v;
+#pragma unroll
+      for (int w = 0; w < NW; ++w)
+        if (w < wn) {
+          // NW = 4: lanes that read the upper half first hold words 2, 3 in acc[0..3] and words 0, 1 in acc[4..7]
+          u32 lo = acc[r][2 * w], hi = acc[r][2 * w + 1];
+          if constexpr (NW == 4) {
+            lo = hsw ? acc[r][(2 * w) ^ 4] : lo;
+            hi = hsw ? acc[r][(2 * w + 1) ^ 4] : hi;
+          }
+          u64 v = (u64)lo | ((u64)hi << 32);
+          if (w == wn - 1) v &= maskC;
+          u64 *d = C + row * ldc + w;
+          if (accumulate) v ^= *d;
+          *d = v;
+        }
     }
   }
 }
@@ -2608,6 +2643,28 @@ extern "C" hipError_t gf2k_tallskinny(const u64 *A, long long lda, const u64 *B,
   // conflicts), below that its byte permutation costs more than the conflicts.  M4RI_HIP_TALLSKINNY_GEN=1 forces the first
   // kernel for every width (A/B runs).
   static const int forced_gen = getenv("M4RI_HIP_TALLSKINNY_GEN") ? atoi(getenv("M4RI_HIP_TALLSKINNY_GEN")) : 0;
+  // generation kernel: 13.6 -> 10.4 us for V = 64; for V = 128 it ties with the skewed kernel (15.9 against 16.0 us) and with
+  // 32-byte entries it runs out of registers (35 against 28 us), so it is used for n <= 64 (M4RI_HIP_TALLSKINNY_GEN4_NW=2: also
+  // for n <= 128, A/B runs)
+  static const int gen4_max_nw = getenv("M4RI_HIP_TALLSKINNY_GEN4_NW") ? atoi(getenv("M4RI_HIP_TALLSKINNY_GEN4_NW")) : 1;
+  if (forced_gen != 1 && forced_gen != 3 && nw <= (gen4_max_nw < 2 ? gen4_max_nw : 2)) {  // generation kernel (replicated tables, skew inside a 64-bit word)
+    constexpr int RPT4 = 4, NT4 = 1024;
+    const unsigned grid4 = (unsigned)(((long long)m + NT4 * RPT4 - 1) / (NT4 * RPT4));
+    const size_t lds4 = 128 * 1024 + 8 * 1024;
+    hipError_t e4;
+#define GF2_TS4_LAUNCH(NWV)                                                                                              \
+  e4 = lds_limit_once(reinterpret_cast<const void *>(&gf2_tallskinny4_kernel<NWV, RPT4, NT4>), (int)lds4);              \
+  if (e4 != hipSuccess) return e4;                                                                                       \
+  hipLaunchKernelGGL((gf2_tallskinny4_kernel<NWV, RPT4, NT4>), dim3(grid4), dim3(NT4), lds4, stream, A, lda, B, ldb, C, ldc, m, \
+                     l, n, accumulate)
+    if (nw == 1) {
+      GF2_TS4_LAUNCH(1);
+    } else {
+      GF2_TS4_LAUNCH(2);
+    }
+#undef GF2_TS4_LAUNCH
+    return hipGetLastError();
+  }
   if (nw >= 2 && forced_gen != 1) {
     constexpr int RPT3 = 4, NT3 = 1024;
     const unsigned grid3 = (unsigned)(((long long)m + NT3 * RPT3 - 1) / (NT3 * RPT3));
@@ -2624,16 +2681,6 @@ extern "C" hipError_t gf2k_tallskinny(const u64 *A, long long lda, const u64 *B,
       GF2_TS3_LAUNCH(4);
     }
 #undef GF2_TS3_LAUNCH
-    return hipGetLastError();
-  }
-  if (nw == 1 && forced_gen != 1) {  // replicated-table kernel (conflict-free 8-byte lookups)
-    constexpr int RPT4 = 4, NT4 = 1024;
-    const unsigned grid4 = (unsigned)(((long long)m + NT4 * RPT4 - 1) / (NT4 * RPT4));
-    const size_t lds4 = 128 * 1024 + 2048;
-    hipError_t e4 = lds_limit_once(reinterpret_cast<const void *>(&gf2_tallskinny4_kernel<RPT4, NT4>), (int)lds4);
-    if (e4 != hipSuccess) return e4;
-    hipLaunchKernelGGL((gf2_tallskinny4_kernel<RPT4, NT4>), dim3(grid4), dim3(NT4), lds4, stream, A, lda, B, ldb, C, ldc, m, l, n,
-                       accumulate);
     return hipGetLastError();
   }
   constexpr int RPT = 4, NT = 1024;

@@ -38,7 +38,7 @@ def main():
     run("2b: 4096^3, automatic", 4096, 4096, 4096, "auto", 200)
     run("3: 32768^3, Strassen over M4RM", 32768, 32768, 32768, "auto", 10)
     run("3b: 32768^3, M4RM only", 32768, 32768, 32768, "m4rm", 5)
-    for v in (1, 64, 256):
+    for v in (1, 64, 128, 256):
         run("5: LPN 2^20 x 256 times 256 x %d, naive entry" % v, 1 << 20, 256, v, "naive", 200)
 
 

@@ -10,7 +10,7 @@ from m4ri_rust_amd import device
 
 m, l = 1 << 20, 256
 A = device.DMat.random(m, l, 3)
-for V, algo in ((1, "naive"), (64, "naive"), (64, "m4rm"), (256, "m4rm"), (256, "naive")):
+for V, algo in ((1, "naive"), (64, "naive"), (64, "m4rm"), (128, "naive"), (256, "m4rm"), (256, "naive")):
     X = device.DMat.random(l, V, 4)
     C = device.DMat(m, V)
     for _ in range(3):
