@@ -24,7 +24,8 @@
 //    packed plain products).
 //  * few-tile products cut the inner dimension into slices (split-K); gf2_splitk_reduce_kernel XORs the partial tiles.
 //  * products with n <= 256 and many rows (batches of matrix x vector products) have their own Four-Russians kernels
-//    with tables over ALL of B in LDS (gf2_tallskinny_kernel, gf2_tallskinny3_kernel); n <= 8 uses an AND/popcount
+//    with tables over ALL of B in LDS (gf2_tallskinny4_kernel for n <= 64, gf2_tallskinny3_kernel above; gf2_tallskinny_kernel
+//    is the first form, kept for A/B runs); n <= 8 uses an AND/popcount
 //    kernel (gf2_narrow_kernel) that streams A at HBM speed.
 //  * everything else (Strassen split / merge passes, transpose, XOR, compare, fill) is an HBM-streaming kernel with
 //    16-byte accesses.  The elimination kernels live in gf2_elim.hip.
