@@ -1,0 +1,71 @@
+"""Every tile-kernel generation that ships in libm4ri_hip.so (the defaults and the ones kept for A/B runs) must produce the same
+bits: they are driven here through the internal launcher gf2k_m4rm (m4ri-rust_amd/csrc/gf2_kernels.h) on device buffers, against
+the first-generation kernel and against the product path the rest of the suite checks against the oracle."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev(built):
+    from m4ri_rust_amd import device
+    device.require_gpu()
+    return device
+
+
+class MulArgs(ctypes.Structure):  # gf2k_mul_args
+    _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p),
+                ("lda", ctypes.c_longlong), ("ldb", ctypes.c_longlong), ("ldc", ctypes.c_longlong),
+                ("sA", ctypes.c_longlong), ("sB", ctypes.c_longlong), ("sC", ctypes.c_longlong),
+                ("m", ctypes.c_int), ("l", ctypes.c_int), ("n", ctypes.c_int),
+                ("tiles_m", ctypes.c_int), ("tiles_n", ctypes.c_int), ("ksplit", ctypes.c_int), ("kwords", ctypes.c_int),
+                ("batch", ctypes.c_int), ("accumulate", ctypes.c_int),
+                ("Bp", ctypes.c_void_p), ("sBp", ctypes.c_longlong), ("bp_nc", ctypes.c_int),
+                ("P", ctypes.c_void_p), ("ldp", ctypes.c_longlong), ("sP", ctypes.c_longlong),
+                ("a_packed", ctypes.c_int)]
+
+
+@pytest.mark.parametrize("m,l,n,batch", [(2048, 2048, 2048, 2), (4160, 1000, 1100, 1), (300, 520, 2300, 3)])
+def test_tile_kernel_generations_agree(dev, m, l, n, batch):
+    import torch
+    from m4ri_rust_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    lib.gf2k_m4rm.restype = ctypes.c_int
+    lib.gf2k_m4rm.argtypes = [MulArgs, ctypes.c_int, ctypes.c_void_p]
+    lib.gf2k_packA.restype = ctypes.c_int
+    lib.gf2k_packA.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int,
+                               ctypes.c_void_p]
+    wa, wb = (l + 63) // 64, (n + 63) // 64
+    lda, ldb = (wa + 1) & ~1, (wb + 1) & ~1
+    As = [dev.DMat.random(m, l, 10 + i) for i in range(batch)]
+    Bs = [dev.DMat.random(l, n, 20 + i) for i in range(batch)]
+    A = torch.zeros((batch, m, lda), dtype=torch.int64, device="cuda")
+    B = torch.zeros((batch, l, ldb), dtype=torch.int64, device="cuda")
+    for i in range(batch):
+        A[i, :, :wa] = torch.from_numpy(As[i].to_words().view(np.int64)).cuda()
+        B[i, :, :wb] = torch.from_numpy(Bs[i].to_words().view(np.int64)).cuda()
+    expect = np.stack([dev.mul(As[i], Bs[i]).to_words() for i in range(batch)])  # the product path (oracle-checked elsewhere)
+    mp = (m + 63) & ~63
+    Apk = torch.zeros((batch, mp * lda), dtype=torch.int64, device="cuda")
+    for i in range(batch):
+        assert lib.gf2k_packA(Apk[i].data_ptr(), lda, A[i].data_ptr(), lda, m, wa, None) == 0
+
+    def run(cfg, packed=False, ksplit=1):
+        C = torch.full((batch, m, ldb), -1, dtype=torch.int64, device="cuda")
+        a = MulArgs()
+        a.A = (Apk if packed else A).data_ptr()
+        a.B, a.C = B.data_ptr(), C.data_ptr()
+        a.lda, a.ldb, a.ldc = lda, ldb, ldb
+        a.sA, a.sB, a.sC = (mp * lda if packed else m * lda), l * ldb, m * ldb
+        a.m, a.l, a.n, a.batch, a.ksplit, a.accumulate, a.a_packed = m, l, n, batch, ksplit, 0, int(packed)
+        assert lib.gf2k_m4rm(a, cfg, None) == 0, cfg
+        torch.cuda.synchronize()
+        return C.cpu().numpy().view(np.uint64)[:, :, :wb]
+
+    for cfg, packed, ks in [(0, False, 1), (1, False, 1), (7, False, 1), (20, False, 1), (80, False, 1), (8, False, 1), (9, False, 1),
+                            (8, True, 1), (9, True, 1), (7, False, 3), (8, False, 3), (9, True, 3)]:
+        got = run(cfg, packed, ks)
+        assert np.array_equal(got, expect), (cfg, packed, ks)
