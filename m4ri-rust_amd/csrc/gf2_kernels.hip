@@ -1212,6 +1212,10 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v7(const gf2k_mul_
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // DBG == 1: wall-clock stamps (s_memrealtime, 100 MHz) of the workgroup's phases and the CU it ran on, written to p.Bp
+  // (five 64-bit words per workgroup; kbench cfg 96 prints the per-tile overheads)
+  unsigned long long dbg_t0 = 0, dbg_t1 = 0, dbg_t2 = 0;
+  if constexpr (DBG == 1) dbg_t0 = __builtin_amdgcn_s_memrealtime();
   int t;
   {
     const int nwg = gridDim.x, bid = blockIdx.x;
@@ -1340,6 +1344,7 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v7(const gf2k_mul_
     build_write(it, std::integral_constant<u32, 0u>{});
   });
   __syncthreads();
+  if constexpr (DBG == 1) dbg_t1 = __builtin_amdgcn_s_memrealtime();
 
   // one quad: look word W of the slab (quad q) up in table W; build quad q+1 from `rows` into the other table; fetch the
   // rows of quad q+2 into `next`; the second quad of a slab reloads each row group's slab of A after its last use
@@ -1412,6 +1417,7 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v7(const gf2k_mul_
     quad_iter(j + 1, std::integral_constant<int, 1>{}, aw, rrA, rrB);
   }
 
+  if constexpr (DBG == 1) dbg_t2 = __builtin_amdgcn_s_memrealtime();
   // ---- epilogue: transpose through LDS (tables are dead), 128 rows x 64 bytes per wave at a time, 4 lanes per row ----
   {
     typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
@@ -1459,6 +1465,19 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v7(const gf2k_mul_
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if constexpr (DBG == 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores of C have left
+    const unsigned long long t3 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) {
+      unsigned long long *d = reinterpret_cast<unsigned long long *>(const_cast<uint32_t *>(p.Bp)) + (long long)blockIdx.x * 5;
+      const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+      d[0] = dbg_t0;
+      d[1] = dbg_t1;
+      d[2] = dbg_t2;
+      d[3] = t3;
+      d[4] = ((unsigned long long)xcc << 32) | hw;
     }
   }
 }
@@ -2536,6 +2555,7 @@ extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {
     case 93: e = a.a_packed ? launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2, 3, 1>, 512, a, nwg, stream) : hipErrorInvalidValue; break;  // no loads in the loop
     case 94: e = a.a_packed ? launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2, 4, 1>, 512, a, nwg, stream) : hipErrorInvalidValue; break;  // no table writes
     case 95: e = a.a_packed ? launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2, 6, 1>, 512, a, nwg, stream) : hipErrorInvalidValue; break;  // no XORs
+    case 96: e = (a.a_packed && a.Bp) ? launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2, 1, 1>, 512, a, nwg, stream) : hipErrorInvalidValue; break;  // phase stamps -> Bp
     case 80: e = launch_tile_kernel(&gf2_m4rm_kernel_v5<8, 256, 4>, 512, a, nwg, stream); break;  // paired chunks, 8 lanes per row
     case 81: e = launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 6>, 512, a, nwg, stream); break;
     case 82: e = launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 3>, 512, a, nwg, stream); break;

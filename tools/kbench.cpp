@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
+#include <utility>
 #include "../m4ri-rust_amd/csrc/gf2_kernels.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -41,6 +43,7 @@ int main(int argc, char **argv) {
     const int cfg = atoi(argv[i]);
     a.C = C;
     const bool pk = Apk && (cfg == 8 || cfg == 9 || (cfg >= 90 && cfg < 100));
+    if (cfg == 96) CK(hipMemset(Bp, 0, (size_t)bpBlocks * 2048 * batch));
     a.A = pk ? Apk : A;
     a.a_packed = pk ? 1 : 0;
     CK(hipMemset(C, 0xff, words * 8 * batch));
@@ -55,6 +58,27 @@ int main(int argc, char **argv) {
     const double macs = (double)n * n * n * batch;
     printf("cfg %d  n=%d batch=%d  %s  %.3f ms  %.2f Tbitmac/s  lds-read %.1f TB/s\n", cfg, n, batch,
            h == 0 ? "OK " : "MISMATCH", ms, macs / ms / 1e9, macs / 64 / ms / 1e9);
+    if (cfg == 96) {  // phase stamps of the v7 kernel (five u64 per workgroup in Bp): per-tile overheads
+      const long long nwg = (long long)((n + 4095) / 4096) * ((n + 511) / 512) * batch;
+      std::vector<unsigned long long> d(nwg * 5);
+      CK(hipMemcpy(d.data(), Bp, d.size() * 8, hipMemcpyDeviceToHost));
+      double pro = 0, loop = 0, epi = 0;
+      std::vector<std::pair<unsigned long long, std::pair<unsigned long long, unsigned long long>>> byc;  // (cu key, (start, end))
+      for (long long w = 0; w < nwg; ++w) {
+        pro += (double)(d[5 * w + 1] - d[5 * w]); loop += (double)(d[5 * w + 2] - d[5 * w + 1]); epi += (double)(d[5 * w + 3] - d[5 * w + 2]);
+        const unsigned hw = (unsigned)d[5 * w + 4]; const unsigned xcc = (unsigned)(d[5 * w + 4] >> 32) & 15;
+        const unsigned long long key = ((unsigned long long)xcc << 16) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15);
+        byc.push_back({key, {d[5 * w], d[5 * w + 3]}});
+      }
+      std::sort(byc.begin(), byc.end());
+      double gap = 0; long long ngap = 0; int ncu = 0;
+      for (size_t i = 0; i < byc.size(); ++i) {
+        if (i == 0 || byc[i].first != byc[i - 1].first) { ++ncu; continue; }
+        gap += (double)((long long)byc[i].second.first - (long long)byc[i - 1].second.second); ++ngap;
+      }
+      printf("   per workgroup (10 ns ticks -> us): prologue %.2f  loop %.2f  epilogue+stores %.2f; %d CUs, gap between consecutive workgroups on a CU %.2f us\n",
+             pro / nwg / 100, loop / nwg / 100, epi / nwg / 100, ncu, ngap ? gap / ngap / 100 : 0.0);
+    }
     if (cfg == 49) {
       unsigned long long d[8]; CK(gf2k_dbg_sec(d));
       for (int w = 0; w < 2; ++w)
