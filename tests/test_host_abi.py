@@ -242,3 +242,18 @@ def test_serde_wire_format(pkg):
     assert back == big and back.ncols() == 130
     v = pkg.BinVector.from_bools([True, False, True])
     assert v.to_json() == '{"vec":{"len":3,"vec":[5]}}' and pkg.BinVector.from_json(v.to_json()) == v
+
+
+def test_workspace_and_level_queries_without_gpu(pkg):
+    """gf2_mul_workspace_bytes / gf2_strassen_levels are pure host arithmetic (no device needed): the Strassen arena of the
+    metric's configuration, and the packed copy of A that a tall plain product stages (include/m4ri_hip.h section 2)."""
+    lib = pkg._lib.lib()
+    AUTO, M4RM = pkg._lib.ALGO_AUTO, pkg._lib.ALGO_M4RM
+    assert lib.gf2_strassen_levels(65536, 65536, 65536, AUTO, 0) == 4
+    assert lib.gf2_strassen_levels(65536, 65536, 65536, M4RM, 0) == 0
+    assert lib.gf2_strassen_levels(1000, 1000, 1000, AUTO, 0) == 0
+    arena = lib.gf2_mul_workspace_bytes(65536, 65536, 65536, AUTO, 0)
+    assert 18 * 2**30 < arena < 20 * 2**30            # DESIGN.md section 3: 18.7 GiB
+    assert lib.gf2_mul_workspace_bytes(65536, 65536, 65536, M4RM, 0) == 65536 * 1024 * 8   # packed copy of A, same footprint
+    assert lib.gf2_mul_workspace_bytes(1000, 1000, 1000, M4RM, 0) == 0
+    assert lib.gf2_mul_workspace_bytes(2049, 70, 1024, M4RM, 0) == 2112 * 2 * 8             # rows padded to 64, even word count
