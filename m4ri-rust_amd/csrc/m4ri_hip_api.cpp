@@ -1022,7 +1022,45 @@ mzd_t *host_mul(mzd_t *C, const mzd_t *A, const mzd_t *B, int accumulate, int al
     return bail("stream");
   }
   int rc = 0;
-  {
+  // Large products are pipelined over row blocks of A and C: C[R,:] = A[R,:] B.  A copy stream uploads B and the blocks of A
+  // and later downloads the blocks of C, the compute stream multiplies block i as soon as it has arrived -- the upload of the
+  // later blocks and the download of the earlier ones overlap the products (PCIe is most of a host call: 1.5 GiB at n = 65536).
+  static const int pipe_blocks = env_int("M4RI_HIP_HOST_PIPELINE_BLOCKS", 4);
+  const bool plain_layout = !(A->flags & mzd_flag_windowed_zerooffset) && !(C->flags & mzd_flag_windowed_zerooffset) &&
+                            A->rowstride >= 1 && C->rowstride >= 1;
+  gf2_dmat cached{};
+  static const int strassen_overlap = env_int("M4RI_HIP_STRASSEN_OVERLAP", 0);  // that experiment uses the same side stream
+  if (pipe_blocks >= 2 && !strassen_overlap && !accumulate && plain_layout && A->nrows >= 16384 && A->nrows % (pipe_blocks * 64) == 0 &&
+      (long long)A->ncols * B->ncols >= (1ll << 28) && !cache_lookup(A, &cached)) {
+    SideStream *side = nullptr;
+    rc = side_stream(s, 2 * pipe_blocks + 1, &side);
+    DMatOwner dA, dB, dC;
+    if (!rc) rc = to_device(dB, B, side->s2, true);
+    if (!rc) rc = to_device(dA, A, s, false);
+    if (!rc) rc = to_device(dC, C, s, false);
+    const int R = A->nrows / pipe_blocks;
+    auto rows_bytes = [](const mzd_t *M, int rows) { return ((size_t)(rows - 1) * M->rowstride + M->width) * sizeof(word); };
+    if (!rc && (dA.d.ld != A->rowstride || dC.d.ld != C->rowstride)) rc = fail_msg("host pipeline: unexpected device stride");
+    for (int i = 0; !rc && i < pipe_blocks; ++i) {  // copy stream: B (above), then the blocks of A in order
+      if (hipMemcpyAsync(dA.d.data + (size_t)i * R * dA.d.ld, A->rows[i * R], rows_bytes(A, R), hipMemcpyHostToDevice, side->s2) != hipSuccess ||
+          hipEventRecord(side->ev[i], side->s2) != hipSuccess)
+        rc = fail(hipGetLastError(), "host pipeline: upload");
+    }
+    for (int i = 0; !rc && i < pipe_blocks; ++i) {
+      gf2_dmat a = dA.d, c = dC.d;
+      a.data += (size_t)i * R * a.ld;
+      c.data += (size_t)i * R * c.ld;
+      a.nrows = c.nrows = R;
+      if (hipStreamWaitEvent(s, side->ev[i], 0) != hipSuccess) rc = fail(hipGetLastError(), "host pipeline: wait");
+      if (!rc) rc = mul_dispatch(&c, &a, &dB.d, 0, algo, param, s, /*sync_free=*/false);
+      if (!rc && (hipEventRecord(side->ev[pipe_blocks + i], s) != hipSuccess ||
+                  hipStreamWaitEvent(side->s2, side->ev[pipe_blocks + i], 0) != hipSuccess ||
+                  hipMemcpyAsync(C->rows[i * R], c.data, rows_bytes(C, R), hipMemcpyDeviceToHost, side->s2) != hipSuccess))
+        rc = fail(hipGetLastError(), "host pipeline: download");
+    }
+    if (side && hipStreamSynchronize(side->s2) != hipSuccess && !rc) rc = fail(hipGetLastError(), "host pipeline: copy stream");
+    if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = fail(hipGetLastError(), "host pipeline: compute stream");
+  } else {
     DMatOwner dA, dB, dC;
     rc = to_device(dA, A, s, true);
     if (!rc) rc = to_device(dB, B, s, true);

@@ -297,6 +297,23 @@ def test_packed_plain_product_2gib_operand(dev):
     assert np.array_equal(dev.mul(Aw, B, algo="m4rm").to_words(), C1.to_words()[r0:r0 + rows])
 
 
+def test_host_product_pipelined_over_row_blocks(pkg, dev):
+    """Host products with >= 16384 rows are pipelined over four row blocks of A and C (uploads, products and downloads on two
+    streams).  Same bits as the device-resident product; ragged column counts; back-to-back calls reuse the streams and events."""
+    m, l, n = 16384, 16384 + 192, 16384 + 77
+    A, B = pkg.BinMatrix.random(m, l), pkg.BinMatrix.random(l, n)
+    a, b = A.to_words(), B.to_words()
+    ref = dev.mul(dev.DMat.from_words(a, l), dev.DMat.from_words(b, n)).to_words()
+    for _ in range(2):
+        assert np.array_equal((A * B).to_words(), ref)
+    rows = np.array([0, 4095, 4096, 8191, 12288, m - 1])
+    assert np.array_equal(ref[rows], g.o_mul_m4rm(np.ascontiguousarray(a[rows]), b, len(rows), l, n))
+    # a row count the blocks do not divide takes the unpipelined route
+    A2 = pkg.BinMatrix.random(m + 64, l)
+    ref2 = dev.mul(dev.DMat.from_words(A2.to_words(), l), dev.DMat.from_words(b, n)).to_words()
+    assert np.array_equal((A2 * B).to_words(), ref2)
+
+
 def test_dev_properties_full_size(dev):
     """Size-independent properties at a BASELINE config size (32768): linearity in B and
     associativity with a vector, (A*B)*x == A*(B*x)."""
