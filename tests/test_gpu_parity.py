@@ -308,6 +308,21 @@ def test_host_product_pipelined_over_row_blocks(pkg, dev):
         assert np.array_equal((A * B).to_words(), ref)
     rows = np.array([0, 4095, 4096, 8191, 12288, m - 1])
     assert np.array_equal(ref[rows], g.o_mul_m4rm(np.ascontiguousarray(a[rows]), b, len(rows), l, n))
+    # three threads at once (every thread has its own pair of streams and events)
+    import threading
+    L, bad = pkg._lib.lib(), []
+
+    def worker():
+        c = L.mzd_mul(None, A.mzd, B.mzd, 0)
+        if not c or not np.array_equal(pkg.BinMatrix(c).to_words(), ref):
+            bad.append(1)
+
+    ts = [threading.Thread(target=worker) for _ in range(3)]
+    for t_ in ts:
+        t_.start()
+    for t_ in ts:
+        t_.join()
+    assert not bad
     # a row count the blocks do not divide takes the unpipelined route
     A2 = pkg.BinMatrix.random(m + 64, l)
     ref2 = dev.mul(dev.DMat.from_words(A2.to_words(), l), dev.DMat.from_words(b, n)).to_words()
