@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 // One (batched) product C (+)= A*B on dense device buffers; strides in 64-bit words.
+// (tests/test_gpu_kernel_variants.py mirrors this struct with ctypes: keep the two in step.)
 struct gf2k_mul_args {
   const uint64_t *A;
   const uint64_t *B;
