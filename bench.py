@@ -40,6 +40,63 @@ def _cpu_model():
     return "unknown"
 
 
+def _launch_ranks(n):
+    import socket
+    import subprocess
+    with socket.socket() as sk:  # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs between processes on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def _cpu_baseline(args):
+    """The reported CPU baseline, run BEFORE the GPU loop (rank 0, N = 1): oracle_mul_fast, the single-thread port of the
+    reference's algorithm (M4RI itself is absent), on one bounded sample product; plus a threaded figure, labelled
+    non-reference.  Returns (json object, sample product words)."""
+    import numpy as np
+    import gf2util as g
+    cn = args.cpu_n
+    a, b = g.random_words(cn, cn, 1), g.random_words(cn, cn, 2)
+    g.oracle()
+    t1 = time.perf_counter()
+    c = g.o_mul_fast(a, b, cn, cn, cn)
+    cdt = time.perf_counter() - t1
+    out = {
+        "value": 2.0 * cn ** 3 / cdt, "unit": "bit-ops/s", "cores": 1, "kind": "port",
+        "sample": "one %dx%dx%d product by oracle_mul_fast (single-thread M4RM k=8 + Strassen-Winograd, "
+                  "gcc -Ofast, no -march), %.2f s; M4RI itself is absent from the reference tree" % (cn, cn, cn, cdt),
+        "host_cpus": os.cpu_count(), "host_cpu_model": _cpu_model(),
+    }
+    # optional second figure (SURVEY.md section 8d): the same port on several cores, row blocks of A in threads
+    # (ctypes releases the GIL).  NOT the reference's configuration: its M4RI build is single-threaded.
+    nthr = min(args.cpu_threads, os.cpu_count() or 1, cn // 2048)
+    if nthr > 1:
+        import threading
+        blk = cn // nthr
+        outs = [None] * nthr
+
+        def work(k):
+            outs[k] = g.o_mul_fast(np.ascontiguousarray(a[k * blk:(k + 1) * blk]), b, blk, cn, cn)
+
+        t1 = time.perf_counter()
+        ths = [threading.Thread(target=work, args=(k,)) for k in range(nthr)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        mdt = time.perf_counter() - t1
+        out["threaded_port"] = {
+            "value": 2.0 * (blk * nthr) * cn * cn / mdt, "unit": "bit-ops/s", "cores": nthr,
+            "matches_single_core": bool(np.array_equal(np.concatenate(outs), c[:blk * nthr])),
+            "note": "non-reference configuration (the reference builds M4RI single-threaded): row blocks of A in %d threads, %.2f s" % (nthr, mdt)}
+    return out, c
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -65,6 +122,12 @@ def main():
                          "workload), sparse = 1/64, ones = all ones (clock / data-dependence sanity runs, SURVEY.md section 8d)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: start the N ranks ourselves as fresh child processes (torch.distributed.run, one
+        # rank per GPU) BEFORE anything in this process has touched the GPU, relay their output (rank 0 prints the JSON
+        # line) and leave with their exit code.  Nothing is exec'ed and this parent never initialises HIP.
+        sys.exit(_launch_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
 
@@ -72,8 +135,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the multiply path has no CPU fallback")
@@ -149,6 +210,14 @@ def main():
         else:
             device.mul(A, B, C=C, algo=args.algo, param=args.levels, stream=stream)
 
+    # the CPU baseline leg first (N = 1 only): the timed GPU loop then ends the run, so a driver-side utilisation sample
+    # taken near the end sees the GPU busy
+    cpu_baseline, cpu_sample = (None, None)
+    if world == 1 and not args.no_cpu:
+        cpu_baseline, cpu_sample = _cpu_baseline(args)
+        if not args.check:
+            cpu_sample = None
+
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -204,7 +273,7 @@ def main():
     achieved = alg_bytes_launch / (avg_kernel_ms * 1e-3) / 1e9 if launches else 0.0
     # on-chip view: every 8 bits of the inner dimension cost one 16-byte LDS read per 128 columns
     lds_bytes_launch = batch * (mi * (li / 8.0) * (ni / 128.0) * 16.0)
-    traffic = None
+    traffic, traffic_source = None, "not measured in this run (HBM counters need rocprofv3 --pmc passes)"
     tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tfile):
         try:
@@ -212,6 +281,8 @@ def main():
                 tj = json.load(f)
             if tj.get("n") == n and tj.get("levels") == levels and tj.get("n_gpus") == world:
                 traffic = tj.get("hbm_bytes_per_launch") * tj.get("launches_per_product", 1) / lps
+                traffic_source = "replayed: profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this " \
+                                 "command in a builder run, %s); not measured in this run" % tj.get("source", "see profiles/INDEX.md")
         except Exception:
             traffic = None
     out = {
@@ -223,13 +294,15 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "strong" if world > 1 else "weak",
+        "scaling": "strong",  # total work (one n^3 product) is fixed as N grows: rows of A are divided among the ranks
         "vs_baseline": None,
         "dtype": "u64",
         "data": "synthetic" if args.density == "half" else "synthetic, bit density %s" % args.density,
         "config": {
-            "workload": "GF(2) %dx%dx%d matmul, inputs resident in HBM, %s" % (
-                n, n, n, "Strassen(%d levels)-over-M4RM" % levels if levels else "M4RM only"),
+            "workload": "GF(2) %dx%dx%d matmul, inputs resident in HBM, %s%s" % (
+                n, n, n, "Strassen(%d levels)-over-M4RM" % levels if levels else "M4RM only",
+                "; per step: B (resident on rank 0) reaches the %d ranks in %d column panels, every rank multiplies its %d-row block "
+                "of A by each panel, the %d x %d blocks of C are gathered on rank 0" % (world, P, rows, rows, ncp) if world > 1 else ""),
             "n": n, "algo": args.algo, "strassen_levels": levels,
             "parallelism": "row-block shard of A over %d GPU(s)%s" % (
                 world, ", B in %d column panels: RCCL %s(panel p+1) / gather(C panel p-1) overlap the product of panel p" % (
@@ -243,7 +316,7 @@ def main():
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "frac_of_measured_copy": achieved / HBM_COPY_GBS,
-            "traffic": traffic,
+            "traffic": traffic, "traffic_source": traffic_source,
             "launches": launches, "avg_launch_ms": avg_kernel_ms,
             "algorithmic_bytes_per_launch": alg_bytes_launch,
             "note": "this kernel is LDS-bound, not HBM-bound (see onchip); HBM fraction is small by construction",
@@ -280,48 +353,15 @@ def main():
                                   "frac": pass_bytes / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                   "note": "step time minus the tile-kernel launch; split2/merge2 kernels, 16-byte accesses"}
 
-    if world == 1 and not args.no_cpu:
-        import numpy as np
-        import gf2util as g
-        cn = args.cpu_n
-        a, b = g.random_words(cn, cn, 1), g.random_words(cn, cn, 2)
-        g.oracle()
-        t1 = time.perf_counter()
-        c = g.o_mul_fast(a, b, cn, cn, cn)
-        cdt = time.perf_counter() - t1
-        out["cpu_baseline"] = {
-            "value": 2.0 * cn ** 3 / cdt, "unit": "bit-ops/s", "cores": 1, "kind": "port",
-            "sample": "one %dx%dx%d product by oracle_mul_fast (single-thread M4RM k=8 + Strassen-Winograd, "
-                      "gcc -Ofast, no -march), %.2f s; M4RI itself is absent from the reference tree" % (cn, cn, cn, cdt),
-            "host_cpus": os.cpu_count(), "host_cpu_model": _cpu_model(),
-        }
-        # optional second figure: the same port on several cores, row blocks of A in threads
-        # (ctypes releases the GIL).  NOT the reference's configuration: its M4RI build is single-threaded.
-        nthr = min(args.cpu_threads, os.cpu_count() or 1, cn // 2048)
-        if nthr > 1:
-            import threading
-            blk = cn // nthr
-            outs = [None] * nthr
-
-            def work(k):
-                outs[k] = g.o_mul_fast(np.ascontiguousarray(a[k * blk:(k + 1) * blk]), b, blk, cn, cn)
-
-            t1 = time.perf_counter()
-            ths = [threading.Thread(target=work, args=(k,)) for k in range(nthr)]
-            for th in ths:
-                th.start()
-            for th in ths:
-                th.join()
-            mdt = time.perf_counter() - t1
-            out["cpu_baseline"]["threaded_port"] = {
-                "value": 2.0 * (blk * nthr) * cn * cn / mdt, "unit": "bit-ops/s", "cores": nthr,
-                "matches_single_core": bool(np.array_equal(np.concatenate(outs), c[:blk * nthr])),
-                "note": "non-reference configuration (the reference builds M4RI single-threaded): row blocks of A in %d threads, %.2f s" % (nthr, mdt)}
-        if args.check and cn <= n:
+    if cpu_baseline is not None:
+        out["cpu_baseline"] = cpu_baseline
+        if args.check and cpu_sample is not None and args.cpu_n <= n:
             # the GPU must reproduce the CPU sample product bit for bit
+            import numpy as np
+            cn = args.cpu_n
             Ad, Bd = device.DMat.random(cn, cn, 1), device.DMat.random(cn, cn, 2)
             out["cpu_baseline"]["gpu_matches_cpu_sample"] = bool(
-                np.array_equal(device.mul(Ad, Bd, algo=args.algo, param=args.levels).to_words(), c))
+                np.array_equal(device.mul(Ad, Bd, algo=args.algo, param=args.levels).to_words(), cpu_sample))
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

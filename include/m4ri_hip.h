@@ -149,9 +149,13 @@ enum { GF2_ALGO_AUTO = 0, GF2_ALGO_M4RM = 1, GF2_ALGO_STRASSEN = 2, GF2_ALGO_NAI
 int gf2_device_count(void);                 /* usable HIP devices (0 if none) */
 const char *gf2_last_error(void);           /* thread-local text of the last failure */
 
-/* allocation helpers (hipMalloc / hipFree on the current device) */
+/* allocation helpers (pooled hipMalloc on the current device).  gf2_dmat_free has hipFree's semantics: it waits for the
+ * owning device (the API above is asynchronous; queued work may still use the block) before the block is recycled.
+ * gf2_dmat_free_async recycles the block once everything queued on `stream` SO FAR has completed: for matrices that were
+ * only used on that one stream (temporaries of a chain of products). */
 int gf2_dmat_alloc(gf2_dmat *M, int nrows, int ncols);
 void gf2_dmat_free(gf2_dmat *M);
+int gf2_dmat_free_async(gf2_dmat *M, void *stream);
 int gf2_dmat_upload(gf2_dmat *dst, mzd_t const *src, void *stream);   /* host mzd_t -> device; returns after the copy */
 int gf2_dmat_download(mzd_t *dst, gf2_dmat const *src, void *stream); /* device -> host mzd_t */
 int gf2_dmat_fill_random(gf2_dmat *M, uint64_t seed, void *stream);   /* splitmix64 stream, same as the oracle */
@@ -185,11 +189,23 @@ int gf2_strassen_levels(int m, int l, int n, int algo, int param);
  * the library keeps one cached arena per device and grows it on demand. */
 size_t gf2_mul_workspace_bytes(int m, int l, int n, int algo, int param);
 
+/* One process, several devices (north_star: "shard row-blocks of A across the GPUs of one node"): C = A*B on host
+ * matrices with the rows of A and C divided among `devices` (ndev ordinals in hipGetDeviceCount's numbering; an ordinal may
+ * repeat = several shares on one device).  Every share uploads its rows of A and its own copy of B over its own PCIe
+ * link, multiplies and downloads its rows of C; the inner dimension is never split, so there is no reduction.  C NULL:
+ * allocated.  Returns C, or NULL on failure.  algo / param as gf2_mul_dev.
+ * The drop-in entry points (mzd_mul, mzd_mul_m4rm, mzd_mul_naive, strassen.rs:18 / brilliantrussian.rs:216 / mzd.rs:152) do
+ * the same by themselves when more than one device is visible and the product is large (>= 7e13 bit operations, >= 4096
+ * rows per share); M4RI_HIP_DEVICES = "auto" (default) | "all" | "0,1,..." overrides (a single ordinal pins the product to
+ * that device). */
+mzd_t *gf2_mul_multi(mzd_t *C, mzd_t const *A, mzd_t const *B, int algo, int param, const int *devices, int ndev);
+
 /* Operand cache for the drop-in entry points: keep a device copy of the host matrix M until gf2_mzd_uncache(M) or
  * mzd_free(M); mzd_mul* calls whose A or B is M then skip its upload (repeated A*v with a fixed A -- mul_slice,
  * binary_matrix.rs:416-431 -- is otherwise bound by moving A over PCIe on every call).  The caller promises not to
- * change M's bits through the host pointers meanwhile; library calls that write M (as destination, mzd_echelonize,
- * mzd_solve_left, ...) drop the copy themselves. */
+ * change M's bits through the host pointers meanwhile (mzd_write_bit and friends on the Rust side are plain stores the
+ * library cannot see); library calls that write M or a window of M (as destination, mzd_echelonize, mzd_solve_left, ...)
+ * drop the copy themselves: the cache is keyed by the block that M and its windows share. */
 int gf2_mzd_cache_on_device(mzd_t const *M);
 void gf2_mzd_uncache(mzd_t const *M);
 

@@ -86,6 +86,7 @@ _PROTOS = {
     "gf2_last_error": (ctypes.c_char_p, []),
     "gf2_dmat_alloc": (_I, [DMatP, _I, _I]),
     "gf2_dmat_free": (None, [DMatP]),
+    "gf2_dmat_free_async": (_I, [DMatP, ctypes.c_void_p]),
     "gf2_dmat_upload": (_I, [DMatP, MzdP, ctypes.c_void_p]),
     "gf2_dmat_download": (_I, [MzdP, DMatP, ctypes.c_void_p]),
     "gf2_dmat_fill_random": (_I, [DMatP, ctypes.c_uint64, ctypes.c_void_p]),
@@ -100,6 +101,7 @@ _PROTOS = {
     "gf2_echelonize_dev": (_I, [DMatP, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.c_void_p]),
     "gf2_inverse_dev": (_I, [DMatP, DMatP, ctypes.POINTER(_I), ctypes.c_void_p]),
     "gf2_mul_workspace_bytes": (ctypes.c_size_t, [_I, _I, _I, _I, _I]),
+    "gf2_mul_multi": (MzdP, [MzdP, MzdP, MzdP, _I, _I, ctypes.POINTER(_I), _I]),
     "gf2_mzd_cache_on_device": (_I, [MzdP]),
     "gf2_mzd_uncache": (None, [MzdP]),
     "gf2_trim": (_I, []),

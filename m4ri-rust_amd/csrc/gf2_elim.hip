@@ -513,10 +513,10 @@ __global__ __launch_bounds__(1024) void gf2_elim_small_kernel(u64 *__restrict__ 
       continue;
     }
     if (p != rank) {
-      if (tid >= cw && tid < aw) {  // both rows are zero left of the column
-        const u64 t = M[rank * stride + tid];
-        M[rank * stride + tid] = M[p * stride + tid];
-        M[p * stride + tid] = t;
+      for (int w = cw + tid; w < aw; w += 1024) {  // both rows are zero left of the column; rows may be wider than 1024 words
+        const u64 t = M[rank * stride + w];
+        M[rank * stride + w] = M[p * stride + w];
+        M[p * stride + w] = t;
       }
     }
     __syncthreads();

@@ -69,10 +69,12 @@ int gf2k_m4rm_cols_per_tile(int cfg);
 // row-group-packed copy of A for gf2k_mul_args::a_packed: dst holds ceil(m/64)*64 rows of wp (even, >= w) words
 hipError_t gf2k_packA(uint64_t *dst, long long wp, const uint64_t *src, long long lds_, int m, int w, hipStream_t stream);
 hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream);
+#ifdef GF2K_DEV_VARIANTS  // development builds only (tools/libm4ri_hip_dev.so): diagnostics and the chunk-packed B experiment
 hipError_t gf2k_dbg_sec(unsigned long long *out8);
 int gf2k_packB_chunks(int l);
 hipError_t gf2k_packB(uint32_t *Bp, long long bpStride, const uint64_t *B, long long ldb, long long bStride, int l, int n,
                       int batch, hipStream_t stream);
+#endif
 hipError_t gf2k_rowparity(const uint64_t *A, long long lda, const uint64_t *Bt, long long ldbt, uint64_t *C, long long ldc,
                           int m, int l, int n, int accumulate, hipStream_t stream);
 hipError_t gf2k_narrow(const uint64_t *A, long long lda, const uint64_t *B, long long ldb, uint64_t *C, long long ldc,

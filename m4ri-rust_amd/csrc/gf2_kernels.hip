@@ -63,195 +63,6 @@ struct Log2<1> {
   static constexpr int value = 0;
 };
 
-template <int WAVES, int RPW>
-__global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel(const gf2k_mul_args p) {
-  constexpr int NT = WAVES * 64;
-  constexpr int R = WAVES * RPW;
-  constexpr int STEPS = RPW / 4;  // 4 rows (one per 16-lane group) per ds_read_b128
-  extern __shared__ __align__(16) unsigned char lds[];
-  unsigned char *const stg = lds + 2 * kTableBytes;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-  // XCD-aware, bijective remap: blocks b and b+8 share an XCD (L2); give each XCD a contiguous
-  // range of logical tiles so that the row tiles sharing a B column panel sit in one L2.
-  int t;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int tm = t % p.tiles_m;
-  t /= p.tiles_m;
-  const int tn = t % p.tiles_n;
-  const int bt = t / p.tiles_n;
-
-  const u64 *__restrict__ A = p.A + (long long)bt * p.sA;
-  const u64 *__restrict__ B = p.B + (long long)bt * p.sB;
-  u64 *__restrict__ C = p.C + (long long)bt * p.sC;
-
-  const int row0 = tm * R, w0 = tn * kTileWords;
-  const int widthA = (p.l + 63) >> 6, widthB = (p.n + 63) >> 6;
-  const u64 maskA = (p.l & 63) ? ((1ull << (p.l & 63)) - 1) : ~0ull;
-  const u64 maskC = (p.n & 63) ? ((1ull << (p.n & 63)) - 1) : ~0ull;
-
-  const int g = lane >> 4, qd = lane & 15;
-  const u32 laneoff0 = (u32)qd * 16u;        // byte offset inside a table row, table 0
-  const u32 laneoff1 = laneoff0 | 0x10000u;  // same, table 1 (at +64 KiB)
-  const int myrow0 = row0 + wave * RPW + g;  // row of step s = myrow0 + 4*s
-
-  uint4 acc[STEPS];
-#pragma unroll
-  for (int s = 0; s < STEPS; ++s) acc[s] = make_uint4(0, 0, 0, 0);
-
-  // B staging: 512 pieces of 32 B (64 rows x 8 pieces) per 64-bit block of the inner dimension
-  constexpr int PIECES = (512 + NT - 1) / NT;
-  uint4 breg[PIECES][2];
-  auto loadB = [&](int lb) {
-#pragma unroll
-    for (int i = 0; i < PIECES; ++i) {
-      const int pc = tid + i * NT;
-      const int brow = lb * 64 + (pc >> 3), wd = w0 + (pc & 7) * 4;
-      uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
-      if (pc < 512 && brow < p.l) {
-        const u64 *src = B + (long long)brow * p.ldb + wd;
-        if (wd + 3 < widthB) {
-          v0 = *reinterpret_cast<const uint4 *>(src);
-          v1 = *reinterpret_cast<const uint4 *>(src + 2);
-        } else {
-          u64 x0 = (wd + 0 < widthB) ? src[0] : 0, x1 = (wd + 1 < widthB) ? src[1] : 0;
-          u64 x2 = (wd + 2 < widthB) ? src[2] : 0;
-          v0 = make_uint4((u32)x0, (u32)(x0 >> 32), (u32)x1, (u32)(x1 >> 32));
-          v1 = make_uint4((u32)x2, (u32)(x2 >> 32), 0, 0);
-        }
-      }
-      breg[i][0] = v0;
-      breg[i][1] = v1;
-    }
-  };
-  auto storeB = [&]() {
-#pragma unroll
-    for (int i = 0; i < PIECES; ++i) {
-      const int pc = tid + i * NT;
-      if (pc < 512) {
-        uint4 *d = reinterpret_cast<uint4 *>(stg + (pc >> 3) * 256 + (pc & 7) * 32);
-        d[0] = breg[i][0];
-        d[1] = breg[i][1];
-      }
-    }
-  };
-
-  // table build: half-wave hw owns entries [hw*EPH, (hw+1)*EPH); lane j of the half owns word j.
-  constexpr int EPH = 256 / (2 * WAVES);
-  constexpr int LOWB = Log2<EPH>::value;
-  const int hw = wave * 2 + (lane >> 5), jw = lane & 31;
-  auto build = [&](int c, int tb) {
-    u64 rr[8];
-#pragma unroll
-    for (int b = 0; b < 8; ++b) rr[b] = *reinterpret_cast<const u64 *>(stg + (8 * c + b) * 256 + jw * 8);
-    u64 cur = 0;
-#pragma unroll
-    for (int b = LOWB; b < 8; ++b)
-      if ((hw >> (b - LOWB)) & 1) cur ^= rr[b];
-    unsigned char *dst = lds + tb * kTableBytes + (hw << LOWB) * 256 + jw * 8;
-    *reinterpret_cast<u64 *>(dst) = cur;
-    unsigned e = 0;
-#pragma unroll
-    for (int i = 1; i < EPH; ++i) {
-      const int bit = __builtin_ctz(i);
-      cur ^= rr[bit];
-      e ^= 1u << bit;
-      *reinterpret_cast<u64 *>(dst + e * 256) = cur;
-    }
-  };
-
-  // A words are kept as 32-bit halves (one register per row): half h of 64-bit block lb is loaded
-  // while the previous half's last table is still being consumed, so the load latency sits under a
-  // table build + barrier.
-  u32 aw[STEPS];
-  const u32 maskA_lo = (u32)maskA, maskA_hi = (u32)(maskA >> 32);
-  // uniform tile base + 32-bit per-lane byte offsets; the offsets are recomputed per load (2 VALU)
-  // instead of being kept in 2*STEPS address registers -- the asm barrier stops hipcc hoisting them.
-  const char *const Atile = reinterpret_cast<const char *>(A + (long long)row0 * p.lda);
-  const u32 ldaB = (u32)p.lda * 8u;
-  const u32 rowoff0 = (u32)(wave * RPW + g) * ldaB;
-  const u32 maxoff = (u32)(min(p.m - row0, R) - 1) * ldaB;  // rows past m are clamped, computed, never stored
-  auto loadA = [&](int lb, int half) {
-    u32 ro = rowoff0;
-    asm volatile("" : "+v"(ro));
-    const char *base = Atile + (long long)lb * 8 + half * 4;
-    const u32 msk = (lb == widthA - 1) ? (half ? maskA_hi : maskA_lo) : 0xffffffffu;
-#pragma unroll
-    for (int s = 0; s < STEPS; ++s) {
-      const u32 off = min(ro + (u32)s * 4u * ldaB, maxoff);
-      aw[s] = *reinterpret_cast<const u32 *>(base + off) & msk;
-    }
-  };
-
-  const int nlb = widthA;
-  if (nlb > 0) {
-    loadB(0);
-    loadA(0, 0);
-  }
-  for (int lb = 0; lb < nlb; ++lb) {
-    storeB();  // safe: every build of the previous block finished before its last barrier
-    if (lb + 1 < nlb) loadB(lb + 1);
-    __syncthreads();
-    const int lbits = p.l - lb * 64;  // valid bits in this block (>0)
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-#pragma unroll 1
-      for (int c4 = 0; c4 < 4; ++c4) {
-        const int c = half * 4 + c4;
-        if (c * 8 >= lbits) break;  // workgroup-uniform
-        const int tb = c4 & 1;
-        build(c, tb);
-        __syncthreads();
-        const u32 lo = tb ? laneoff1 : laneoff0;
-        // v_perm_b32 selector: byte0 <- lo.byte0, byte1 <- aw.byte[c4], byte2 <- lo.byte2, byte3 <- 0
-        const u32 sel = 0x0c020000u | ((4u + (u32)c4) << 8);
-#pragma unroll
-        for (int s = 0; s < STEPS; ++s) {
-          const u32 addr = __builtin_amdgcn_perm(aw[s], lo, sel);
-          const uint4 tv = *reinterpret_cast<const uint4 *>(lds + addr);
-          acc[s] = xor4(acc[s], tv);
-        }
-      }
-      // next half's A words (wave-uniform control flow)
-      if (half == 0) {
-        if (lbits > 32) loadA(lb, 1);
-      } else if (lb + 1 < nlb) {
-        loadA(lb + 1, 0);
-      }
-    }
-  }
-
-  // epilogue: lane (g, qd) holds words w0+2qd, w0+2qd+1 of row myrow0+4s
-  const int wc = w0 + 2 * qd;
-#pragma unroll
-  for (int s = 0; s < STEPS; ++s) {
-    const int row = myrow0 + 4 * s;
-    if (row < p.m && wc < widthB) {
-      u64 *dst = C + (long long)row * p.ldc + wc;
-      u64 v0 = (u64)acc[s].x | ((u64)acc[s].y << 32);
-      u64 v1 = (u64)acc[s].z | ((u64)acc[s].w << 32);
-      if (wc == widthB - 1) v0 &= maskC;
-      if (wc + 1 == widthB - 1) v1 &= maskC;
-      if (wc + 1 < widthB) {
-        if (p.accumulate) {
-          const uint4 old = *reinterpret_cast<const uint4 *>(dst);
-          v0 ^= (u64)old.x | ((u64)old.y << 32);
-          v1 ^= (u64)old.z | ((u64)old.w << 32);
-        }
-        *reinterpret_cast<uint4 *>(dst) = make_uint4((u32)v0, (u32)(v0 >> 32), (u32)v1, (u32)(v1 >> 32));
-      } else {
-        if (p.accumulate) v0 ^= dst[0];
-        dst[0] = v0;
-      }
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
 // helpers for the v3 kernel
 // ---------------------------------------------------------------------------------------------
@@ -652,241 +463,9 @@ constexpr int v5_wait_count(int st_wait, int target, int G, int STEPS) {
 
 static constexpr int kTileWords5 = 16;  // 1024 columns per tile
 
-// DBG != 0: timing-only ablations (wrong results): 2 no barriers, 3 no global loads in the loop, 4 no table writes,
-// 5 no lookups (reads + XORs), 6 no XORs
-template <int WAVES, int RPW, int G, int DBG = 0>
-__global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v5(const gf2k_mul_args p) {
-  constexpr int R = WAVES * RPW;
-  constexpr int STEPS = RPW / 8;
-  constexpr int EPW = 256 / WAVES;  // pair-table rows built per wave
-  constexpr int LOWB = Log2<EPW>::value;
-  static_assert(EPW * WAVES == 256 && G <= STEPS && EPW <= STEPS, "geometry");
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int t;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int tm = t % p.tiles_m;
-  t /= p.tiles_m;
-  const int ks = t % p.ksplit;
-  t /= p.ksplit;
-  const int tn = t % p.tiles_n;
-  const int bt = t / p.tiles_n;
-  const u64 *__restrict__ A = p.A + (long long)bt * p.sA;
-  const u64 *__restrict__ B = p.B + (long long)bt * p.sB;
-  const bool part = p.P != nullptr && p.ksplit > 1;
-  u64 *__restrict__ C = part ? p.P + ((long long)bt * p.ksplit + ks) * p.sP : p.C + (long long)bt * p.sC;
-  const long long ldc = part ? p.ldp : p.ldc;
-  const bool accum = !part && p.accumulate;
-
-  const int row0 = tm * R, w0 = tn * kTileWords5;
-  const int widthB = (p.n + 63) >> 6;
-  const u64 maskC = (p.n & 63) ? ((1ull << (p.n & 63)) - 1) : ~0ull;
-  const int nw32 = (p.l + 31) >> 5;
-  const int jbeg = ks * p.kwords;
-  const int jend = min(nw32, jbeg + p.kwords);
-
-  const int g = lane >> 3, qd = lane & 7, h = g & 1;
-  // byte offsets inside a pair-table row: first read / second read, pair table 0 / 1
-  const u32 lo0a = (u32)qd * 16u + (u32)h * 128u, lo0b = lo0a ^ 128u;
-  const u32 lo1a = lo0a | 0x10000u, lo1b = lo0b | 0x10000u;
-  // v_perm_b32 selectors {0, table bit, byte of the A word, lane offset}: the first read takes the even chunk's byte
-  // for even rows and the odd chunk's for odd rows
-  const u32 sel0a = 0x0c020000u | ((4u + (u32)h) << 8), sel0b = sel0a ^ 0x100u;  // bytes 0,1 of the word
-  const u32 sel1a = 0x0c020000u | ((6u + (u32)h) << 8), sel1b = sel1a ^ 0x100u;  // bytes 2,3
-  const int myrow0 = row0 + wave * RPW + g;
-
-  u32 acc[STEPS][4];
-#pragma unroll
-  for (int s = 0; s < STEPS; ++s) acc[s][0] = acc[s][1] = acc[s][2] = acc[s][3] = 0;
-
-  // ---- A: 32-bit word j of the row of each step; rows past m read as zero (descriptor bound) ----
-  const u32 ldaB = (u32)p.lda * 8u;
-  const int rows_here = min(p.m - row0, R);
-  const __amdgpu_buffer_rsrc_t rsrcA =
-      __builtin_amdgcn_make_buffer_rsrc((void *)(A + (long long)row0 * p.lda), (short)0, (int)((u32)rows_here * ldaB), 0x00020000);
-  const u32 voffA0 = (u32)(wave * RPW + g) * ldaB;
-  const u32 tailA = (p.l & 31) ? ((1u << (p.l & 31)) - 1u) : 0xffffffffu;
-  u32 aw[STEPS];
-
-  // ---- B: lanes 0..31 hold dword `lane` of the 8 rows of the pair's even chunk, lanes 32..63 of its odd chunk ----
-  const u32 ldbB = (u32)p.ldb * 8u;
-  const int validB = min(128, (widthB - w0) * 8);  // bytes of this tile's columns that exist
-  const u32 voffB = ((int)((lane & 31) * 4) < validB) ? (u32)(lane & 31) * 4u + (u32)(lane >> 5) * 8u * ldbB : 0x80000000u;
-  auto rsrcB_for = [&](int pr) __attribute__((always_inline)) {  // rows [16 pr, 16 pr + 16) of B, cut at l
-    const int rows = min(16, p.l - 16 * pr);
-    return __builtin_amdgcn_make_buffer_rsrc((void *)(B + (long long)pr * 16 * p.ldb + w0), (short)0,
-                                             rows > 0 ? (int)((u32)rows * ldbB) : 0, 0x00020000);
-  };
-
-  // ---- table build: wave w owns rows [EPW*w, EPW*(w+1)) of the pair table, one ds_write_addtid_b32 each ----
-  u32 cur32 = 0;
-  auto build_begin = [&](const u32 (&rr)[8], u32 tbase) __attribute__((always_inline)) {
-    cur32 = 0;
-#pragma unroll
-    for (int b = LOWB; b < 8; ++b)
-      if ((wave >> (b - LOWB)) & 1) cur32 ^= rr[b];
-    const u32 kOff = tbase ? (0x10004u - (u32)(EPW * 256)) : 0u;  // see gf2_m4rm_kernel_v3
-    const u32 m0v = tbase + (u32)wave * (u32)(EPW * 256) - kOff;
-    asm volatile("s_mov_b32 m0, %0" ::"s"(m0v) : "memory");
-  };
-  auto build_write = [&cur32](auto itag, auto ttag) __attribute__((always_inline)) {
-    constexpr int i = decltype(itag)::value;
-    constexpr u32 tbase = decltype(ttag)::value;
-    constexpr unsigned e = (unsigned)i ^ ((unsigned)i >> 1);
-    constexpr u32 kOff = tbase ? (0x10004u - (u32)(EPW * 256)) : 0u;
-    asm volatile("ds_write_addtid_b32 %0 offset:%1" ::"v"(cur32), "n"(kOff + e * 256u) : "memory");
-  };
-
-  // ---- prologue: rows of pair 2*jbeg -> pair table 0, rows of the next pair -> rrB, A column jbeg ----
-  u32 rrA[8], rrB[8];
-  {
-    const __amdgpu_buffer_rsrc_t rs0 = rsrcB_for(2 * jbeg), rs1 = rsrcB_for(2 * jbeg + 1);
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      rrA[b] = __builtin_amdgcn_raw_buffer_load_b32(rs0, voffB + (u32)b * ldbB, 0, 0);  // row offset in the VGPR: bound-checked
-      rrB[b] = __builtin_amdgcn_raw_buffer_load_b32(rs1, voffB + (u32)b * ldbB, 0, 0);
-    }
-  }
-  {
-    u32 vo = voffA0;
-    asm volatile("" : "+v"(vo));
-#pragma unroll
-    for (int s = 0; s < STEPS; ++s) {
-      aw[s] = __builtin_amdgcn_raw_buffer_load_b32(rsrcA, vo, jbeg * 4, 0);
-      vo += 8u * ldaB;
-    }
-  }
-  if (jbeg == nw32 - 1) {
-#pragma unroll
-    for (int s = 0; s < STEPS; ++s) aw[s] &= tailA;
-  }
-  build_begin(rrA, 0u);
-  static_for<EPW>([&](auto it) __attribute__((always_inline)) {
-    constexpr int i = decltype(it)::value;
-    if constexpr (i > 0) cur32 ^= rrA[__builtin_ctz(i | 256)];
-    build_write(it, std::integral_constant<u32, 0u>{});
-  });
-  __syncthreads();
-
-  // one pair: look pair `pr` up in pair table PP; build pair pr+1 from `rows` into the other table; fetch the rows of
-  // pair pr+2 into `next` and (second pair of a 32-bit column) the next A column in place
-  // FAST: pair pr+2 lies wholly inside the inner dimension (the row offset may then ride in the scalar offset, which the
-  // descriptor's bound check ignores)
-  auto pair_iter = [&](int pr, auto pptag, auto fast, const u32 (&rows)[8], u32 (&next)[8]) __attribute__((always_inline)) {
-    constexpr int PP = decltype(pptag)::value;
-    const u32 loa = PP ? lo1a : lo0a, lob = PP ? lo1b : lo0b;
-    const u32 sela = PP ? sel1a : sel0a, selb = PP ? sel1b : sel0b;
-    using tnext = std::integral_constant<u32, PP ? 0u : (u32)kTableBytes>;
-    build_begin(rows, tnext::value);
-    const __amdgpu_buffer_rsrc_t rsN = rsrcB_for(pr + 2);
-    const int jn = min((pr >> 1) + 1, nw32 - 1);  // clamped: never past the end of a row
-    u32 voA = voffA0;
-    asm volatile("" : "+v"(voA));
-    u32x4 ta[G], tb[G];
-    auto issue = [&](int st, u32x4 &da, u32x4 &db) __attribute__((always_inline)) {
-      u32 a0, a1;
-      asm volatile("v_perm_b32 %2, %4, %5, %6\n\tds_read_b128 %0, %2\n\tv_perm_b32 %3, %4, %7, %8\n\tds_read_b128 %1, %3"
-                   : "=&v"(da), "=&v"(db), "=&v"(a0), "=&v"(a1)
-                   : "v"(aw[st]), "v"(loa), "v"(sela), "v"(lob), "v"(selb)
-                   : "memory");
-    };
-    if constexpr (DBG != 5) {
-#pragma unroll
-      for (int k = 0; k < G; ++k) issue(k, ta[k], tb[k]);
-    } else {
-#pragma unroll
-      for (int k = 0; k < G; ++k) ta[k] = tb[k] = u32x4{aw[k], aw[k], aw[k], aw[k]};
-    }
-    static_for<STEPS>([&](auto stag) __attribute__((always_inline)) {
-      constexpr int st = decltype(stag)::value;
-      // one s_waitcnt per pair of steps (it covers the younger step's reads)
-      if constexpr (DBG == 5) {
-      } else if constexpr (st % 2 == 0 || st + 1 >= STEPS) {
-        constexpr int sw = (st % 2 == 0 && st + 1 < STEPS) ? st + 1 : st;
-        constexpr int N = v5_wait_count(st, sw, G, STEPS);
-        if constexpr (sw != st)
-          asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(ta[st % G]), "+v"(tb[st % G]), "+v"(ta[sw % G]), "+v"(tb[sw % G]) : "n"(N) : "memory");
-        else
-          asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(ta[st % G]), "+v"(tb[st % G]) : "n"(N) : "memory");
-      }
-      if constexpr (st < EPW && st > 0) cur32 ^= rows[__builtin_ctz(st | 256)];
-      if constexpr (DBG != 5 && DBG != 6) {
-        asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[st][0]) : "v"(ta[st % G].x), "v"(tb[st % G].x));
-        asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[st][1]) : "v"(ta[st % G].y), "v"(tb[st % G].y));
-        asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[st][2]) : "v"(ta[st % G].z), "v"(tb[st % G].z));
-        asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[st][3]) : "v"(ta[st % G].w), "v"(tb[st % G].w));
-      } else if constexpr (DBG == 6) {
-        asm volatile("" :: "v"(ta[st % G]), "v"(tb[st % G]));
-      }
-      if constexpr (st + G < STEPS && DBG != 5) issue(st + G, ta[st % G], tb[st % G]);
-      if constexpr (st < EPW && DBG != 4) build_write(std::integral_constant<int, st>{}, tnext{});
-      if constexpr (DBG == 3) {
-      } else if constexpr (st < 8) {
-        if constexpr (decltype(fast)::value)
-          next[st] = __builtin_amdgcn_raw_buffer_load_b32(rsN, voffB, st * (int)ldbB, 0);
-        else
-          next[st] = __builtin_amdgcn_raw_buffer_load_b32(rsN, voffB + (u32)st * ldbB, 0, 0);
-      }
-      if constexpr (PP == 1 && DBG != 3) {  // aw[st] was consumed G steps ago: fetch the next column's word in place
-        aw[st] = __builtin_amdgcn_raw_buffer_load_b32(rsrcA, voA, jn * 4, 0);
-        voA += 8u * ldaB;
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    if constexpr (PP == 1) {
-      if (jn == nw32 - 1 && tailA != 0xffffffffu) {
-#pragma unroll
-        for (int s = 0; s < STEPS; ++s) aw[s] &= tailA;
-      }
-    }
-    if constexpr (DBG != 2) __syncthreads();
-  };
-
-  // two separate loops (not one loop with a branch): see gf2_m4rm_kernel_v3
-  int j = jbeg;
-#pragma unroll 1
-  for (; j < jend && (j + 2) * 32 <= p.l; ++j) {
-    pair_iter(2 * j, std::integral_constant<int, 0>{}, std::true_type{}, rrB, rrA);
-    pair_iter(2 * j + 1, std::integral_constant<int, 1>{}, std::true_type{}, rrA, rrB);
-  }
-#pragma unroll 1
-  for (; j < jend; ++j) {  // ragged end
-    pair_iter(2 * j, std::integral_constant<int, 0>{}, std::false_type{}, rrB, rrA);
-    pair_iter(2 * j + 1, std::integral_constant<int, 1>{}, std::false_type{}, rrA, rrB);
-  }
-
-  const int wc = w0 + 2 * qd;
-#pragma unroll
-  for (int s = 0; s < STEPS; ++s) {
-    const int row = myrow0 + 8 * s;
-    if (row < p.m && wc < widthB) {
-      u64 *dst = C + (long long)row * ldc + wc;
-      u64 v0 = (u64)acc[s][0] | ((u64)acc[s][1] << 32);
-      u64 v1 = (u64)acc[s][2] | ((u64)acc[s][3] << 32);
-      if (wc == widthB - 1) v0 &= maskC;
-      if (wc + 1 == widthB - 1) v1 &= maskC;
-      if (p.ksplit > 1 && !part) {
-        if (v0) atomicXor(reinterpret_cast<unsigned long long *>(dst), (unsigned long long)v0);
-        if (wc + 1 < widthB && v1) atomicXor(reinterpret_cast<unsigned long long *>(dst + 1), (unsigned long long)v1);
-      } else if (wc + 1 < widthB) {
-        if (accum) {
-          const uint4 old = *reinterpret_cast<const uint4 *>(dst);
-          v0 ^= (u64)old.x | ((u64)old.y << 32);
-          v1 ^= (u64)old.z | ((u64)old.w << 32);
-        }
-        *reinterpret_cast<uint4 *>(dst) = make_uint4((u32)v0, (u32)(v0 >> 32), (u32)v1, (u32)(v1 >> 32));
-      } else {
-        if (accum) v0 ^= dst[0];
-        dst[0] = v0;
-      }
-    }
-  }
-}
+#ifdef GF2K_DEV_VARIANTS
+#include "../../tools/gf2_kernels_legacy.inc"  // v1 and v5, kbench A/B runs only
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // M4RM tile kernel v6: the paired lookups of v5 with ONE ROW PER LANE.  In v5 the eight lanes that share a row all fetch
@@ -2434,6 +2013,7 @@ __global__ __launch_bounds__(256) void gf2_strassen_merge2_kernel(u64 *__restric
   }
 }
 
+#ifdef GF2K_DEV_VARIANTS
 // ---------------------------------------------------------------------------------------------
 // B (l x n, row-major) -> chunk-packed layout of the tile kernel (see gf2_m4rm_kernel_v3, BPACK).
 // thread <-> (chunk c, column tile tn, lane d): reads dword d of rows 8c..8c+7 (a wave reads 256 contiguous bytes of
@@ -2467,6 +2047,8 @@ __global__ __launch_bounds__(256) void gf2_packB_kernel(u32 *__restrict__ Bp, lo
   dst[0] = make_uint4(v[0], v[1], v[2], v[3]);
   dst[1] = make_uint4(v[4], v[5], v[6], v[7]);
 }
+
+#endif  // GF2K_DEV_VARIANTS
 
 // ---------------------------------------------------------------------------------------------
 // launchers (internal C ABI used by m4ri_hip_api.cpp)
@@ -2513,7 +2095,10 @@ static hipError_t launch_tile_kernel(K kernel, int threads, const gf2k_mul_args 
   return e;
 }
 
-// cfg: 0 = v1 8x128, 1 = v1 4x64 (small m), 2.. = pipelined variants (see kbench)
+// cfg (shipped): 7 = v3 1024 x 2048 tile, 20 = v3 256 x 2048 (4 waves), 8 = v6 2048 x 1024, 81 / 82 = v6 with a deeper /
+// shallower read window, 9 = v7 4096 x 512.  Everything else -- the first-generation kernels 0 / 1, v5 (80), packed B (50)
+// and the timing-only ablations whose results are wrong by design (40-45, 49, 83-89, 92-96) -- exists only in builds
+// with -DGF2K_DEV_VARIANTS (tools/libm4ri_hip_dev.so for tools/kbench) and is hipErrorInvalidValue in libm4ri_hip.so.
 extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {
   if (a.m <= 0 || a.n <= 0 || a.batch <= 0) return hipSuccess;
   if (a.a_packed && cfg != 8 && !cfg_is_v7(cfg)) return hipErrorInvalidValue;  // only v6 / v7 read the packed layout
@@ -2538,8 +2123,6 @@ extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {
   if (nwg > 0x7fffffffLL) return hipErrorInvalidValue;
   hipError_t e = hipErrorInvalidValue;
   switch (cfg) {
-    case 0: e = launch_tile_kernel(&gf2_m4rm_kernel<8, 128>, 512, a, nwg, stream); break;
-    case 1: e = launch_tile_kernel(&gf2_m4rm_kernel<4, 64>, 256, a, nwg, stream); break;
     case 7: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4>, 512, a, nwg, stream); break;
     case 20: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<4, 64, 4>, 256, a, nwg, stream); break;
     case 8:  // paired chunks, one row per lane
@@ -2550,6 +2133,11 @@ extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {
       e = a.a_packed ? launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2, 0, 1>, 512, a, nwg, stream)
                      : launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2>, 512, a, nwg, stream);
       break;
+    case 81: e = launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 6>, 512, a, nwg, stream); break;
+    case 82: e = launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 3>, 512, a, nwg, stream); break;
+#ifdef GF2K_DEV_VARIANTS
+    case 0: e = launch_tile_kernel(&gf2_m4rm_kernel<8, 128>, 512, a, nwg, stream); break;
+    case 1: e = launch_tile_kernel(&gf2_m4rm_kernel<4, 64>, 256, a, nwg, stream); break;
     // timing-only ablations of v7 on packed A (wrong results by design)
     case 92: e = a.a_packed ? launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2, 2, 1>, 512, a, nwg, stream) : hipErrorInvalidValue; break;  // no barriers
     case 93: e = a.a_packed ? launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2, 3, 1>, 512, a, nwg, stream) : hipErrorInvalidValue; break;  // no loads in the loop
@@ -2557,8 +2145,6 @@ extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {
     case 95: e = a.a_packed ? launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2, 6, 1>, 512, a, nwg, stream) : hipErrorInvalidValue; break;  // no XORs
     case 96: e = (a.a_packed && a.Bp) ? launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2, 1, 1>, 512, a, nwg, stream) : hipErrorInvalidValue; break;  // phase stamps -> Bp
     case 80: e = launch_tile_kernel(&gf2_m4rm_kernel_v5<8, 256, 4>, 512, a, nwg, stream); break;  // paired chunks, 8 lanes per row
-    case 81: e = launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 6>, 512, a, nwg, stream); break;
-    case 82: e = launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 3>, 512, a, nwg, stream); break;
     case 86: e = launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 4, 2>, 512, a, nwg, stream); break;  // timing only: no barriers
     case 87: e = launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 4, 3>, 512, a, nwg, stream); break;  // timing only: no loads in the loop
     case 88: e = launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 4, 4>, 512, a, nwg, stream); break;  // timing only: no table writes
@@ -2574,6 +2160,7 @@ extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {
     case 45: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 7>, 512, a, nwg, stream); break;  // no A loads in the loop
     case 43: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 4, 5>, 512, a, nwg, stream); break;  // none of the three
     case 49: e = launch_tile_kernel(&gf2_m4rm_kernel_v3<8, 128, 6, 1>, 512, a, nwg, stream); break;  // section stamps
+#endif
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess || !a.P) return e;
@@ -2592,10 +2179,13 @@ extern "C" hipError_t gf2k_packA(u64 *dst, long long wp, const u64 *src, long lo
   return hipGetLastError();
 }
 
+#ifdef GF2K_DEV_VARIANTS
 extern "C" hipError_t gf2k_dbg_sec(unsigned long long *out8) {
   return hipMemcpyFromSymbol(out8, HIP_SYMBOL(gf2_dbg_sec), 8 * sizeof(unsigned long long));
 }
+#endif
 
+#ifdef GF2K_DEV_VARIANTS
 // chunks per tile column of a packed operand with inner dimension l (4 padding chunks: the kernel prefetches two
 // chunks past the last 32-bit word)
 extern "C" int gf2k_packB_chunks(int l) { return ((l + 31) / 32) * 4 + 4; }
@@ -2609,6 +2199,7 @@ extern "C" hipError_t gf2k_packB(uint32_t *Bp, long long bpStride, const u64 *B,
                      bStride, l, n, nc, tiles_n);
   return hipGetLastError();
 }
+#endif
 
 extern "C" hipError_t gf2k_rowparity(const u64 *A, long long lda, const u64 *Bt, long long ldbt, u64 *C, long long ldc,
                                      int m, int l, int n, int accumulate, hipStream_t stream) {

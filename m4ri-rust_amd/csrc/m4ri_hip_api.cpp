@@ -16,7 +16,10 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <memory>
+#include <algorithm>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -85,6 +88,30 @@ size_t round_size(size_t b) {
   return ((b + g - 1) / g) * g;
 }
 
+// every block remembers the device it was allocated on: a free (possibly deferred, possibly issued while another device
+// is current) files it under THAT device's pool
+std::mutex g_owner_mu;
+std::map<void *, int> g_owner;
+
+void remember_owner(void *p, int dev) {
+  std::lock_guard<std::mutex> lk(g_owner_mu);
+  g_owner[p] = dev;
+}
+int owner_of(void *p, bool forget) {
+  std::lock_guard<std::mutex> lk(g_owner_mu);
+  auto it = g_owner.find(p);
+  if (it == g_owner.end()) return -1;
+  const int d = it->second;
+  if (forget) g_owner.erase(it);
+  return d;
+}
+
+// hipFree acts on the pointer's own device, but wants that device's context alive: keep the caller's device current
+void raw_free(void *p) {
+  (void)owner_of(p, true);
+  (void)hipFree(p);
+}
+
 int dev_alloc(void **p, size_t bytes) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
@@ -104,26 +131,29 @@ int dev_alloc(void **p, size_t bytes) {
   if (e != hipSuccess) {
     // drop the cache and retry once
     std::lock_guard<std::mutex> lk(pool.mu);
-    for (auto &kv : pool.free_) (void)hipFree(kv.second);
+    for (auto &kv : pool.free_) raw_free(kv.second);
     pool.free_.clear();
     pool.cached = 0;
     (void)hipGetLastError();
     e = hipMalloc(p, bytes);
   }
   if (e != hipSuccess) return fail(e, "hipMalloc");
+  remember_owner(*p, dev);
   return 0;
 }
 
+// Hands a block back to the pool of the device that owns it.  NOT stream-ordered: the caller guarantees that no queued
+// work still touches the block (it synchronised its stream, or it goes through free_after / gf2_dmat_free).
 void dev_free(void *p, size_t bytes) {
   if (!p) return;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return;
+  int dev = owner_of(p, false);
+  if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return;
   bytes = round_size(bytes ? bytes : 1);
   DevPool &pool = g_pools[dev & 15];
   std::lock_guard<std::mutex> lk(pool.mu);
   static const size_t kMaxCached = (size_t)32 << 30;
   if (pool.cached + bytes > kMaxCached) {
-    (void)hipFree(p);
+    raw_free(p);
     return;
   }
   pool.free_.emplace(bytes, p);
@@ -249,7 +279,7 @@ extern "C" int gf2_trim(void) {
   reap_deferred(true);
   DevPool &pool = g_pools[dev & 15];
   std::lock_guard<std::mutex> lk(pool.mu);
-  for (auto &kv : pool.free_) (void)hipFree(kv.second);
+  for (auto &kv : pool.free_) raw_free(kv.second);
   pool.free_.clear();
   pool.cached = 0;
   return 0;
@@ -261,16 +291,18 @@ namespace {
 // an LDS-bound kernel).  Cached per (device, stream); never destroyed (a handful per process).
 struct SideStream {
   hipStream_t s2 = nullptr;
+  hipStream_t s3 = nullptr;  // second copy stream of the host pipeline (downloads; s2 carries the uploads)
   std::vector<hipEvent_t> ev;
 };
 std::map<std::pair<int, hipStream_t>, SideStream> g_side;
 
-int side_stream(hipStream_t s, int nevents, SideStream **out) {
+int side_stream(hipStream_t s, int nevents, SideStream **out, bool want_s3 = false) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lk(g_ws_mu);
   SideStream &sd = g_side[{dev, s}];
   if (!sd.s2) HIP_TRY(hipStreamCreateWithFlags(&sd.s2, hipStreamNonBlocking));
+  if (want_s3 && !sd.s3) HIP_TRY(hipStreamCreateWithFlags(&sd.s3, hipStreamNonBlocking));
   while ((int)sd.ev.size() < nevents) {
     hipEvent_t e;
     HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -354,7 +386,7 @@ static int env_int(const char *name, int dflt) {
 // ---- launch geometry of the tile kernel (shared by the launcher and the level chooser) ----
 // kernel variants (gf2_kernels.hip): 8 = v6 2048 x 1024 tile, two chunks per lookup step, one row per lane; 9 = v7 4096 x 512
 // tile, four chunks per table (only ahead of v6 when A comes row-group packed from the Strassen split); 7 = v3 1024 x 2048
-// tile; 20 = v3 256 x 2048 tile (4 waves).  M4RI_HIP_M4RM_CFG overrides (0/1 = first-generation kernels, kept for A/B runs)
+// tile; 20 = v3 256 x 2048 tile (4 waves).  M4RI_HIP_M4RM_CFG overrides (shipped variants only)
 struct TileGeom {
   int rows, cols;
   double cyc_per_chunk;  // measured cycles per 8 bits of the inner dimension and tile, 2.4 GHz
@@ -373,7 +405,18 @@ static long long tiles_of(const TileGeom &g, int m, int n) {
 // checks the answer and asks again with packed = false if it got another one
 static int m4rm_cfg_for(int m, int n, int batch, bool packed = false) {
   (void)batch;
-  static const int forced = env_int("M4RI_HIP_M4RM_CFG", -1);
+  // A/B override, restricted to variants that compute the product (the timing-only ablations exist only in development
+  // builds of the kernels and would be hipErrorInvalidValue here anyway)
+  static const int forced = [] {
+    const int f = env_int("M4RI_HIP_M4RM_CFG", -1);
+#ifdef GF2K_DEV_VARIANTS
+    return f;
+#else
+    if (f < 0 || f == 7 || f == 8 || f == 9 || f == 20 || f == 81 || f == 82) return f;
+    std::fprintf(stderr, "m4ri_hip: M4RI_HIP_M4RM_CFG=%d ignored (accepted: 7, 8, 9, 20, 81, 82)\n", f);
+    return -1;
+#endif
+  }();
   if (forced >= 0) return forced;
   if (m <= 256) return 20;
   // same tile area: the kernel with the smaller (tiles x cycles per tile) wins, i.e. the paired kernels unless their tall
@@ -857,10 +900,39 @@ extern "C" int gf2_dmat_alloc(gf2_dmat *M, int nrows, int ncols) {
   return 0;
 }
 
-extern "C" void gf2_dmat_free(gf2_dmat *M) {
+// internal: the caller has already waited for every stream that touched M
+static void dmat_release(gf2_dmat *M) {
   if (!M || !M->data) return;
   dev_free(M->data, (size_t)(M->nrows ? M->nrows : 1) * M->ld * sizeof(u64));
   M->data = nullptr;
+}
+
+// Public free = hipFree semantics: the device API is asynchronous, so the block may still be read or written by queued
+// work on any stream; wait for the owning device before the block can be handed to another caller.
+extern "C" void gf2_dmat_free(gf2_dmat *M) {
+  if (!M || !M->data) return;
+  int cur = 0, own = owner_of(M->data, false);
+  if (hipGetDevice(&cur) != hipSuccess) cur = -1;
+  if (own >= 0 && cur >= 0 && own != cur) (void)hipSetDevice(own);
+  if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+  if (own >= 0 && cur >= 0 && own != cur) (void)hipSetDevice(cur);
+  dmat_release(M);
+}
+
+// Stream-ordered free: the block returns to the pool once everything queued on `stream` so far has completed.  For
+// matrices that were only ever used on that one stream (temporaries of a chain of device products).
+extern "C" int gf2_dmat_free_async(gf2_dmat *M, void *stream) {
+  if (!M || !M->data) return 0;
+  hipStream_t s;
+  if (int rc = get_stream(stream, &s)) return rc;
+  const size_t bytes = (size_t)(M->nrows ? M->nrows : 1) * M->ld * sizeof(u64);
+  if (free_after(s, M->data, bytes) != 0) {  // could not record an event: fall back to waiting
+    gf2_dmat_free(M);
+    return 0;
+  }
+  M->data = nullptr;
+  reap_deferred(false);
+  return 0;
 }
 
 extern "C" int gf2_dmat_fill_random_block(gf2_dmat *M, uint64_t seed, int64_t row0, int64_t col_word0, int full_ncols,
@@ -891,19 +963,24 @@ extern "C" int gf2_strassen_levels(int m, int l, int n, int algo, int param) {
   return L;
 }
 
-// host rows -> device. Our mzd_t are single-block with a constant rowstride (mzd_host.cpp), windows included.
+// host rows -> device. Our mzd_t are single-block with a constant rowstride (mzd_host.cpp), windows included, so rows
+// [r0, r0 + dst->nrows) of `src` are one strided region starting at src->rows[r0].
 // Asynchronous form (internal): `src` must stay untouched until the stream has passed the copy.
-static int upload_async(gf2_dmat *dst, mzd_t const *src, hipStream_t s) {
-  if (dst->nrows != src->nrows || dst->ncols != src->ncols) return fail_msg("gf2_dmat_upload: dimension mismatch");
-  if (src->nrows == 0 || src->ncols == 0) return 0;
+static int upload_rows_async(gf2_dmat *dst, mzd_t const *src, int r0, hipStream_t s) {
+  if (r0 < 0 || r0 + dst->nrows > src->nrows || dst->ncols != src->ncols) return fail_msg("gf2_dmat_upload: dimension mismatch");
+  if (dst->nrows == 0 || src->ncols == 0) return 0;
   const size_t wbytes = (size_t)src->width * sizeof(word);
   if (dst->ld == src->rowstride)
-    HIP_TRY(hipMemcpyAsync(dst->data, src->rows[0], ((size_t)(src->nrows - 1) * src->rowstride + src->width) * sizeof(word),
+    HIP_TRY(hipMemcpyAsync(dst->data, src->rows[r0], ((size_t)(dst->nrows - 1) * src->rowstride + src->width) * sizeof(word),
                            hipMemcpyHostToDevice, s));
   else
-    HIP_TRY(hipMemcpy2DAsync(dst->data, (size_t)dst->ld * sizeof(u64), src->rows[0], (size_t)src->rowstride * sizeof(word),
-                             wbytes, src->nrows, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpy2DAsync(dst->data, (size_t)dst->ld * sizeof(u64), src->rows[r0], (size_t)src->rowstride * sizeof(word),
+                             wbytes, dst->nrows, hipMemcpyHostToDevice, s));
   return 0;
+}
+static int upload_async(gf2_dmat *dst, mzd_t const *src, hipStream_t s) {
+  if (dst->nrows != src->nrows) return fail_msg("gf2_dmat_upload: dimension mismatch");
+  return upload_rows_async(dst, src, 0, s);
 }
 
 // public form: returns once the host rows have been consumed (the caller may free or modify `src` right away;
@@ -917,22 +994,21 @@ extern "C" int gf2_dmat_upload(gf2_dmat *dst, mzd_t const *src, void *stream) {
   return 0;
 }
 
-extern "C" int gf2_dmat_download(mzd_t *dst, gf2_dmat const *src, void *stream) {
-  if (int rc = require_device()) return rc;
-  if (dst->nrows != src->nrows || dst->ncols != src->ncols) return fail_msg("gf2_dmat_download: dimension mismatch");
-  if (dst->nrows == 0 || dst->ncols == 0) return 0;
-  hipStream_t s;
-  if (int rc = get_stream(stream, &s)) return rc;
+// device -> rows [r0, r0 + src->nrows) of a host matrix; returns when they are complete in host memory
+static int download_rows(mzd_t *dst, int r0, gf2_dmat const *src, hipStream_t s) {
+  if (r0 < 0 || r0 + src->nrows > dst->nrows || dst->ncols != src->ncols) return fail_msg("gf2_dmat_download: dimension mismatch");
+  const int nrows = src->nrows;
+  if (nrows == 0 || dst->ncols == 0) return 0;
   const size_t wbytes = (size_t)dst->width * sizeof(word);
   const bool windowed = (dst->flags & mzd_flag_windowed_zerooffset) != 0;
   if (windowed && dst->high_bitmask != m4ri_ffff) {
     // the last word of each row is shared with the parent matrix: merge under the mask
-    std::vector<word> tmp((size_t)dst->nrows * dst->width);
-    HIP_TRY(hipMemcpy2DAsync(tmp.data(), wbytes, src->data, (size_t)src->ld * sizeof(u64), wbytes, dst->nrows,
+    std::vector<word> tmp((size_t)nrows * dst->width);
+    HIP_TRY(hipMemcpy2DAsync(tmp.data(), wbytes, src->data, (size_t)src->ld * sizeof(u64), wbytes, nrows,
                              hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    for (rci_t i = 0; i < dst->nrows; ++i) {
-      word *d = dst->rows[i];
+    for (rci_t i = 0; i < nrows; ++i) {
+      word *d = dst->rows[r0 + i];
       const word *t = tmp.data() + (size_t)i * dst->width;
       for (wi_t j = 0; j + 1 < dst->width; ++j) d[j] = t[j];
       d[dst->width - 1] = (d[dst->width - 1] & ~dst->high_bitmask) | (t[dst->width - 1] & dst->high_bitmask);
@@ -940,13 +1016,21 @@ extern "C" int gf2_dmat_download(mzd_t *dst, gf2_dmat const *src, void *stream) 
     return 0;
   }
   if (!windowed && src->ld == dst->rowstride)
-    HIP_TRY(hipMemcpyAsync(dst->rows[0], src->data, ((size_t)(dst->nrows - 1) * dst->rowstride + dst->width) * sizeof(word),
+    HIP_TRY(hipMemcpyAsync(dst->rows[r0], src->data, ((size_t)(nrows - 1) * dst->rowstride + dst->width) * sizeof(word),
                            hipMemcpyDeviceToHost, s));
   else
-    HIP_TRY(hipMemcpy2DAsync(dst->rows[0], (size_t)dst->rowstride * sizeof(word), src->data,
-                             (size_t)src->ld * sizeof(u64), wbytes, dst->nrows, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpy2DAsync(dst->rows[r0], (size_t)dst->rowstride * sizeof(word), src->data,
+                             (size_t)src->ld * sizeof(u64), wbytes, nrows, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   return 0;
+}
+
+extern "C" int gf2_dmat_download(mzd_t *dst, gf2_dmat const *src, void *stream) {
+  if (int rc = require_device()) return rc;
+  if (dst->nrows != src->nrows || dst->ncols != src->ncols) return fail_msg("gf2_dmat_download: dimension mismatch");
+  hipStream_t s;
+  if (int rc = get_stream(stream, &s)) return rc;
+  return download_rows(dst, 0, src, s);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -954,55 +1038,221 @@ extern "C" int gf2_dmat_download(mzd_t *dst, gf2_dmat const *src, void *stream) 
 // ---------------------------------------------------------------------------------------------
 
 namespace {
-struct DMatOwner {
-  gf2_dmat d{};
-  bool borrowed = false;  // d belongs to the operand cache
-  ~DMatOwner() {
-    if (!borrowed) gf2_dmat_free(&d);
-  }
-};
-
 // Operand cache: device copies of host matrices that the caller declared constant (gf2_mzd_cache_on_device).  A product
 // whose A or B is cached skips that upload -- the drop-in path of repeated A*v with a fixed A (mul_slice,
 // binary_matrix.rs:416-431) is otherwise bound by moving A over PCIe every call.
+// Entries are keyed by the matrix' BLOCK (mzd_t::blocks, which windows share with their parent, mzd.rs:323-346): a library
+// call that writes through a window therefore drops the parent's copy too.  An entry is handed out as a shared reference
+// that a product holds until its stream has drained, so gf2_mzd_uncache from another thread never frees a copy in use.
 struct CachedOperand {
   gf2_dmat d{};
   int dev = 0;
-  int nrows = 0, ncols = 0;
+  int nrows = 0, ncols = 0, rowstride = 0;
+  const word *row0 = nullptr;
+  ~CachedOperand() {
+    if (d.data) dev_free(d.data, (size_t)(d.nrows ? d.nrows : 1) * d.ld * sizeof(u64));
+  }
 };
 std::mutex g_cache_mu;
-std::map<const mzd_t *, CachedOperand> g_cache;
+std::map<const void *, std::shared_ptr<CachedOperand>> g_cache;
 
-bool cache_lookup(const mzd_t *M, gf2_dmat *out) {
+struct DMatOwner {
+  gf2_dmat d{};
+  std::shared_ptr<CachedOperand> borrowed;  // d belongs to the operand cache, kept alive by this reference
+  bool released = false;                    // ownership moved elsewhere
+  ~DMatOwner() {
+    if (!borrowed && !released) dmat_release(&d);  // every user synchronises its stream before the owner goes out of scope
+  }
+};
+
+static inline const void *cache_key(const mzd_t *M) { return M->blocks ? static_cast<const void *>(M->blocks) : M; }
+
+std::shared_ptr<CachedOperand> cache_lookup(const mzd_t *M) {
   std::lock_guard<std::mutex> lk(g_cache_mu);
-  auto it = g_cache.find(M);
-  if (it == g_cache.end()) return false;
+  auto it = g_cache.find(cache_key(M));
+  if (it == g_cache.end()) return nullptr;
+  const CachedOperand &c = *it->second;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev != it->second.dev) return false;
-  if (it->second.nrows != M->nrows || it->second.ncols != M->ncols) return false;
-  *out = it->second.d;
-  return true;
+  if (hipGetDevice(&dev) != hipSuccess || dev != c.dev) return nullptr;
+  // the same view of the block (a window of a cached parent, or the parent of a cached window, is a different operand)
+  if (c.nrows != M->nrows || c.ncols != M->ncols || c.rowstride != M->rowstride || (M->nrows && c.row0 != M->rows[0])) return nullptr;
+  return it->second;
 }
 
-// device copy whose row stride equals the host row stride when the host block is contiguous, so that
-// the transfer is one linear DMA
-int to_device(DMatOwner &o, const mzd_t *M, hipStream_t s, bool copy) {
-  if (copy && cache_lookup(M, &o.d)) {  // a read-only operand that already lives on the device
-    o.borrowed = true;
-    return 0;
+// device copy of rows [r0, r1) of M whose row stride equals the host row stride when the host block is contiguous, so
+// that the transfer is one linear DMA
+int to_device_rows(DMatOwner &o, const mzd_t *M, int r0, int r1, hipStream_t s, bool copy) {
+  if (copy && r0 == 0 && r1 == M->nrows) {
+    if (auto hit = cache_lookup(M)) {  // a read-only operand that already lives on the device
+      o.d = hit->d;
+      o.borrowed = std::move(hit);
+      return 0;
+    }
   }
-  o.d.nrows = M->nrows;
+  o.d.nrows = r1 - r0;
   o.d.ncols = M->ncols;
   const bool windowed = (M->flags & mzd_flag_windowed_zerooffset) != 0;
   o.d.ld = (!windowed && M->rowstride >= 1) ? M->rowstride : dev_ld_for(M->ncols);
   void *p = nullptr;
-  if (int rc = dev_alloc(&p, (size_t)(M->nrows ? M->nrows : 1) * o.d.ld * sizeof(u64))) return rc;
+  if (int rc = dev_alloc(&p, (size_t)(o.d.nrows ? o.d.nrows : 1) * o.d.ld * sizeof(u64))) return rc;
   o.d.data = static_cast<u64 *>(p);
-  if (copy) return upload_async(&o.d, M, s);  // host_mul synchronises before it returns
+  if (copy) return upload_rows_async(&o.d, M, r0, s);  // the callers synchronise before they return
+  return 0;
+}
+int to_device(DMatOwner &o, const mzd_t *M, hipStream_t s, bool copy) { return to_device_rows(o, M, 0, M->nrows, s, copy); }
+
+// Streams for the worker threads of a multi-device product: leased from a per-device pool for the duration of a call
+// (a thread_local stream per short-lived worker would leak one stream, and its scratch arenas, per call).
+std::mutex g_lease_mu;
+std::vector<hipStream_t> g_lease[16];
+int lease_stream(int dev, hipStream_t *out) {
+  {
+    std::lock_guard<std::mutex> lk(g_lease_mu);
+    auto &v = g_lease[dev & 15];
+    if (!v.empty()) {
+      *out = v.back();
+      v.pop_back();
+      return 0;
+    }
+  }
+  HIP_TRY(hipStreamCreateWithFlags(out, hipStreamNonBlocking));  // on the current device: the caller has set `dev`
+  return 0;
+}
+void unlease_stream(int dev, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_lease_mu);
+  g_lease[dev & 15].push_back(s);
+}
+
+// One device's share of a host product: C[r0:r1, :] (+)= A[r0:r1, :] * B on the CURRENT device, stream s.  Returns when
+// those rows of C are complete in host memory.
+int host_mul_range(mzd_t *C, const mzd_t *A, const mzd_t *B, int r0, int r1, int accumulate, int algo, int param, hipStream_t s) {
+  const int rows = r1 - r0;
+  if (rows <= 0) return 0;
+  int rc = 0;
+  // Large products are pipelined over row blocks of A and C: C[R,:] = A[R,:] B.  An upload stream brings B and the blocks
+  // of A in, a download stream takes the blocks of C out (PCIe is full duplex: the two directions get a stream each), the
+  // compute stream multiplies block i as soon as it has arrived -- PCIe is most of a host call: 1.5 GiB at n = 65536.
+  static const int pipe_blocks = env_int("M4RI_HIP_HOST_PIPELINE_BLOCKS", 4);
+  const bool plain_layout = !(A->flags & mzd_flag_windowed_zerooffset) && !(C->flags & mzd_flag_windowed_zerooffset) &&
+                            A->rowstride >= 1 && C->rowstride >= 1;
+  static const int strassen_overlap = env_int("M4RI_HIP_STRASSEN_OVERLAP", 0);  // that experiment uses the same side stream
+  const bool whole = r0 == 0 && r1 == A->nrows;
+  if (pipe_blocks >= 2 && !strassen_overlap && !accumulate && plain_layout && rows >= 16384 && rows % (pipe_blocks * 64) == 0 &&
+      (long long)A->ncols * B->ncols >= (1ll << 28) && !(whole && cache_lookup(A))) {
+    SideStream *side = nullptr;
+    rc = side_stream(s, 2 * pipe_blocks + 1, &side, /*want_s3=*/true);
+    DMatOwner dA, dB, dC;
+    if (!rc) rc = to_device(dB, B, side->s2, true);
+    if (!rc) rc = to_device_rows(dA, A, r0, r1, s, false);
+    if (!rc) rc = to_device_rows(dC, C, r0, r1, s, false);
+    const int R = rows / pipe_blocks;
+    auto rows_bytes = [](const mzd_t *M, int nr) { return ((size_t)(nr - 1) * M->rowstride + M->width) * sizeof(word); };
+    if (!rc && (dA.d.ld != A->rowstride || dC.d.ld != C->rowstride)) rc = fail_msg("host pipeline: unexpected device stride");
+    for (int i = 0; !rc && i < pipe_blocks; ++i) {  // upload stream: B (above), then the blocks of A in order
+      if (hipMemcpyAsync(dA.d.data + (size_t)i * R * dA.d.ld, A->rows[r0 + i * R], rows_bytes(A, R), hipMemcpyHostToDevice, side->s2) != hipSuccess ||
+          hipEventRecord(side->ev[i], side->s2) != hipSuccess)
+        rc = fail(hipGetLastError(), "host pipeline: upload");
+    }
+    for (int i = 0; !rc && i < pipe_blocks; ++i) {
+      gf2_dmat a = dA.d, c = dC.d;
+      a.data += (size_t)i * R * a.ld;
+      c.data += (size_t)i * R * c.ld;
+      a.nrows = c.nrows = R;
+      if (hipStreamWaitEvent(s, side->ev[i], 0) != hipSuccess) rc = fail(hipGetLastError(), "host pipeline: wait");
+      if (!rc) rc = mul_dispatch(&c, &a, &dB.d, 0, algo, param, s, /*sync_free=*/false);
+      if (!rc && (hipEventRecord(side->ev[pipe_blocks + i], s) != hipSuccess ||
+                  hipStreamWaitEvent(side->s3, side->ev[pipe_blocks + i], 0) != hipSuccess ||
+                  hipMemcpyAsync(C->rows[r0 + i * R], c.data, rows_bytes(C, R), hipMemcpyDeviceToHost, side->s3) != hipSuccess))
+        rc = fail(hipGetLastError(), "host pipeline: download");
+    }
+    if (side && hipStreamSynchronize(side->s2) != hipSuccess && !rc) rc = fail(hipGetLastError(), "host pipeline: upload stream");
+    if (side && side->s3 && hipStreamSynchronize(side->s3) != hipSuccess && !rc) rc = fail(hipGetLastError(), "host pipeline: download stream");
+    if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = fail(hipGetLastError(), "host pipeline: compute stream");
+  } else {
+    DMatOwner dA, dB, dC;
+    rc = to_device_rows(dA, A, r0, r1, s, true);
+    if (!rc) rc = to_device(dB, B, s, true);
+    if (!rc) rc = to_device_rows(dC, C, r0, r1, s, accumulate != 0);
+    if (!rc) rc = mul_dispatch(&dC.d, &dA.d, &dB.d, accumulate, algo, param, s, /*sync_free=*/true);
+    if (!rc) rc = download_rows(C, r0, &dC.d, s);
+    if (rc) (void)hipStreamSynchronize(s);
+  }
+  return rc;
+}
+
+// Devices a host product of this shape is spread over.  M4RI_HIP_DEVICES: unset / "auto" = every visible device once the
+// product is large enough to pay for a copy of B per device; "all"; or a comma-separated list of device ordinals (an
+// ordinal may repeat: two shares on one device -- how the one-GPU test box exercises this path).
+std::vector<int> pick_devices(long long m, long long l, long long n) {
+  const char *e = std::getenv("M4RI_HIP_DEVICES");
+  std::vector<int> out;
+  const int nvis = gf2_device_count();
+  if (e && *e && std::strcmp(e, "auto") != 0 && std::strcmp(e, "all") != 0) {
+    for (const char *p = e; *p;) {
+      char *end = nullptr;
+      const long d = std::strtol(p, &end, 10);
+      if (end == p) break;
+      if (d >= 0 && d < nvis) out.push_back((int)d);
+      p = (*end == ',') ? end + 1 : end;
+      if (*end && *end != ',') break;
+    }
+    return out;
+  }
+  const bool all = e && std::strcmp(e, "all") == 0;
+  // automatic: a share should keep >= 4096 rows (tall tiles) and the product should outweigh moving B once more per device
+  if (nvis > 1 && (all || (2.0 * (double)m * (double)l * (double)n >= 7.0e13 && m >= 8192))) {
+    int k = nvis;
+    while (k > 1 && m / k < 4096 && !all) --k;
+    for (int d = 0; d < k; ++d) out.push_back(d);
+  }
+  return out;
+}
+
+// C (+)= A*B with the rows of A and C divided among `devs` (one worker thread per share; each uploads its rows of A and
+// its own copy of B over its own PCIe link, multiplies, and downloads its rows of C).  Shares are independent: the inner
+// dimension is never split, so there is no reduction.
+int host_mul_multi(mzd_t *C, const mzd_t *A, const mzd_t *B, int accumulate, int algo, int param, const std::vector<int> &devs) {
+  const int k = (int)devs.size(), m = A->nrows;
+  // shares: equal, rounded up to a multiple of 1024 rows (whole tiles / Strassen-divisible blocks), the last one takes the rest
+  long long per = ((long long)m + k - 1) / k;
+  per = (per + 1023) / 1024 * 1024;
+  std::vector<int> rcs(k, 0);
+  std::vector<std::string> errs(k);
+  std::vector<std::thread> th;
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  for (int t = 0; t < k; ++t) {
+    const int r0 = (int)std::min<long long>(m, per * t), r1 = (int)std::min<long long>(m, per * (t + 1));
+    if (r1 <= r0) continue;
+    th.emplace_back([&, t, r0, r1] {
+      const int dev = devs[t];
+      if (hipSetDevice(dev) != hipSuccess) {
+        rcs[t] = fail(hipGetLastError(), "hipSetDevice");
+        errs[t] = gf2_last_error();
+        return;
+      }
+      hipStream_t s = nullptr;
+      rcs[t] = lease_stream(dev, &s);
+      if (!rcs[t]) {
+        rcs[t] = host_mul_range(C, A, B, r0, r1, accumulate, algo, param, s);
+        if (rcs[t]) (void)hipStreamSynchronize(s);
+        unlease_stream(dev, s);
+      }
+      if (rcs[t]) errs[t] = gf2_last_error();
+    });
+  }
+  for (auto &x : th) x.join();
+  (void)hipSetDevice(cur);
+  for (int t = 0; t < k; ++t)
+    if (rcs[t]) {
+      tls_error = "device " + std::to_string(devs[t]) + ": " + errs[t];
+      return rcs[t];
+    }
   return 0;
 }
 
-mzd_t *host_mul(mzd_t *C, const mzd_t *A, const mzd_t *B, int accumulate, int algo, int param, const char *name) {
+mzd_t *host_mul_on(mzd_t *C, const mzd_t *A, const mzd_t *B, int accumulate, int algo, int param, const char *name,
+                   const int *devices, int ndev) {
   if (A->ncols != B->nrows) gf2_die((std::string(name) + ": A ncols need to match B nrows.").c_str());
   if (accumulate && !C) gf2_die((std::string(name) + ": C must not be NULL.").c_str());
   const bool allocated = (C == nullptr);
@@ -1016,58 +1266,33 @@ mzd_t *host_mul(mzd_t *C, const mzd_t *A, const mzd_t *B, int accumulate, int al
   if (!C) C = (A->nrows == 0 || B->ncols == 0) ? mzd_init(A->nrows, B->ncols) : gf2_mzd_init_uncleared(A->nrows, B->ncols);
   else gf2_cache_forget(C);  // about to be overwritten
   if (A->nrows == 0 || B->ncols == 0) return C;
-  hipStream_t s;
-  if (get_private_stream(&s)) {
-    if (allocated) mzd_free(C);
-    return bail("stream");
-  }
-  int rc = 0;
-  // Large products are pipelined over row blocks of A and C: C[R,:] = A[R,:] B.  A copy stream uploads B and the blocks of A
-  // and later downloads the blocks of C, the compute stream multiplies block i as soon as it has arrived -- the upload of the
-  // later blocks and the download of the earlier ones overlap the products (PCIe is most of a host call: 1.5 GiB at n = 65536).
-  static const int pipe_blocks = env_int("M4RI_HIP_HOST_PIPELINE_BLOCKS", 4);
-  const bool plain_layout = !(A->flags & mzd_flag_windowed_zerooffset) && !(C->flags & mzd_flag_windowed_zerooffset) &&
-                            A->rowstride >= 1 && C->rowstride >= 1;
-  gf2_dmat cached{};
-  static const int strassen_overlap = env_int("M4RI_HIP_STRASSEN_OVERLAP", 0);  // that experiment uses the same side stream
-  if (pipe_blocks >= 2 && !strassen_overlap && !accumulate && plain_layout && A->nrows >= 16384 && A->nrows % (pipe_blocks * 64) == 0 &&
-      (long long)A->ncols * B->ncols >= (1ll << 28) && !cache_lookup(A, &cached)) {
-    SideStream *side = nullptr;
-    rc = side_stream(s, 2 * pipe_blocks + 1, &side);
-    DMatOwner dA, dB, dC;
-    if (!rc) rc = to_device(dB, B, side->s2, true);
-    if (!rc) rc = to_device(dA, A, s, false);
-    if (!rc) rc = to_device(dC, C, s, false);
-    const int R = A->nrows / pipe_blocks;
-    auto rows_bytes = [](const mzd_t *M, int rows) { return ((size_t)(rows - 1) * M->rowstride + M->width) * sizeof(word); };
-    if (!rc && (dA.d.ld != A->rowstride || dC.d.ld != C->rowstride)) rc = fail_msg("host pipeline: unexpected device stride");
-    for (int i = 0; !rc && i < pipe_blocks; ++i) {  // copy stream: B (above), then the blocks of A in order
-      if (hipMemcpyAsync(dA.d.data + (size_t)i * R * dA.d.ld, A->rows[i * R], rows_bytes(A, R), hipMemcpyHostToDevice, side->s2) != hipSuccess ||
-          hipEventRecord(side->ev[i], side->s2) != hipSuccess)
-        rc = fail(hipGetLastError(), "host pipeline: upload");
+  std::vector<int> devs;
+  if (devices) {
+    for (int i = 0; i < ndev; ++i) {
+      if (devices[i] < 0 || devices[i] >= gf2_device_count()) {
+        if (allocated) mzd_free(C);
+        fail_msg("device ordinal out of range");
+        return bail("device list");
+      }
+      devs.push_back(devices[i]);
     }
-    for (int i = 0; !rc && i < pipe_blocks; ++i) {
-      gf2_dmat a = dA.d, c = dC.d;
-      a.data += (size_t)i * R * a.ld;
-      c.data += (size_t)i * R * c.ld;
-      a.nrows = c.nrows = R;
-      if (hipStreamWaitEvent(s, side->ev[i], 0) != hipSuccess) rc = fail(hipGetLastError(), "host pipeline: wait");
-      if (!rc) rc = mul_dispatch(&c, &a, &dB.d, 0, algo, param, s, /*sync_free=*/false);
-      if (!rc && (hipEventRecord(side->ev[pipe_blocks + i], s) != hipSuccess ||
-                  hipStreamWaitEvent(side->s2, side->ev[pipe_blocks + i], 0) != hipSuccess ||
-                  hipMemcpyAsync(C->rows[i * R], c.data, rows_bytes(C, R), hipMemcpyDeviceToHost, side->s2) != hipSuccess))
-        rc = fail(hipGetLastError(), "host pipeline: download");
-    }
-    if (side && hipStreamSynchronize(side->s2) != hipSuccess && !rc) rc = fail(hipGetLastError(), "host pipeline: copy stream");
-    if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = fail(hipGetLastError(), "host pipeline: compute stream");
   } else {
-    DMatOwner dA, dB, dC;
-    rc = to_device(dA, A, s, true);
-    if (!rc) rc = to_device(dB, B, s, true);
-    if (!rc) rc = to_device(dC, C, s, accumulate != 0);
-    if (!rc) rc = mul_dispatch(&dC.d, &dA.d, &dB.d, accumulate, algo, param, s, /*sync_free=*/true);
-    if (!rc) rc = gf2_dmat_download(C, &dC.d, s);
-    if (rc) (void)hipStreamSynchronize(s);
+    devs = pick_devices(A->nrows, A->ncols, B->ncols);
+  }
+  const bool windows = ((A->flags | C->flags) & mzd_flag_windowed_zerooffset) != 0;
+  int rc;
+  if (devs.size() > 1 && !windows) {
+    rc = host_mul_multi(C, A, B, accumulate, algo, param, devs);
+  } else {
+    int cur = 0, want = devs.size() == 1 ? devs[0] : -1;
+    if (want >= 0 && (hipGetDevice(&cur) != hipSuccess || hipSetDevice(want) != hipSuccess)) want = -1;
+    hipStream_t s;
+    if (get_private_stream(&s)) {
+      if (allocated) mzd_free(C);
+      return bail("stream");
+    }
+    rc = host_mul_range(C, A, B, 0, A->nrows, accumulate, algo, param, s);
+    if (want >= 0) (void)hipSetDevice(cur);
   }
   if (rc) {
     if (allocated) mzd_free(C);
@@ -1075,19 +1300,35 @@ mzd_t *host_mul(mzd_t *C, const mzd_t *A, const mzd_t *B, int accumulate, int al
   }
   return C;
 }
+
+mzd_t *host_mul(mzd_t *C, const mzd_t *A, const mzd_t *B, int accumulate, int algo, int param, const char *name) {
+  return host_mul_on(C, A, B, accumulate, algo, param, name, nullptr, 0);
+}
 }  // namespace
 
+// One process, several devices: C = A*B (C NULL: allocated) with the rows of A and C divided among `devices` (ordinals of
+// hipGetDeviceCount's numbering; an ordinal may repeat).  mzd_mul / mzd_mul_m4rm / mzd_mul_naive do the same by
+// themselves for large products when more than one device is visible (M4RI_HIP_DEVICES).
+extern "C" mzd_t *gf2_mul_multi(mzd_t *C, mzd_t const *A, mzd_t const *B, int algo, int param, const int *devices, int ndev) {
+  if (!A || !B || !devices || ndev < 1) {
+    fail_msg("gf2_mul_multi: bad arguments");
+    return nullptr;
+  }
+  return host_mul_on(C, A, B, 0, algo, param, "gf2_mul_multi", devices, ndev);
+}
+
 void gf2_cache_forget(mzd_t const *M) {
-  CachedOperand c;
+  std::shared_ptr<CachedOperand> c;
   {
     std::lock_guard<std::mutex> lk(g_cache_mu);
-    auto it = g_cache.find(M);
+    if (g_cache.empty()) return;
+    auto it = g_cache.find(cache_key(M));
     if (it == g_cache.end()) return;
-    c = it->second;
+    c = std::move(it->second);
     g_cache.erase(it);
   }
-  (void)hipDeviceSynchronize();  // products of other threads may still be reading the copy
-  gf2_dmat_free(&c.d);
+  // products that looked the copy up hold their own reference until their stream has drained; the block goes back to the
+  // pool when the last reference is dropped (here, if nobody is using it)
 }
 
 extern "C" int gf2_mzd_cache_on_device(mzd_t const *M) {
@@ -1099,14 +1340,16 @@ extern "C" int gf2_mzd_cache_on_device(mzd_t const *M) {
   DMatOwner o;
   if (int rc = to_device(o, M, s, true)) return rc;
   HIP_TRY(hipStreamSynchronize(s));
-  CachedOperand c;
-  c.d = o.d;
-  c.nrows = M->nrows;
-  c.ncols = M->ncols;
-  HIP_TRY(hipGetDevice(&c.dev));
-  o.borrowed = true;  // ownership moves to the cache
+  auto c = std::make_shared<CachedOperand>();
+  HIP_TRY(hipGetDevice(&c->dev));
+  c->d = o.d;
+  c->nrows = M->nrows;
+  c->ncols = M->ncols;
+  c->rowstride = M->rowstride;
+  c->row0 = M->rows[0];
+  o.released = true;  // ownership moves to the cache
   std::lock_guard<std::mutex> lk(g_cache_mu);
-  g_cache[M] = c;
+  g_cache[cache_key(M)] = std::move(c);
   return 0;
 }
 
@@ -1245,7 +1488,8 @@ int echelonize_dev(gf2_dmat *A, int full, int col_limit, int *rank_out, int *piv
   // the rank reaches the row count) against ~0.8 us per column plus ~50 us fixed for the blocked algorithm below, so it
   // is taken when at most 256 columns can matter (1000 x 64: 94 us against 139; 10 x 10: 60 against 109)
   const int cols_to_visit = limit < m + 64 ? limit : m + 64;
-  if (m <= 1024 && (long long)m * (aw | 1) <= 19000 && cols_to_visit <= 256 && env_int("M4RI_HIP_ELIM_SMALL", 1)) {
+  // (cols_to_visit is an estimate: a rank-deficient input walks all `limit` columns serially, hence the second bound)
+  if (m <= 1024 && (long long)m * (aw | 1) <= 19000 && cols_to_visit <= 256 && limit <= 4096 && env_int("M4RI_HIP_ELIM_SMALL", 1)) {
     HIP_TRY(gf2k_elim_small(A->data, lda, m, ncols, limit, full, reinterpret_cast<int *>(st.p), pv.as<int>(), s));
     HIP_TRY(hipMemcpyAsync(rank_out, st.p, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));

@@ -67,7 +67,7 @@ static void *block_alloc(size_t bytes, uint8_t *kind, bool zero) {
         g_pin_free.erase(it);
       }
     }
-    if (!p && hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+    if (!p && hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
       (void)hipGetLastError();
       p = nullptr;
     }
@@ -146,7 +146,9 @@ static bool owns_blocks(const mzd_t *A) {
 
 extern "C" void mzd_free(mzd_t *A) {
   if (!A) return;
-  gf2_cache_forget(A);  // a later matrix may get the same address
+  // the operand cache is keyed by the block: it goes with the block's owner (a later block may get the same address);
+  // freeing a window of a cached parent leaves the parent's device copy alone
+  if (owns_blocks(A) || !A->blocks) gf2_cache_forget(A);
   std::free(A->rows);
   if (owns_blocks(A)) {
     block_free(A->blocks[0].begin, A->padding[0], A->blocks[0].size);
@@ -393,15 +395,13 @@ extern "C" void mzd_copy_row(mzd_t *B, rci_t i, mzd_t const *A, rci_t j) {
 }
 
 extern "C" int m4ri_opt_k(int a, int b, int c) {
-  // graycode.rs:44-56: 0.75*log2(n), n = b for multiplication (c != 0), min(a,b) otherwise.
-  // Only a hint here: the device kernel always uses 8-bit tables.
-  int n = (c != 0) ? b : (a < b ? a : b);
-  int lg = 0;
-  while ((1 << (lg + 1)) <= n && lg < 30) ++lg;
-  int k = (int)(0.75 * (double)(1 + lg));
-  if (k < 1) k = 1;
-  if (k > 16) k = 16;
-  return k;
+  // graycode.rs:44-56: "0.75 log_2(n) where n is min(a,b) for inversion and b for multiplication" (c != 0 = multiplication).
+  // Only a hint on this side of the ABI: the tile kernels' tables are fixed at 8 bits by the LDS bank-row geometry.
+  const int n = c != 0 ? b : (a < b ? a : b);
+  if (n < 2) return 1;
+  const int bits = 32 - __builtin_clz((unsigned)n);  // 1 + floor(log2 n)
+  const int k = bits * 3 / 4;
+  return k < 1 ? 1 : (k > 16 ? 16 : k);
 }
 
 // ---- compact binary wire format (the reference only has one-way serde JSON,

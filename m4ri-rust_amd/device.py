@@ -28,6 +28,7 @@ class DMat:
         self.s = DMatStruct()
         self._owned = _wrap is None
         self._keep = None
+        self._streams = set()  # streams this matrix has been used on (the device API is asynchronous)
         if _wrap is None:
             _lib.check(_lib.lib().gf2_dmat_alloc(ctypes.byref(self.s), nrows, ncols), "gf2_dmat_alloc")
         else:
@@ -38,9 +39,16 @@ class DMat:
     def __del__(self):
         if getattr(self, "_owned", False) and self.s.data:
             try:
-                _lib.lib().gf2_dmat_free(ctypes.byref(self.s))
+                if len(self._streams) == 1:  # stream-ordered: recycled once that stream has passed this point
+                    _lib.lib().gf2_dmat_free_async(ctypes.byref(self.s), next(iter(self._streams)))
+                else:  # never used, or used on several streams: hipFree semantics (waits for the device)
+                    _lib.lib().gf2_dmat_free(ctypes.byref(self.s))
             except Exception:  # interpreter shutdown: module globals may already be gone
                 pass
+
+    def _on(self, stream):
+        self._streams.add(stream)
+        return ctypes.byref(self.s)
 
     nrows = property(lambda self: self.s.nrows)
     ncols = property(lambda self: self.s.ncols)
@@ -65,12 +73,12 @@ class DMat:
         return m
 
     def fill_random(self, seed, stream=None):
-        _lib.check(_lib.lib().gf2_dmat_fill_random(ctypes.byref(self.s), seed, stream), "gf2_dmat_fill_random")
+        _lib.check(_lib.lib().gf2_dmat_fill_random(self._on(stream), seed, stream), "gf2_dmat_fill_random")
 
     @staticmethod
     def from_host(bm, stream=None):
         m = DMat(bm.nrows(), bm.ncols())
-        _lib.check(_lib.lib().gf2_dmat_upload(ctypes.byref(m.s), bm.mzd, stream), "gf2_dmat_upload")
+        _lib.check(_lib.lib().gf2_dmat_upload(m._on(stream), bm.mzd, stream), "gf2_dmat_upload")
         return m
 
     @staticmethod
@@ -79,7 +87,7 @@ class DMat:
 
     def to_host(self, stream=None):
         bm = BinMatrix.zero(self.nrows, self.ncols)
-        _lib.check(_lib.lib().gf2_dmat_download(bm.mzd, ctypes.byref(self.s), stream), "gf2_dmat_download")
+        _lib.check(_lib.lib().gf2_dmat_download(bm.mzd, self._on(stream), stream), "gf2_dmat_download")
         return bm
 
     def to_words(self, stream=None):
@@ -101,10 +109,9 @@ class DMat:
     def transposed(self):
         return transpose(self)
 
-    def clone(self):
-        zero = DMat(self.nrows, self.ncols)
-        _lib.check(_lib.lib().gf2_add_dev(ctypes.byref(zero.s), ctypes.byref(self.s), ctypes.byref(self.s), None), "gf2_add_dev")
-        return add(self, zero)  # self ^ (self ^ self)
+    def clone(self, stream=None):
+        zero = add(self, self, stream=stream)  # self ^ self; freed stream-ordered behind the second add
+        return add(self, zero, stream=stream)
 
     def rank(self):
         return echelonize(self.clone(), full=False)[0]
@@ -120,8 +127,7 @@ def mul(A, B, C=None, accumulate=False, algo="auto", param=0, stream=None):
     """C (+)= A*B on the device; asynchronous on `stream` (int hipStream_t or None)."""
     if C is None:
         C = DMat(A.nrows, B.ncols)
-    rc = _lib.lib().gf2_mul_dev(ctypes.byref(C.s), ctypes.byref(A.s), ctypes.byref(B.s), int(accumulate), ALGOS[algo],
-                                param, stream)
+    rc = _lib.lib().gf2_mul_dev(C._on(stream), A._on(stream), B._on(stream), int(accumulate), ALGOS[algo], param, stream)
     _lib.check(rc, "gf2_mul_dev")
     return C
 
@@ -129,28 +135,27 @@ def mul(A, B, C=None, accumulate=False, algo="auto", param=0, stream=None):
 def mul_nt(A, Bt, C=None, accumulate=False, stream=None):
     if C is None:
         C = DMat(A.nrows, Bt.nrows)
-    _lib.check(_lib.lib().gf2_mul_nt_dev(ctypes.byref(C.s), ctypes.byref(A.s), ctypes.byref(Bt.s), int(accumulate), stream),
-               "gf2_mul_nt_dev")
+    _lib.check(_lib.lib().gf2_mul_nt_dev(C._on(stream), A._on(stream), Bt._on(stream), int(accumulate), stream), "gf2_mul_nt_dev")
     return C
 
 
 def add(A, B, C=None, stream=None):
     if C is None:
         C = DMat(A.nrows, A.ncols)
-    _lib.check(_lib.lib().gf2_add_dev(ctypes.byref(C.s), ctypes.byref(A.s), ctypes.byref(B.s), stream), "gf2_add_dev")
+    _lib.check(_lib.lib().gf2_add_dev(C._on(stream), A._on(stream), B._on(stream), stream), "gf2_add_dev")
     return C
 
 
 def transpose(S, D=None, stream=None):
     if D is None:
         D = DMat(S.ncols, S.nrows)
-    _lib.check(_lib.lib().gf2_transpose_dev(ctypes.byref(D.s), ctypes.byref(S.s), stream), "gf2_transpose_dev")
+    _lib.check(_lib.lib().gf2_transpose_dev(D._on(stream), S._on(stream), stream), "gf2_transpose_dev")
     return D
 
 
 def equal(A, B, stream=None):
     out = ctypes.c_int(0)
-    _lib.check(_lib.lib().gf2_equal_dev(ctypes.byref(A.s), ctypes.byref(B.s), ctypes.byref(out), stream), "gf2_equal_dev")
+    _lib.check(_lib.lib().gf2_equal_dev(A._on(stream), B._on(stream), ctypes.byref(out), stream), "gf2_equal_dev")
     return bool(out.value)
 
 
@@ -159,7 +164,7 @@ def echelonize(A, full=True, ncols_limit=0, stream=None):
     rank = ctypes.c_int(0)
     cap = min(A.nrows, ncols_limit if 0 < ncols_limit < A.ncols else A.ncols)
     piv = (ctypes.c_int * max(cap, 1))()
-    _lib.check(_lib.lib().gf2_echelonize_dev(ctypes.byref(A.s), int(bool(full)), int(ncols_limit), ctypes.byref(rank), piv,
+    _lib.check(_lib.lib().gf2_echelonize_dev(A._on(stream), int(bool(full)), int(ncols_limit), ctypes.byref(rank), piv,
                                              stream), "gf2_echelonize_dev")
     return rank.value, list(piv[:rank.value])
 
@@ -168,7 +173,7 @@ def inverse(A, stream=None):
     """A^-1 as a new DMat, or None if A is singular."""
     out = DMat(A.nrows, A.ncols)
     singular = ctypes.c_int(0)
-    _lib.check(_lib.lib().gf2_inverse_dev(ctypes.byref(out.s), ctypes.byref(A.s), ctypes.byref(singular), stream),
+    _lib.check(_lib.lib().gf2_inverse_dev(out._on(stream), A._on(stream), ctypes.byref(singular), stream),
                "gf2_inverse_dev")
     return None if singular.value else out
 

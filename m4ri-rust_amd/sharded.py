@@ -17,7 +17,7 @@ from . import _lib, device
 
 def fill_row_block(A, seed, row0, stream=None):
     """Rows [row0, row0 + A.nrows) of the seeded global matrix (same stream as the oracle generator)."""
-    _lib.check(_lib.lib().gf2_dmat_fill_random_rows(ctypes.byref(A.s), seed, row0, stream), "gf2_dmat_fill_random_rows")
+    _lib.check(_lib.lib().gf2_dmat_fill_random_rows(A._on(stream), seed, row0, stream), "gf2_dmat_fill_random_rows")
 
 
 def levels_used(m, l, n, algo, levels):
@@ -63,7 +63,7 @@ def mul_row_sharded(a_block, b, c_block, c_full, ncols_inner, ncols_out, local_m
 
 def fill_block(M, seed, row0, col_word0, full_ncols, stream=None):
     """Rows [row0, ..) x 64-bit words [col_word0, ..) of the seeded global matrix with `full_ncols` columns."""
-    _lib.check(_lib.lib().gf2_dmat_fill_random_block(ctypes.byref(M.s), seed, row0, col_word0, full_ncols, stream),
+    _lib.check(_lib.lib().gf2_dmat_fill_random_block(M._on(stream), seed, row0, col_word0, full_ncols, stream),
                "gf2_dmat_fill_random_block")
 
 

@@ -70,6 +70,37 @@ def test_rref_rank_deficient(pkg, block_words, m, n, r):
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("m,n,r", [(10, 100000, 10), (10, 100000, 4), (18, 66000, 18), (3, 70000, 2)])
+@pytest.mark.parametrize("full", [True, False])
+def test_rref_short_and_wide(pkg, m, n, r, full):
+    """Rows wider than 1024 words with a handful of rows (the one-workgroup kernel swapped one word per
+    thread only); rank-deficient cases included."""
+    a = g.random_words(m, n, 900 + m + r) if r == m else _low_rank(m, n, r, 900 + m + r)
+    got, rank = _host_rref(pkg, a, n, full=full)
+    ref, orank, opiv = g.o_echelonize(a, m, n, full=True)
+    assert rank == orank
+    if full:
+        assert np.array_equal(got, ref)
+    else:  # same row space and pivots: reducing it fully gives the unique reduced form
+        again, rank2, _ = g.o_echelonize(got, m, n, full=True)
+        assert rank2 == rank and np.array_equal(again, ref)
+
+
+@pytest.mark.parametrize("m,n,k", [(10, 10, 100000), (16, 12, 70000)])
+def test_solve_left_wide_rhs_small_kernel(pkg, m, n, k):
+    """[A | B] with a right-hand side wider than 1024 words and a column limit of n: the route on which the
+    one-workgroup kernel sees rows of more than 1024 words."""
+    a = g.random_words(m, n, 930 + m)
+    a[0], a[m - 1] = a[m - 1].copy(), a[0].copy()
+    x0 = g.random_words(n, k, 931)
+    b = g.o_mul_naive(a, x0, m, n, k)
+    A, B = pkg.BinMatrix.from_words(a, n), pkg.BinMatrix.from_words(b, k)
+    ref, ok = g.o_solve_left(a, m, n, b, m, k)
+    assert pkg.solve_left(A, B) is ok
+    if ok:
+        assert np.array_equal(B.to_words(), ref)
+
+
 def test_rref_structured(pkg, block_words):
     n = 700
     ident = g.bits_to_words(np.eye(n, dtype=np.uint8))

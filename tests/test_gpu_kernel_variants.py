@@ -1,10 +1,13 @@
-"""Every tile-kernel generation that ships in libm4ri_hip.so (the defaults and the ones kept for A/B runs) must produce the same
-bits: they are driven here through the internal launcher gf2k_m4rm (m4ri-rust_amd/csrc/gf2_kernels.h) on device buffers, against
-the first-generation kernel and against the product path the rest of the suite checks against the oracle."""
+"""Every tile-kernel variant that ships in libm4ri_hip.so (the defaults and the read-window variants kept for A/B runs) must
+produce the oracle's bits: they are driven here through the internal launcher gf2k_m4rm (m4ri-rust_amd/csrc/gf2_kernels.h) on
+device buffers and compared with oracle_mul_m4rm.  The development-only generations and the timing-only ablations (wrong
+results by design) live in tools/libm4ri_hip_dev.so and must be refused by the shipped library."""
 import ctypes
 
 import numpy as np
 import pytest
+
+import gf2util as g
 
 pytestmark = pytest.mark.gpu
 
@@ -47,7 +50,7 @@ def test_tile_kernel_generations_agree(dev, m, l, n, batch):
     for i in range(batch):
         A[i, :, :wa] = torch.from_numpy(As[i].to_words().view(np.int64)).cuda()
         B[i, :, :wb] = torch.from_numpy(Bs[i].to_words().view(np.int64)).cuda()
-    expect = np.stack([dev.mul(As[i], Bs[i]).to_words() for i in range(batch)])  # the product path (oracle-checked elsewhere)
+    expect = np.stack([g.o_mul_m4rm(As[i].to_words(), Bs[i].to_words(), m, l, n) for i in range(batch)])  # the CPU oracle
     mp = (m + 63) & ~63
     Apk = torch.zeros((batch, mp * lda), dtype=torch.int64, device="cuda")
     for i in range(batch):
@@ -65,7 +68,14 @@ def test_tile_kernel_generations_agree(dev, m, l, n, batch):
         torch.cuda.synchronize()
         return C.cpu().numpy().view(np.uint64)[:, :, :wb]
 
-    for cfg, packed, ks in [(0, False, 1), (1, False, 1), (7, False, 1), (20, False, 1), (80, False, 1), (8, False, 1), (9, False, 1),
-                            (8, True, 1), (9, True, 1), (7, False, 3), (8, False, 3), (9, True, 3)]:
+    for cfg, packed, ks in [(7, False, 1), (20, False, 1), (8, False, 1), (9, False, 1), (81, False, 1), (82, False, 1),
+                            (8, True, 1), (9, True, 1), (7, False, 3), (20, False, 2), (8, False, 3), (9, True, 3)]:
         got = run(cfg, packed, ks)
         assert np.array_equal(got, expect), (cfg, packed, ks)
+    # first-generation kernels, v5, packed B and every timing-only ablation: not in the shipped library
+    a = MulArgs()
+    a.A, a.B, a.lda, a.ldb, a.ldc, a.m, a.l, a.n, a.batch, a.ksplit = A.data_ptr(), B.data_ptr(), lda, ldb, ldb, m, l, n, 1, 1
+    a.C = torch.zeros((m, ldb), dtype=torch.int64, device="cuda").data_ptr()
+    for cfg in (0, 1, 80, 50, 40, 41, 42, 43, 44, 45, 49, 83, 84, 85, 86, 87, 88, 89, 92, 93, 94, 95, 96):
+        assert lib.gf2k_m4rm(a, cfg, None) != 0, cfg
+    torch.cuda.synchronize()

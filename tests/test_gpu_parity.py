@@ -93,6 +93,52 @@ def test_golden_digests(pkg, dev):
             assert hashlib.sha256(c.tobytes()).hexdigest() == d["sha256_c"], (name, algo)
 
 
+def _large_digests():
+    with open(os.path.join(GOLDEN, "digests_large.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("v", [1, 64, 256])
+def test_full_size_config5_lpn_digests(pkg, dev, v):
+    """BASELINE config 5 at its stated size, 2^20 x 256 times 256 x V (mul_slice / mzd_mul_naive path,
+    binary_matrix.rs:416-431, mzd.rs:152): the device product through all three entry points' algorithms must hash to
+    the digest of the independent numpy product (tests/golden/make_golden_large.py)."""
+    d = _large_digests()["lpn_1048576x256x%d" % v]
+    m, l, n = d["m"], d["l"], d["n"]
+    assert (m, l, n) == (1 << 20, 256, v)
+    A, B = dev.DMat.random(m, l, d["seed_a"]), dev.DMat.random(l, n, d["seed_b"])
+    for algo in ("naive", "m4rm", "strassen"):
+        c = dev.mul(A, B, algo=algo).to_words()
+        assert hashlib.sha256(c.tobytes()).hexdigest() == d["sha256_c"], (v, algo)
+    del A, B
+    if v == 1:  # and once through the friendly layer exactly as the reference's `&A * &v` does it (host mzd_t, mul_slice)
+        a = g.random_words(m, l, d["seed_a"])
+        x = g.random_words(l, 1, d["seed_b"])  # 256 x 1: one word per row, bit 0
+        vec = pkg.BinVector.from_bools([bool(int(w) & 1) for w in x[:, 0]])
+        got = pkg.BinMatrix.from_words(a, l) * vec
+        assert len(got) == m
+        bits = np.unpackbits(got.get_storage().view(np.uint8), bitorder="little")[:m].reshape(m, 1)
+        assert hashlib.sha256(g.bits_to_words(bits).tobytes()).hexdigest() == d["sha256_c"]
+
+
+@pytest.mark.parametrize("n", [32768, 65536])
+def test_full_size_square_digests(dev, n):
+    """BASELINE configs 3 and 4 (single-GPU form) at full size: sha256 of the whole product, Strassen-over-M4RM (auto)
+    and M4RM only, against the digest written by tests/golden/make_golden_large.py (oracle_mul_fast, itself cross-checked
+    on sampled rows against plain M4RM and the independent numpy product) -- BASELINE.md section 3's parity gate."""
+    d = _large_digests()["sq_%d" % n]
+    A, B = dev.DMat.random(n, n, d["seed_a"]), dev.DMat.random(n, n, d["seed_b"])
+    C = dev.DMat(n, n)
+    rows = d["sample_rows"]
+    for algo in ("auto", "m4rm"):
+        c = dev.mul(A, B, C=C, algo=algo).to_words()
+        assert hashlib.sha256(np.ascontiguousarray(c[rows]).tobytes()).hexdigest() == d["sample_rows_sha256"], (n, algo, "rows")
+        assert hashlib.sha256(c.tobytes()).hexdigest() == d["sha256_c"], (n, algo)
+        del c
+    del A, B, C
+    assert dev._lib.lib().gf2_trim() == 0
+
+
 # ---- device generator == oracle generator ---------------------------------------------------------
 
 def test_device_random_matches_oracle(dev):
@@ -344,6 +390,62 @@ def test_dev_properties_full_size(dev):
     from m4ri_rust_amd import BinMatrix
     I = dev.DMat.from_host(BinMatrix.identity(n))
     assert dev.equal(dev.mul(A, I), A) and dev.equal(dev.mul(I, A, algo="m4rm"), A)
+
+
+# ---- one process, several devices: row shares of A and C (SURVEY.md section 8e behind the C ABI) ----------
+
+@pytest.mark.parametrize("m,l,n,shares", [(5000, 3000, 2100, 3), (16384, 4096, 4096, 2), (1000, 700, 900, 4), (70000, 256, 64, 2),
+                                          (3, 100, 100, 2)])
+def test_multi_device_shares_through_c_abi(pkg, dev, monkeypatch, m, l, n, shares):
+    """gf2_mul_multi and the automatic form of the drop-in entry points (M4RI_HIP_DEVICES): the rows of A and C are
+    divided among device shares, one worker thread each.  With one GPU visible the shares all run on device 0 (an ordinal
+    may repeat), with several they spread over them: same code path, same bits as the oracle."""
+    import ctypes
+    L = pkg._lib.lib()
+    nvis = dev.device_count()
+    devices = [i % nvis for i in range(shares)]
+    a, b = g.random_words(m, l, 41), g.random_words(l, n, 42)
+    ref = g.o_mul_m4rm(a, b, m, l, n)
+    A, B = pkg.BinMatrix.from_words(a, l), pkg.BinMatrix.from_words(b, n)
+    arr = (ctypes.c_int * shares)(*devices)
+    for algo in (dev.ALGO_AUTO, dev.ALGO_M4RM, dev.ALGO_NAIVE):
+        c = L.gf2_mul_multi(None, A.mzd, B.mzd, algo, 0, arr, shares)
+        assert c, "NULL product"
+        assert np.array_equal(pkg.BinMatrix(c).to_words(), ref), algo
+    # preallocated destination
+    Cp = pkg.BinMatrix.random(m, n)
+    assert L.gf2_mul_multi(Cp.mzd, A.mzd, B.mzd, dev.ALGO_AUTO, 0, arr, shares)
+    assert np.array_equal(Cp.to_words(), ref)
+    # the drop-in entry points with a device list from the environment, accumulate form included
+    monkeypatch.setenv("M4RI_HIP_DEVICES", ",".join(str(d) for d in devices))
+    for fn in (L.mzd_mul, L.mzd_mul_m4rm):
+        c = fn(None, A.mzd, B.mzd, 0)
+        assert c and np.array_equal(pkg.BinMatrix(c).to_words(), ref)
+    c0 = g.random_words(m, n, 43)
+    Cacc = pkg.BinMatrix.from_words(c0, n)
+    assert L.mzd_addmul(Cacc.mzd, A.mzd, B.mzd, 0)
+    assert np.array_equal(Cacc.to_words(), c0 ^ ref)
+    # a bad ordinal is refused, not dereferenced
+    bad = (ctypes.c_int * 2)(0, nvis)
+    assert not L.gf2_mul_multi(None, A.mzd, B.mzd, dev.ALGO_AUTO, 0, bad, 2)
+
+
+def test_multi_device_pipelined_shares(pkg, dev):
+    """Shares large enough for the per-device upload / compute / download pipeline (>= 16384 rows each)."""
+    import ctypes
+    L = pkg._lib.lib()
+    m, l, n = 32768, 16384, 16384
+    a, b = g.random_words(m, l, 44), g.random_words(l, n, 45)
+    A, B = pkg.BinMatrix.from_words(a, l), pkg.BinMatrix.from_words(b, n)
+    nvis = dev.device_count()
+    arr = (ctypes.c_int * 2)(0, 1 % nvis)
+    c = L.gf2_mul_multi(None, A.mzd, B.mzd, dev.ALGO_AUTO, 0, arr, 2)
+    assert c
+    got = pkg.BinMatrix(c).to_words()
+    rows = [0, 1, 16383, 16384, 20000, 32767]
+    assert np.array_equal(got[rows], g.o_mul_m4rm(np.ascontiguousarray(a[rows]), b, len(rows), l, n))
+    single = L.mzd_mul_m4rm(None, A.mzd, B.mzd, 0)
+    assert np.array_equal(got, pkg.BinMatrix(single).to_words())
 
 
 # ---- re-entrancy: BinMatrix is Send + Sync (binary_matrix.rs:38-39) -------------------------------

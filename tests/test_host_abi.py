@@ -257,3 +257,23 @@ def test_workspace_and_level_queries_without_gpu(pkg):
     assert lib.gf2_mul_workspace_bytes(65536, 65536, 65536, M4RM, 0) == 65536 * 1024 * 8   # packed copy of A, same footprint
     assert lib.gf2_mul_workspace_bytes(1000, 1000, 1000, M4RM, 0) == 0
     assert lib.gf2_mul_workspace_bytes(2049, 70, 1024, M4RM, 0) == 2112 * 2 * 8             # rows padded to 64, even word count
+
+
+def test_product_opt_k_follows_graycode_rs(built):
+    """The library's exported m4ri_opt_k (graycode.rs:44-56: 0.75 * log2(n), n = b for a multiplication (c != 0), min(a, b)
+    for an inversion), checked against the documented rule written out independently here -- not against the oracle's copy."""
+    import math
+    from m4ri_rust_amd import _lib
+    L = _lib.lib()
+
+    def rule(a, b, c):
+        n = b if c != 0 else min(a, b)
+        k = int(0.75 * (1 + math.floor(math.log2(n)))) if n >= 1 else 1
+        return max(1, min(16, k))
+
+    table = [(1, 1, 1), (1, 1, 0), (2, 2, 2), (10, 10, 10), (100, 10, 100), (1000, 64, 1000), (1000, 1024, 1000), (1000, 1023, 1),
+             (65536, 65536, 65536), (65536, 65535, 65536), (1 << 20, 256, 1), (256, 1 << 20, 0), (1 << 20, 256, 0), (3, 1 << 30, 7),
+             (4096, 4096, 0), (5, 1 << 22, 1), (1 << 30, 1 << 30, 1)]
+    for a, b, c in table:
+        assert L.m4ri_opt_k(a, b, c) == rule(a, b, c), (a, b, c)
+    assert L.m4ri_opt_k(1000, 1024, 1000) == 8 and L.m4ri_opt_k(65536, 65536, 1) == 12

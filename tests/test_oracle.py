@@ -210,3 +210,35 @@ def test_oracle_matches_elimination_fixtures(path):
         x, ok = g.o_solve_left(d["a"], m, n, d["b"], m, k)
         assert ok and np.array_equal(x, d["x"])
         assert g.o_solve_left(d["a"], m, n, d["b_inconsistent"], m, k)[1] == (not bool(d["inconsistent"][0]))
+
+
+# ---- full-size digests of the BASELINE configurations (tests/golden/make_golden_large.py) -------------------
+
+def _large():
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "digests_large.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("v", [1, 64, 256])
+def test_oracle_reproduces_full_size_lpn_digest(v):
+    """BASELINE config 5 at 2^20 rows: the oracle's Four-Russians product hashes to the digest of the independent numpy product."""
+    import hashlib
+    d = _large()["lpn_1048576x256x%d" % v]
+    m, l, n = d["m"], d["l"], d["n"]
+    a, b = g.random_words(m, l, d["seed_a"]), g.random_words(l, n, d["seed_b"])
+    assert hashlib.sha256(g.o_mul_m4rm(a, b, m, l, n).tobytes()).hexdigest() == d["sha256_c"]
+    if v == 1:
+        assert hashlib.sha256(g.o_mul_naive(a, b, m, l, n).tobytes()).hexdigest() == d["sha256_c"]
+
+
+def test_full_size_square_digest_rows_against_plain_m4rm():
+    """sq_32768: the committed sample rows of the oracle_mul_fast product equal plain Four Russians on those rows."""
+    import hashlib
+    d = _large()["sq_32768"]
+    n, rows = d["n"], d["sample_rows"]
+    a = g.random_words(n, n, d["seed_a"])[rows]
+    b = g.random_words(n, n, d["seed_b"])
+    got = g.o_mul_m4rm(np.ascontiguousarray(a), b, len(rows), n, n)
+    assert hashlib.sha256(got.tobytes()).hexdigest() == d["sample_rows_sha256"]
+    assert set(_large()) >= {"lpn_1048576x256x1", "lpn_1048576x256x64", "lpn_1048576x256x256", "sq_32768", "sq_65536"}

@@ -133,3 +133,27 @@ def test_row_block_generator_matches_full_matrix():
     blk = g.splitmix64(5, t).reshape(32, w)
     blk[:, -1] &= np.uint64((1 << (130 % 64)) - 1)
     assert np.array_equal(blk, full[32:64])
+
+
+# ---- the driver's own invocation, rehearsed on the GPU box ---------------------------------------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bcast", ["broadcast", "allgather"])
+def test_bench_two_ranks_from_a_bare_shell(bcast):
+    """`python bench.py --gpus 2 ...` with WORLD_SIZE unset -- exactly how the driver starts the scaling runs -- must launch
+    its own two ranks (torch.distributed.run children; the parent never touches the GPU), run the row-sharded step
+    (broadcast of B panels, HIP product of the row block, gather of C) and print ONE JSON line whose sharded result equals
+    the single-GPU product.  On the one-GPU test box the two ranks share device 0 and talk over gloo; on a multi-GPU node
+    the same command with --backend nccl is the real thing."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--check", "--dim", "8192",
+           "--no-cpu", "--steps", "2", "--warmup", "1", "--bcast", bcast]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["sharded_result_matches_single_gpu"] is True
+    assert out["scaling"] == "strong" and out["value"] > 0 and out["config"]["n"] == 8192
