@@ -332,26 +332,14 @@ def main():
         out["sharded_result_matches_single_gpu"] = bool(sharded_ok)
     if world == 1 and levels > 0 and launches:
         # the rest of a step is the Strassen split / merge passes (same stream, serial): HBM-streaming kernels whose
-        # bytes are known exactly (fused pairs of levels read 16 / write 49 sub-blocks per operand, single levels 4 / 7)
-        mats, lv = [], 0
-        if levels & 1:
-            lv = 1
-            mats.append(1)
-        while lv < levels:
-            lv += 2
-            mats.append(lv)
-        pass_bytes, prev = 0.0, 0
-        for i in mats:
-            k = i - prev
-            units = (7 ** prev) * ((4 if k == 1 else 16) + (7 if k == 1 else 49))
-            blk = (n >> i) * (n >> i) / 8.0
-            pass_bytes += 3 * units * blk  # A side, B side and the merge of C move the same number of blocks
-            prev = i
+        # bytes are known exactly (every pass reads its sources once and writes its destinations once; the library's own count)
+        pass_bytes = float(device._lib.lib().gf2_strassen_pass_bytes(n, n, n, levels))
         pass_ms = max(ms_per_step - kernel_ms / args.steps, 1e-9)
         out["strassen_passes"] = {"bound": "hbm", "ms_per_step": pass_ms, "bytes_per_step": pass_bytes,
                                   "achieved": pass_bytes / (pass_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": pass_bytes / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                  "note": "step time minus the tile-kernel launch; split2/merge2 kernels, 16-byte accesses"}
+                                  "note": "step time minus the tile-kernel launch; gf2_strassen_split3 / merge3 (three fused levels, a "
+                                          "virtual fourth on top) and the single-level merge"}
 
     if cpu_baseline is not None:
         out["cpu_baseline"] = cpu_baseline

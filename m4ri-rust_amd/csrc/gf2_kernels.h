@@ -95,6 +95,11 @@ hipError_t gf2k_strassen_split(uint64_t *dst, long long ldd, long long dstStride
                                long long srcStride, int h, int w, int side, int batch, hipStream_t stream);
 hipError_t gf2k_strassen_split2(uint64_t *dst, long long ldd, long long dstStride, const uint64_t *src, long long lds_,
                                 long long srcStride, int h, int w, int side, int batch, hipStream_t stream);
+hipError_t gf2k_strassen_split3(uint64_t *dst, long long ldd, long long dstStride, const uint64_t *const *src0,
+                                const uint64_t *const *src1, int groups, long long lds_, long long srcStride, int h, int w, int side,
+                                int batch, hipStream_t stream);
+hipError_t gf2k_strassen_merge3(uint64_t *dst, long long ldd, long long dstStride, const uint64_t *src, long long lds_,
+                                long long srcStride, int h, int w, int accumulate, int groups, int batch, hipStream_t stream);
 hipError_t gf2k_strassen_merge2(uint64_t *dst, long long ldd, long long dstStride, const uint64_t *src, long long lds_,
                                 long long srcStride, int h, int w, int accumulate, int batch, hipStream_t stream);
 hipError_t gf2k_strassen_merge(uint64_t *dst, long long ldd, long long dstStride, const uint64_t *src, long long lds_,

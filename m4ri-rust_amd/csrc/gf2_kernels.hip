@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <mutex>
 #include <set>
 #include <type_traits>
@@ -2013,6 +2014,173 @@ __global__ __launch_bounds__(256) void gf2_strassen_merge2_kernel(u64 *__restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Three Strassen levels in one pass, with an optional "virtual" fourth level on top.
+// A source operand is cut into 8 x 8 sub-blocks x[i1][i2][i3] (i = 2 * row half + column half at each level, i1 the
+// coarsest); operand 49 q1 + 7 q2 + q3 of the third level below is T(q1) T(q2) T(q3) applied along the three axes, T being
+// the 7 x 4 combination table of the side (two non-zeros per row at most).  A thread owns ONE 64-bit word position of the
+// output operands: it loads the 64 source words of that position (128 registers), and walks q1 -> 16 values, q2 -> 4
+// values, q3 -> one word to store.  Each source word is read once and each destination word written once: 64 + 343 block
+// units, against (16 + 49) + 49 (16 + 49) / 16 = 264 for two fused-pair passes in the same unit -- the intermediate
+// level is never written or re-read.
+// Virtual level: blockIdx.y = q0 picks ONE or TWO quadrants of the grandparent matrix (src0[q0], src1[q0] or null) whose
+// XOR is the source operand, so that four levels cost one read of (12 / 4 of) the matrix and one write of the 2401 leaves.
+// Accesses are 8 bytes per lane (512 contiguous bytes per wave and stream): the register budget is what sets the width.
+// PACK: row-group-packed output for the paired tile kernels (see gf2_strassen_split2_kernel).
+// ---------------------------------------------------------------------------------------------
+
+struct gf2k_split3_srcs {
+  const u64 *a[7];
+  const u64 *b[7];  // second quadrant of the virtual level's combination, or nullptr
+};
+
+// quadrants (0 = X11, 1 = X12, 2 = X21, 3 = X22) that combination q of a side adds up; second entry -1: a plain copy
+__device__ constexpr int kStrassenSupp[2][7][2] = {
+    {{0, 3}, {2, 3}, {0, -1}, {3, -1}, {0, 1}, {2, 0}, {1, 3}},   // A side: A11+A22, A21+A22, A11, A22, A11+A12, A21+A11, A12+A22
+    {{0, 3}, {0, -1}, {1, 3}, {2, 0}, {3, -1}, {0, 1}, {2, 3}}};  // B side: B11+B22, B11, B12+B22, B21+B11, B22, B11+B12, B21+B22
+
+template <int SIDE, bool PACK, bool NT = false>
+__global__ __launch_bounds__(256) void gf2_strassen_split3_kernel(u64 *__restrict__ dst, long long ldd, long long dstStride,
+                                                                  const gf2k_split3_srcs srcs, long long lds_,
+                                                                  long long srcStride, int h, int w) {
+  // h, w: rows / words of one OUTPUT operand (an eighth of the source operand in each dimension)
+  const int b = blockIdx.z, g = blockIdx.y;
+  const u64 *X0 = srcs.a[g] + (long long)b * srcStride;
+  const u64 *X1 = srcs.b[g] ? srcs.b[g] + (long long)b * srcStride : nullptr;
+  u64 *Y = dst + ((long long)b * gridDim.y + g) * 343 * dstStride;
+  const long long total = (long long)h * w;
+  // PACK with w % 16 == 0: a workgroup takes a tile of 16 rows x 16 words -- wave v the words 4v..4v+3, lane L row L % 16 of
+  // word L / 16 -- so that its reads are whole 128-byte lines (a lane-per-row mapping touches 64 lines per load and ran at
+  // half the bandwidth) and its packed stores 128-byte runs (16 rows of one 64-bit column); tiles in packed-address order
+  const bool tiled = PACK && (w & 15) == 0;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    int r, c;
+    if (tiled) {
+      const long long tile = idx >> 8;           // 256 positions per tile
+      const int t = (int)(idx & 255);
+      const int rb = (int)(tile & 3);            // 16-row block inside the 64-row group
+      const long long rest = tile >> 2;
+      const int cb = (int)(rest % (w >> 4));
+      const int grp = (int)(rest / (w >> 4));
+      r = grp * 64 + rb * 16 + (t & 15);
+      c = cb * 16 + (t >> 4);
+    } else if (PACK) {
+      const long long rest = idx >> 6;
+      r = (int)(rest / w) * 64 + (int)(idx & 63);
+      c = (int)(rest % w);
+    } else {
+      r = (int)(idx / w);
+      c = (int)(idx % w);
+    }
+    u64 x[64];
+    static_for<64>([&](auto K) {
+      constexpr int k = decltype(K)::value;
+      constexpr int R = 4 * ((k >> 5) & 1) + 2 * ((k >> 3) & 1) + ((k >> 1) & 1);
+      constexpr int Cc = 4 * ((k >> 4) & 1) + 2 * ((k >> 2) & 1) + (k & 1);
+      x[k] = X0[(long long)(r + R * h) * lds_ + (long long)Cc * w + c];
+    });
+    if (X1) {
+      static_for<64>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        constexpr int R = 4 * ((k >> 5) & 1) + 2 * ((k >> 3) & 1) + ((k >> 1) & 1);
+        constexpr int Cc = 4 * ((k >> 4) & 1) + 2 * ((k >> 2) & 1) + (k & 1);
+        x[k] ^= X1[(long long)(r + R * h) * lds_ + (long long)Cc * w + c];
+      });
+    }
+    const long long at = PACK ? ((long long)(r >> 6) * w + c) * 64 + (r & 63) : (long long)r * ldd + c;
+    static_for<7>([&](auto Q1) {
+      constexpr int q1 = decltype(Q1)::value;
+      constexpr int a1 = kStrassenSupp[SIDE][q1][0], b1 = kStrassenSupp[SIDE][q1][1];
+      u64 y[16];
+      static_for<16>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        y[j] = b1 >= 0 ? (x[a1 * 16 + j] ^ x[(b1 < 0 ? 0 : b1) * 16 + j]) : x[a1 * 16 + j];
+      });
+      static_for<7>([&](auto Q2) {
+        constexpr int q2 = decltype(Q2)::value;
+        constexpr int a2 = kStrassenSupp[SIDE][q2][0], b2 = kStrassenSupp[SIDE][q2][1];
+        u64 z[4];
+        static_for<4>([&](auto J) {
+          constexpr int j = decltype(J)::value;
+          z[j] = b2 >= 0 ? (y[a2 * 4 + j] ^ y[(b2 < 0 ? 0 : b2) * 4 + j]) : y[a2 * 4 + j];
+        });
+        static_for<7>([&](auto Q3) {
+          constexpr int q3 = decltype(Q3)::value;
+          constexpr int a3 = kStrassenSupp[SIDE][q3][0], b3 = kStrassenSupp[SIDE][q3][1];
+          const u64 o = b3 >= 0 ? (z[a3] ^ z[b3 < 0 ? 0 : b3]) : z[a3];
+          if (NT) __builtin_nontemporal_store(o, &Y[(long long)(49 * q1 + 7 * q2 + q3) * dstStride + at]);
+          else Y[(long long)(49 * q1 + 7 * q2 + q3) * dstStride + at] = o;
+        });
+      });
+    });
+  }
+}
+
+// quadrants of C (0 = C11, 1 = C12, 2 = C21, 3 = C22) that product q is added to; -1: none further
+//   C11 = M1+M4+M5+M7, C12 = M3+M5, C21 = M2+M4, C22 = M1+M2+M3+M6
+__device__ constexpr int kStrassenFoldTo[7][2] = {{0, 3}, {2, 3}, {1, 3}, {0, 2}, {0, 1}, {3, -1}, {0, -1}};
+
+// The mirror image: the 343 products three levels down -> the 8 x 8 sub-blocks of their great-grandparent product.  A
+// thread owns one 64-bit word position: it loads the 343 product words as it goes (seven at a time) and keeps the 64
+// results in registers.  blockIdx.y = g: several independent parents per batch element (the seven level-1 products of a
+// four-level plan), parent (b * gridDim.y + g) at dst + that * dstStride.
+__global__ __launch_bounds__(256) void gf2_strassen_merge3_kernel(u64 *__restrict__ dst, long long ldd, long long dstStride,
+                                                                  const u64 *__restrict__ src, long long lds_,
+                                                                  long long srcStride, int h, int w, int accumulate) {
+  // h, w: rows / words of one INPUT product (an eighth of the destination in each dimension)
+  const long long parent = (long long)blockIdx.z * gridDim.y + blockIdx.y;
+  const u64 *M = src + parent * 343 * srcStride;
+  u64 *Cq = dst + parent * dstStride;
+  const long long total = (long long)h * w;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(idx / w), c = (int)(idx % w);
+    const u64 *Mp = M + (long long)r * lds_ + c;
+    u64 z[64];
+    static_for<64>([&](auto K) { z[decltype(K)::value] = 0; });
+    // q1 is a run-time loop on purpose (fully unrolled, the scheduler hoists all 343 loads and spills): its contribution
+    // to the four coarse quadrants is applied under all-ones / zero masks, so register indices stay static
+#pragma unroll 1
+    for (int q1 = 0; q1 < 7; ++q1) {
+      u64 y[16];
+      static_for<16>([&](auto J) { y[decltype(J)::value] = 0; });
+      const u64 *Mq = Mp + (long long)(49 * q1) * srcStride;
+      static_for<7>([&](auto Q2) {
+        constexpr int q2 = decltype(Q2)::value;
+        u64 m[7];
+        static_for<7>([&](auto Q3) {
+          constexpr int q3 = decltype(Q3)::value;
+          m[q3] = Mq[(long long)(7 * q2 + q3) * srcStride];
+        });
+        const u64 f[4] = {m[0] ^ m[3] ^ m[4] ^ m[6], m[2] ^ m[4], m[1] ^ m[3], m[0] ^ m[1] ^ m[2] ^ m[5]};
+        constexpr int t0 = kStrassenFoldTo[q2][0], t1 = kStrassenFoldTo[q2][1];
+        static_for<4>([&](auto J) {
+          constexpr int j = decltype(J)::value;
+          y[t0 * 4 + j] ^= f[j];
+          if (t1 >= 0) y[(t1 < 0 ? 0 : t1) * 4 + j] ^= f[j];
+        });
+      });
+      const int u0 = kStrassenFoldTo[q1][0], u1 = kStrassenFoldTo[q1][1];
+      static_for<4>([&](auto U) {
+        constexpr int u = decltype(U)::value;
+        const u64 mask = (u == u0 || u == u1) ? ~0ull : 0ull;
+        static_for<16>([&](auto J) {
+          constexpr int j = decltype(J)::value;
+          z[u * 16 + j] ^= y[j] & mask;
+        });
+      });
+    }
+    static_for<64>([&](auto K) {
+      constexpr int k = decltype(K)::value;
+      constexpr int R = 4 * ((k >> 5) & 1) + 2 * ((k >> 3) & 1) + ((k >> 1) & 1);
+      constexpr int Cc = 4 * ((k >> 4) & 1) + 2 * ((k >> 2) & 1) + (k & 1);
+      u64 *pd = Cq + (long long)(r + R * h) * ldd + (long long)Cc * w + c;
+      u64 v = z[k];
+      if (accumulate) v ^= *pd;
+      *pd = v;
+    });
+  }
+}
+
 #ifdef GF2K_DEV_VARIANTS
 // ---------------------------------------------------------------------------------------------
 // B (l x n, row-major) -> chunk-packed layout of the tile kernel (see gf2_m4rm_kernel_v3, BPACK).
@@ -2385,6 +2553,52 @@ extern "C" hipError_t gf2k_strassen_split2(u64 *dst, long long ldd, long long ds
   int gx = grid_for(total, 256, (4096 + batch - 1) / batch);
   hipLaunchKernelGGL(gf2_strassen_split2_kernel, dim3(gx, 1, batch), dim3(256), 0, stream, dst, ldd, dstStride, src, lds_,
                      srcStride, h, w, side);
+  return hipGetLastError();
+}
+
+// Three fused levels.  src0 / src1: per virtual-level group g < groups the one or two source quadrants whose XOR is the source
+// operand of that group (src1[g] may be null; groups == 1 with src1[0] == null: an ordinary three-level split of the batch).
+// Outputs: operand 49 q1 + 7 q2 + q3 of (batch element b, group g) at dst + ((b * groups + g) * 343 + that) * dstStride.
+// side: 0 = A, 1 = B, 2 = A with row-group-packed outputs (h % 64 == 0).
+extern "C" hipError_t gf2k_strassen_split3(u64 *dst, long long ldd, long long dstStride, const u64 *const *src0,
+                                           const u64 *const *src1, int groups, long long lds_, long long srcStride, int h, int w,
+                                           int side, int batch, hipStream_t stream) {
+  if (h <= 0 || w <= 0 || batch <= 0 || groups <= 0) return hipSuccess;
+  if (groups > 7 || (side == 2 && (h & 63))) return hipErrorInvalidValue;
+  gf2k_split3_srcs srcs{};
+  for (int g = 0; g < groups; ++g) {
+    srcs.a[g] = src0[g];
+    srcs.b[g] = src1 ? src1[g] : nullptr;
+  }
+  const long long total = (long long)h * w;
+  static const int cap = getenv("M4RI_HIP_PASS_GRID") ? atoi(getenv("M4RI_HIP_PASS_GRID")) : 8192;
+  const int gx = grid_for(total, 256, (cap + batch * groups - 1) / (batch * groups));
+  const dim3 grid(gx, groups, batch);
+  // non-temporal stores: the 343 operand streams are not re-read before the leaf launch (measured: -3 % / -6 % pass time)
+  static const int nt = getenv("M4RI_HIP_PASS_NT") ? atoi(getenv("M4RI_HIP_PASS_NT")) : 1;
+  if (side == 2 && nt)
+    hipLaunchKernelGGL((gf2_strassen_split3_kernel<0, true, true>), grid, dim3(256), 0, stream, dst, ldd, dstStride, srcs, lds_, srcStride, h, w);
+  else if (side == 2)
+    hipLaunchKernelGGL((gf2_strassen_split3_kernel<0, true>), grid, dim3(256), 0, stream, dst, ldd, dstStride, srcs, lds_, srcStride, h, w);
+  else if (side == 0)
+    hipLaunchKernelGGL((gf2_strassen_split3_kernel<0, false>), grid, dim3(256), 0, stream, dst, ldd, dstStride, srcs, lds_, srcStride, h, w);
+  else if (nt)
+    hipLaunchKernelGGL((gf2_strassen_split3_kernel<1, false, true>), grid, dim3(256), 0, stream, dst, ldd, dstStride, srcs, lds_, srcStride, h, w);
+  else
+    hipLaunchKernelGGL((gf2_strassen_split3_kernel<1, false>), grid, dim3(256), 0, stream, dst, ldd, dstStride, srcs, lds_, srcStride, h, w);
+  return hipGetLastError();
+}
+
+// 343 products per parent -> the parent (8h rows x 8w words); parent p of batch * groups at dst + p * dstStride, its products
+// at src + p * 343 * srcStride
+extern "C" hipError_t gf2k_strassen_merge3(u64 *dst, long long ldd, long long dstStride, const u64 *src, long long lds_,
+                                           long long srcStride, int h, int w, int accumulate, int groups, int batch,
+                                           hipStream_t stream) {
+  if (h <= 0 || w <= 0 || batch <= 0 || groups <= 0) return hipSuccess;
+  const long long total = (long long)h * w;
+  const int gx = grid_for(total, 256, (8192 + batch * groups - 1) / (batch * groups));
+  hipLaunchKernelGGL(gf2_strassen_merge3_kernel, dim3(gx, groups, batch), dim3(256), 0, stream, dst, ldd, dstStride, src, lds_,
+                     srcStride, h, w, accumulate);
   return hipGetLastError();
 }
 

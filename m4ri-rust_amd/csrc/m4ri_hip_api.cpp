@@ -457,22 +457,43 @@ static double m4rm_time_model(int m, int l, int n, int batch, bool packed) {
   return rounds * (chunks * g.cyc_per_chunk + 6000.0) / 2.4e9 + 3e-6;
 }
 
-// Levels whose operands are materialised in the arena: the passes fuse two Strassen levels at a time
-// (gf2_strassen_split2 / merge2), an odd level count starts with one single-level pass.
-static std::vector<int> strassen_materialised(int L) {
-  std::vector<int> v;
-  int lv = 0;
-  if (L & 1) v.push_back(lv = 1);
-  while (lv < L) v.push_back(lv += 2);
-  return v;
+// The level plan: a product with L Strassen levels runs L levels of operand splits, ONE batched leaf launch and L levels of
+// product merges.  The passes fuse levels so that intermediate operands are never written:
+//   step {k, virt}: k (1..3) levels fused in one kernel, operands materialised at the step's end; virt: one more level on
+//   top that is never materialised -- the kernel reads the one or two quadrants of the grandparent whose XOR is its source
+//   (on the product side the 7 parents of that level ARE materialised: merge3 into them, then a single-level merge).
+//   L: 1 {1}  2 {2}  3 {3}  4 {3 + virtual}  5 {2, 3}  6 {3, 3}          (M4RI_HIP_STRASSEN_FUSE3=0: pairs only, round 1's plan)
+struct PlanStep {
+  int k;
+  bool virt;
+  int levels() const { return k + (virt ? 1 : 0); }
+};
+static std::vector<PlanStep> strassen_plan(int L) {
+  const int fuse3 = env_int("M4RI_HIP_STRASSEN_FUSE3", 1);  // read per call: the tests switch plans
+  std::vector<PlanStep> p;
+  if (L <= 0) return p;
+  if (!fuse3) {
+    if (L & 1) p.push_back({1, false});
+    for (int lv = L & 1; lv < L; lv += 2) p.push_back({2, false});
+    return p;
+  }
+  switch (L) {
+    case 1: p = {{1, false}}; break;
+    case 2: p = {{2, false}}; break;
+    case 3: p = {{3, false}}; break;
+    case 4: p = {{3, true}}; break;
+    case 5: p = {{2, false}, {3, false}}; break;
+    default: p = {{3, false}, {3, false}}; break;  // 6
+  }
+  return p;
 }
 
-// Does the last split pass of an L-level product write the A leaves row-group packed?  (It must be a fused two-level pass
-// and the leaf rows a multiple of 64; M4RI_HIP_APACK=0 switches the layout off.)
+// Does the last split pass of an L-level product write the A leaves row-group packed?  (It must be a fused pass -- the
+// single-level kernel has no packed form -- and the leaf rows a multiple of 64; M4RI_HIP_APACK=0 switches the layout off.)
 static bool strassen_packs_a(int m, int L) {
   static const int apack_on = env_int("M4RI_HIP_APACK", 1);
   if (!apack_on || L < 2) return false;
-  return ((m >> L) & 63) == 0;  // L >= 2: the last materialised step is always a fused one (strassen_materialised)
+  return ((m >> L) & 63) == 0;  // L >= 2: the last step of every plan is a fused one
 }
 
 static size_t pow7(int i) {
@@ -481,14 +502,33 @@ static size_t pow7(int i) {
   return p;
 }
 
+// bytes the split / merge passes of an L-level product move (every kernel reads its sources once and writes its
+// destinations once; a virtual level reads 12 quadrants instead of 4)
+static double strassen_pass_bytes(double m, double l, double n, int L) {
+  double bytes = 0;
+  int prev = 0;
+  for (const PlanStep &st : strassen_plan(L)) {
+    const int i = prev + st.levels();
+    const double p7 = (double)pow7(prev);
+    const double a_i = (m * l) / std::pow(4.0, i) / 8.0, b_i = (l * n) / std::pow(4.0, i) / 8.0, c_i = (m * n) / std::pow(4.0, i) / 8.0;
+    const double rd = st.virt ? 12.0 * std::pow(4.0, st.k) : std::pow(4.0, st.k), wr = std::pow(7.0, st.levels());
+    bytes += p7 * (rd + wr) * (a_i + b_i);  // operand sides
+    if (st.virt)  // products: merge3 into the 7 level-(prev+1) parents, then a single-level merge
+      bytes += p7 * c_i * (wr + 7.0 * std::pow(4.0, st.k) + 7.0 * std::pow(4.0, st.k) + std::pow(4.0, st.k + 1));
+    else
+      bytes += p7 * c_i * (wr + std::pow(4.0, st.k));
+    prev = i;
+  }
+  return bytes;
+}
+
 // number of Strassen levels: `req` > 0 explicit; 0 automatic = the level count with the smallest modelled time
 //   t(L) = modelled time of the batched leaf launch (rounds of 256 workgroups x chunks x measured cycles per
 //          chunk, split-K included)  +  bytes moved by the split / merge passes / bw
-// (a pass over k fused levels reads 4^k and writes 7^k blocks per operand on the way down, the reverse on the way up).  `leaf_min` bounds the leaf dimensions from below
-// (mzd_mul's cutoff argument, strassen.rs:8-18).
+// `leaf_min` bounds the leaf dimensions from below (mzd_mul's cutoff argument, strassen.rs:8-18).
 static int pick_levels(int m, int l, int n, int req, int leaf_min) {
   static const int max_auto = env_int("M4RI_HIP_STRASSEN_MAX_LEVELS", 5);
-  static const double bw = (double)env_int("M4RI_HIP_STREAM_GBS", 4800) * 1e9;        // streaming B/s
+  static const double bw = (double)env_int("M4RI_HIP_STREAM_GBS", 5000) * 1e9;        // streaming B/s
   const int cap = req > 0 ? (req > 6 ? 6 : req) : max_auto;
   int best = 0;
   double best_t = 0;
@@ -503,14 +543,7 @@ static int pick_levels(int m, int l, int n, int req, int leaf_min) {
       continue;
     }
     double t = m4rm_time_model(m >> L, l >> L, n >> L, (int)pow7(L), strassen_packs_a(m, L));
-    int prev = 0;
-    for (int i : strassen_materialised(L)) {
-      const int k = i - prev;
-      const double mi = (double)(m >> i), li = (double)(l >> i), ni = (double)(n >> i);
-      const double units = (double)pow7(prev) * ((k == 1 ? 4.0 : 16.0) + (k == 1 ? 7.0 : 49.0));
-      t += units * (mi * li + li * ni + mi * ni) / 8.0 / bw + 3 * 3e-6;  // three passes (A, B, C), a launch each
-      prev = i;
-    }
+    if (L > 0) t += strassen_pass_bytes(m, l, n, L) / bw + 3 * 3e-6 * (double)strassen_plan(L).size();
     if (L == 0 || t < best_t) {
       best = L;
       best_t = t;
@@ -519,11 +552,16 @@ static int pick_levels(int m, int l, int n, int req, int leaf_min) {
   return best;
 }
 
+// 64-bit words of the operand arena: operands and products at the end of every step, plus the parents of a virtual level
 static size_t strassen_ws_words(int m, int l, int n, int L) {
   size_t total = 0;
-  for (int i : strassen_materialised(L)) {
+  int prev = 0;
+  for (const PlanStep &st : strassen_plan(L)) {
+    const int i = prev + st.levels();
     const size_t mi = (size_t)m >> i, li = (size_t)l >> i, ni = (size_t)n >> i;
     total += pow7(i) * (mi * (li / 64) + li * (ni / 64) + mi * (ni / 64));
+    if (st.virt) total += pow7(prev + 1) * ((size_t)m >> (prev + 1)) * (((size_t)n >> (prev + 1)) / 64);
+    prev = i;
   }
   return total;
 }
@@ -591,6 +629,11 @@ static int mul_m4rm_plain(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int
   return launch_m4rm(a, cfg, s);
 }
 
+// quadrants (0 = X11, 1 = X12, 2 = X21, 3 = X22) that combination q of a side adds up (second entry -1: a plain copy);
+// the device copy of this table lives in gf2_kernels.hip (kStrassenSupp)
+static const int kSupp[2][7][2] = {{{0, 3}, {2, 3}, {0, -1}, {3, -1}, {0, 1}, {2, 0}, {1, 3}},
+                                   {{0, 3}, {0, -1}, {1, 3}, {2, 0}, {3, -1}, {0, 1}, {2, 3}}};
+
 static int mul_strassen(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int accumulate, int L, hipStream_t s,
                         bool sync_free) {
   const int m = A->nrows, l = A->ncols, n = B->ncols;
@@ -602,115 +645,120 @@ static int mul_strassen(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int a
   void *ws = nullptr;
   if (int rc = stream_workspace(s, ws_bytes, &ws)) return rc;
   u64 *cur = static_cast<u64 *>(ws);
-  std::vector<u64 *> Aop(L + 1), Bop(L + 1), Pop(L + 1);
-  const std::vector<int> mats = strassen_materialised(L);
-  for (int i : mats) {
-    const size_t mi = (size_t)m >> i, li = (size_t)l >> i, ni = (size_t)n >> i, p7 = pow7(i);
-    Aop[i] = cur;
-    cur += p7 * mi * (li / 64);
-    Bop[i] = cur;
-    cur += p7 * li * (ni / 64);
-    Pop[i] = cur;
-    cur += p7 * mi * (ni / 64);
-  }
-  int rc = 0;
-  // Optional (M4RI_HIP_STRASSEN_OVERLAP=1, default off): the last materialised level is processed in chunks of parent
-  // nodes so that its passes overlap the leaf kernel -- chunk k's operands are split on `s`, its leaf products run on a
-  // side stream, and `s` folds them when they are done.  Measured at 65536^3, 4 levels: the passes disappear from the
-  // critical path (5.4 -> 2.0 ms exposed) but the leaf kernel, whose operand loads then compete with 5 TB/s of pass
-  // traffic, slows from 38.8 to 43.2 ms (raising its wave priority changes nothing): 45.2 ms against 44.3 ms serial.
-  const int last = mats.back(), lastprev = mats.size() > 1 ? mats[mats.size() - 2] : 0;
-  const int parents = (int)pow7(lastprev), cpp = (int)pow7(last - lastprev);  // children (leaves) per parent node
-  const int overlap_on = env_int("M4RI_HIP_STRASSEN_OVERLAP", 0);
-  const int nchunks = (overlap_on && parents >= 7) ? (overlap_on == 1 ? 7 : (overlap_on < parents ? overlap_on : parents)) : 1;
-  SideStream *side = nullptr;
-  if (nchunks > 1)
-    if (int r = side_stream(s, 2 * nchunks, &side)) return r;
-  // leaf operands of A in the row-group-packed layout of the paired tile kernel (its A loads become contiguous): written by
-  // the last split pass when that pass is a fused two-level one
-  int leaf_cfg = m4rm_cfg_for(m >> L, n >> L, (int)pow7(L), strassen_packs_a(m, L));
-  const bool a_packed = strassen_packs_a(m, L) && (leaf_cfg == 8 || leaf_cfg == 9);
-  if (!a_packed) leaf_cfg = m4rm_cfg_for(m >> L, n >> L, (int)pow7(L), false);
-  auto run = [&]() -> int {
-    // operand trees: level i holds 7^i operands of (m/2^i x l/2^i) and (l/2^i x n/2^i)
+  const std::vector<PlanStep> plan = strassen_plan(L);
+  std::vector<u64 *> Aop(L + 1, nullptr), Bop(L + 1, nullptr), Pop(L + 1, nullptr);
+  {
     int prev = 0;
-    for (int i : mats) {
-      const int mi = m >> i, li = l >> i, ni = n >> i, batch = (int)pow7(prev);
-      const u64 *srcA = prev ? Aop[prev] : A->data;
-      const long long ldsA = prev ? (long long)((l >> prev) / 64) : A->ld;
-      const long long strA = prev ? (long long)(m >> prev) * ldsA : 0;
-      const u64 *srcB = prev ? Bop[prev] : B->data;
-      const long long ldsB = prev ? (long long)((n >> prev) / 64) : B->ld;
-      const long long strB = prev ? (long long)(l >> prev) * ldsB : 0;
-      const long long dA = (long long)mi * (li / 64), dB = (long long)li * (ni / 64);  // operand sizes at level i
-      const int per = (int)pow7(i - prev);
-      const int chunks = i == last ? nchunks : 1;
-      for (int c = 0; c < chunks; ++c) {
-        const int k0 = (int)((long long)batch * c / chunks), k1 = (int)((long long)batch * (c + 1) / chunks);
-        u64 *dAp = Aop[i] + (long long)k0 * per * dA, *dBp = Bop[i] + (long long)k0 * per * dB;
-        if (i - prev == 1) {
-          HIP_TRY(gf2k_strassen_split(dAp, li / 64, dA, srcA + k0 * strA, ldsA, strA, mi, li / 64, 0, k1 - k0, s));
-          HIP_TRY(gf2k_strassen_split(dBp, ni / 64, dB, srcB + k0 * strB, ldsB, strB, li, ni / 64, 1, k1 - k0, s));
-        } else {
-          HIP_TRY(gf2k_strassen_split2(dAp, li / 64, dA, srcA + k0 * strA, ldsA, strA, mi, li / 64, (i == last && a_packed) ? 2 : 0,
-                                       k1 - k0, s));
-          HIP_TRY(gf2k_strassen_split2(dBp, ni / 64, dB, srcB + k0 * strB, ldsB, strB, li, ni / 64, 1, k1 - k0, s));
-        }
-        if (i == last) {  // leaf products of this chunk
-          const int mL = m >> L, lL = l >> L, nL = n >> L;
-          gf2k_mul_args a{};
-          a.lda = lL / 64;
-          a.ldb = nL / 64;
-          a.ldc = nL / 64;
-          a.sA = (long long)mL * a.lda;
-          a.sB = (long long)lL * a.ldb;
-          a.sC = (long long)mL * a.ldc;
-          a.A = Aop[L] + (long long)k0 * cpp * a.sA;
-          a.B = Bop[L] + (long long)k0 * cpp * a.sB;
-          a.C = Pop[L] + (long long)k0 * cpp * a.sC;
-          a.m = mL;
-          a.l = lL;
-          a.n = nL;
-          a.batch = (k1 - k0) * cpp;
-          a.accumulate = 0;
-          a.a_packed = a_packed ? 1 : 0;
-          a.ksplit = m4rm_ksplit_for(mL, lL, nL, a.batch, leaf_cfg);
-          hipStream_t ls = s;
-          if (side) {
-            ls = side->s2;
-            HIP_TRY(hipEventRecord(side->ev[2 * c], s));
-            HIP_TRY(hipStreamWaitEvent(ls, side->ev[2 * c], 0));
-          }
-          if (int r = launch_m4rm(a, leaf_cfg, ls)) return r;
-          if (side) HIP_TRY(hipEventRecord(side->ev[2 * c + 1], ls));
-        }
+    for (const PlanStep &st : plan) {
+      const int i = prev + st.levels();
+      const size_t mi = (size_t)m >> i, li = (size_t)l >> i, ni = (size_t)n >> i, p7 = pow7(i);
+      Aop[i] = cur;
+      cur += p7 * mi * (li / 64);
+      Bop[i] = cur;
+      cur += p7 * li * (ni / 64);
+      Pop[i] = cur;
+      cur += p7 * mi * (ni / 64);
+      if (st.virt) {  // the parents of the virtual level exist on the product side only
+        Pop[prev + 1] = cur;
+        cur += pow7(prev + 1) * ((size_t)m >> (prev + 1)) * (((size_t)n >> (prev + 1)) / 64);
       }
       prev = i;
     }
+  }
+  // leaf operands of A in the row-group-packed layout of the paired tile kernel (its A loads become contiguous): written by
+  // the last split pass when that pass is a fused one
+  int leaf_cfg = m4rm_cfg_for(m >> L, n >> L, (int)pow7(L), strassen_packs_a(m, L));
+  const bool a_packed = strassen_packs_a(m, L) && (leaf_cfg == 8 || leaf_cfg == 9);
+  if (!a_packed) leaf_cfg = m4rm_cfg_for(m >> L, n >> L, (int)pow7(L), false);
+
+  // one split step on one side: operands of level `prev` (7^prev of them, or the caller's matrix) -> level i
+  auto split_step = [&](const PlanStep &st, int prev, int i, int side, bool pack) -> int {
+    const bool isA = side == 0;
+    const int rows_prev = (isA ? m : l) >> prev, rows_i = (isA ? m : l) >> i;
+    const int words_prev = ((isA ? l : n) >> prev) / 64, words_i = ((isA ? l : n) >> i) / 64;
+    const int batch = (int)pow7(prev);
+    const gf2_dmat *top = isA ? A : B;
+    const u64 *src = prev ? (isA ? Aop[prev] : Bop[prev]) : top->data;
+    const long long lds_ = prev ? (long long)words_prev : top->ld;
+    const long long srcStride = prev ? (long long)rows_prev * lds_ : 0;
+    u64 *dst = isA ? Aop[i] : Bop[i];
+    const long long dstStride = (long long)rows_i * words_i;
+    const int kside = pack ? 2 : side;
+    if (st.k == 1) return (int)gf2k_strassen_split(dst, words_i, dstStride, src, lds_, srcStride, rows_i, words_i, side, batch, s);
+    if (st.k == 2) return (int)gf2k_strassen_split2(dst, words_i, dstStride, src, lds_, srcStride, rows_i, words_i, kside, batch, s);
+    const u64 *s0[7], *s1[7];
+    int groups = 1;
+    s0[0] = src;
+    s1[0] = nullptr;
+    if (st.virt) {
+      groups = 7;
+      const long long hq = rows_prev / 2, wq = words_prev / 2;  // quadrants of the source operand
+      auto quad = [&](int q) { return src + (long long)(q >> 1) * hq * lds_ + (long long)(q & 1) * wq; };
+      for (int g = 0; g < 7; ++g) {
+        s0[g] = quad(kSupp[side][g][0]);
+        s1[g] = kSupp[side][g][1] >= 0 ? quad(kSupp[side][g][1]) : nullptr;
+      }
+    }
+    return (int)gf2k_strassen_split3(dst, words_i, dstStride, s0, s1, groups, lds_, srcStride, rows_i, words_i, kside, batch, s);
+  };
+
+  auto run = [&]() -> int {
+    int prev = 0;
+    for (size_t k = 0; k < plan.size(); ++k) {
+      const int i = prev + plan[k].levels();
+      const bool last = k + 1 == plan.size();
+      HIP_TRY((hipError_t)split_step(plan[k], prev, i, 0, last && a_packed));
+      HIP_TRY((hipError_t)split_step(plan[k], prev, i, 1, false));
+      prev = i;
+    }
+    {  // all 7^L leaf products in one batched launch
+      const int mL = m >> L, lL = l >> L, nL = n >> L;
+      gf2k_mul_args a{};
+      a.lda = lL / 64;
+      a.ldb = nL / 64;
+      a.ldc = nL / 64;
+      a.sA = (long long)mL * a.lda;
+      a.sB = (long long)lL * a.ldb;
+      a.sC = (long long)mL * a.ldc;
+      a.A = Aop[L];
+      a.B = Bop[L];
+      a.C = Pop[L];
+      a.m = mL;
+      a.l = lL;
+      a.n = nL;
+      a.batch = (int)pow7(L);
+      a.accumulate = 0;
+      a.a_packed = a_packed ? 1 : 0;
+      a.ksplit = m4rm_ksplit_for(mL, lL, nL, a.batch, leaf_cfg);
+      if (int r = launch_m4rm(a, leaf_cfg, s)) return r;
+    }
     // fold the products back up
-    for (int k = (int)mats.size() - 1; k >= 0; --k) {
-      const int i = mats[k], up = k ? mats[k - 1] : 0;  // products of level i -> level `up`
-      const int mi = m >> i, ni = n >> i, batch = (int)pow7(up);
+    int i = L;
+    for (int k = (int)plan.size() - 1; k >= 0; --k) {
+      const PlanStep &st = plan[k];
+      const int up = i - st.levels();  // products of level i -> level `up`
+      const int mi = m >> i, wi = (n >> i) / 64, batch = (int)pow7(up);
       u64 *dst = up ? Pop[up] : C->data;
       const long long ldd = up ? (long long)((n >> up) / 64) : C->ld;
       const long long strD = up ? (long long)(m >> up) * ldd : 0;
       const int acc = up ? 0 : accumulate;
-      const long long dP = (long long)mi * (ni / 64);
-      const int per = (int)pow7(i - up);
-      const int chunks = i == last ? nchunks : 1;
-      for (int c = 0; c < chunks; ++c) {
-        const int k0 = (int)((long long)batch * c / chunks), k1 = (int)((long long)batch * (c + 1) / chunks);
-        if (i == last && side) HIP_TRY(hipStreamWaitEvent(s, side->ev[2 * c + 1], 0));
-        const u64 *src = Pop[i] + (long long)k0 * per * dP;
-        if (i - up == 1)
-          HIP_TRY(gf2k_strassen_merge(dst + k0 * strD, ldd, strD, src, ni / 64, dP, mi, ni / 64, acc, k1 - k0, s));
-        else
-          HIP_TRY(gf2k_strassen_merge2(dst + k0 * strD, ldd, strD, src, ni / 64, dP, mi, ni / 64, acc, k1 - k0, s));
+      const long long dP = (long long)mi * wi;
+      if (st.k == 1) {
+        HIP_TRY(gf2k_strassen_merge(dst, ldd, strD, Pop[i], wi, dP, mi, wi, acc, batch, s));
+      } else if (st.k == 2) {
+        HIP_TRY(gf2k_strassen_merge2(dst, ldd, strD, Pop[i], wi, dP, mi, wi, acc, batch, s));
+      } else if (!st.virt) {
+        HIP_TRY(gf2k_strassen_merge3(dst, ldd, strD, Pop[i], wi, dP, mi, wi, acc, 1, batch, s));
+      } else {
+        const int m1 = m >> (up + 1), w1 = (n >> (up + 1)) / 64;  // the 7 parents of the virtual level, dense
+        HIP_TRY(gf2k_strassen_merge3(Pop[up + 1], w1, (long long)m1 * w1, Pop[i], wi, dP, mi, wi, 0, 7, batch, s));
+        HIP_TRY(gf2k_strassen_merge(dst, ldd, strD, Pop[up + 1], w1, (long long)m1 * w1, m1, w1, acc, batch, s));
       }
+      i = up;
     }
     return 0;
   };
-  rc = run();
+  int rc = run();
   if (sync_free && rc == 0 && hipStreamSynchronize(s) != hipSuccess) rc = fail(hipGetLastError(), "hipStreamSynchronize");
   return rc;
 }
@@ -953,6 +1001,10 @@ extern "C" int gf2_dmat_fill_random(gf2_dmat *M, uint64_t seed, void *stream) {
   return gf2_dmat_fill_random_rows(M, seed, 0, stream);
 }
 
+extern "C" double gf2_strassen_pass_bytes(int m, int l, int n, int levels) {
+  return levels > 0 ? strassen_pass_bytes(m, l, n, levels) : 0.0;
+}
+
 extern "C" int gf2_strassen_levels(int m, int l, int n, int algo, int param) {
   if (algo != GF2_ALGO_AUTO && algo != GF2_ALGO_STRASSEN) return 0;
   static const int leaf_min = env_int("M4RI_HIP_STRASSEN_LEAF_MIN", 2048);
@@ -1135,9 +1187,8 @@ int host_mul_range(mzd_t *C, const mzd_t *A, const mzd_t *B, int r0, int r1, int
   static const int pipe_blocks = env_int("M4RI_HIP_HOST_PIPELINE_BLOCKS", 4);
   const bool plain_layout = !(A->flags & mzd_flag_windowed_zerooffset) && !(C->flags & mzd_flag_windowed_zerooffset) &&
                             A->rowstride >= 1 && C->rowstride >= 1;
-  static const int strassen_overlap = env_int("M4RI_HIP_STRASSEN_OVERLAP", 0);  // that experiment uses the same side stream
   const bool whole = r0 == 0 && r1 == A->nrows;
-  if (pipe_blocks >= 2 && !strassen_overlap && !accumulate && plain_layout && rows >= 16384 && rows % (pipe_blocks * 64) == 0 &&
+  if (pipe_blocks >= 2 && !accumulate && plain_layout && rows >= 16384 && rows % (pipe_blocks * 64) == 0 &&
       (long long)A->ncols * B->ncols >= (1ll << 28) && !(whole && cache_lookup(A))) {
     SideStream *side = nullptr;
     rc = side_stream(s, 2 * pipe_blocks + 1, &side, /*want_s3=*/true);

@@ -558,19 +558,25 @@ def test_tall_skinny_shapes(pkg, dev, m, l, n):
     assert np.array_equal(C.to_words(), ref ^ c0)
 
 
-def test_strassen_overlap_switch(pkg, dev, monkeypatch):
-    """M4RI_HIP_STRASSEN_OVERLAP=1 runs the leaf products chunk by chunk on a side stream while the main stream streams
-    the operands of the next chunk (an experiment that is off by default): same bits either way."""
-    n = 8192
-    A, B = dev.DMat.random(n, n, 1), dev.DMat.random(n, n, 2)
+@pytest.mark.parametrize("m,l,n,levels", [(8192, 8192, 8192, 3), (8192, 8192, 8192, 4), (8192, 8192, 8192, 5), (8192, 8192, 8192, 6),
+                                          (4160, 8192, 4096, 5), (4096, 2048, 6144, 4), (1000 * 8, 3072, 1024, 3), (2048, 4096, 2048, 4)])
+def test_strassen_level_plans(dev, monkeypatch, m, l, n, levels):
+    """Every level plan of the Strassen driver -- three fused levels per pass, a virtual fourth on top at 4 levels, pairs
+    (M4RI_HIP_STRASSEN_FUSE3=0, round 1's plan) -- gives the bits of plain Four Russians and of the oracle; packed and
+    unpacked A leaves (leaf rows a multiple of 64 or not), accumulate form included."""
+    A, B = dev.DMat.random(m, l, 11), dev.DMat.random(l, n, 12)
     ref = dev.mul(A, B, algo="m4rm")
-    for levels in (3, 4):
-        monkeypatch.setenv("M4RI_HIP_STRASSEN_OVERLAP", "1")
+    rows = [0, 1, m // 2 - 1, m // 2, m - 1]
+    a_rows = np.ascontiguousarray(g.random_words(m, l, 11)[rows])
+    assert np.array_equal(ref.to_words()[rows], g.o_mul_m4rm(a_rows, g.random_words(l, n, 12), len(rows), l, n))
+    for fuse3 in ("1", "0"):
+        monkeypatch.setenv("M4RI_HIP_STRASSEN_FUSE3", fuse3)
         C1 = dev.mul(A, B, algo="strassen", param=levels)
-        C1b = dev.mul(A, B, algo="strassen", param=levels)  # back to back on the same streams
-        monkeypatch.setenv("M4RI_HIP_STRASSEN_OVERLAP", "0")
-        C0 = dev.mul(A, B, algo="strassen", param=levels)
-        assert dev.equal(C1, ref) and dev.equal(C1b, ref) and dev.equal(C0, ref)
+        assert dev.equal(C1, ref), (fuse3, "product")
+        C2 = dev.DMat.random(m, n, 13)
+        expect = dev.add(C2, ref)
+        dev.mul(A, B, C=C2, accumulate=True, algo="strassen", param=levels)
+        assert dev.equal(C2, expect), (fuse3, "accumulate")
 
 
 @pytest.mark.parametrize("kind", ["sparse", "ones", "zero_a", "identity_b"])
