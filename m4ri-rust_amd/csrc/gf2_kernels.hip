@@ -1502,6 +1502,226 @@ __global__ __launch_bounds__(NT) void gf2_tallskinny3_kernel(const u64 *__restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// tall-skinny kernel for an inner dimension of at most 256 bits (BASELINE config 5: l = 256) and 64 < n <= 256: the skewed
+// lookups of gf2_tallskinny3_kernel with every row of A read exactly ONCE.
+// gf2_tallskinny3_kernel fetches the words of a row again for every row set (16 bytes per lane and row: half of every
+// 32-byte sector, once per row set -- 1.19x the algorithmic traffic at n = 256 and a load latency in the middle of the
+// kernel each time).  Here a lane loads its RPT whole rows (32 bytes each, two 16-byte loads) before anything else, the 256
+// rows of B are staged once, and the tables of 2 row sets (128 KiB: 256 bits of the inner dimension at NW = 2, 128 bits at
+// NW = 4) are built per phase.  NW = 2 has ONE phase: a row goes through both row sets, is stored and forgotten (4 accumulator
+// registers in all).  NW = 4 has two phases with 8 accumulator registers per row; it runs with 512 threads and 8 rows per
+// lane so that 8 whole rows and their accumulators fit into registers.  The build of a phase needs only LDS, so the loads
+// of A issued at the top stay in flight across it (the barriers wait for LDS operations only).
+// ---------------------------------------------------------------------------------------------
+template <int NW, int RPT, int NT, bool FULL, bool DBG = false, int EARLY = (RPT >= 8 ? 2 : 1), bool AHEAD = false>  // FULL: l in (192, 256], rows 16-byte aligned: two 16-byte loads per row, no branches
+__global__ __launch_bounds__(NT) void gf2_tallskinny5_kernel(const u64 *__restrict__ A, long long lda, const u64 *__restrict__ B,
+                                                              long long ldb, u64 *__restrict__ C, long long ldc, int m, int l,
+                                                              int n, int accumulate, u64 *__restrict__ stamps = nullptr) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  constexpr int TPR = 32 / NW;       // tables per row set (a 256-byte LDS row holds entry e of TPR tables)
+  constexpr int ND = TPR / 4;        // dwords of a row that select inside one row set
+  constexpr int WRS = TPR / 8;       // 64-bit words of the inner dimension per row set
+  constexpr int SETS = NW == 1 ? 1 : 2;  // row sets in LDS at a time (64 KiB each); NW = 1: one row set holds all 256 bits
+  constexpr int PHASES = 4 / (SETS * WRS);  // 4 words = SETS * WRS * PHASES
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wl = (l + 63) >> 6, wn = (n + 63) >> 6;
+  const u64 maskL = (l & 63) ? ((1ull << (l & 63)) - 1) : ~0ull;
+  const u64 maskC = (n & 63) ? ((1ull << (n & 63)) - 1) : ~0ull;
+  const long long row_base = (long long)blockIdx.x * (NT * RPT);
+  const int s = lane & (TPR - 1);
+  const u32 bsel = (s & 3) == 0 ? 0x03020100u : (s & 3) == 1 ? 0x02030001u : (s & 3) == 2 ? 0x01000302u : 0x00010203u;
+  const int hsw = NW == 4 ? (lane >> 3) & 1 : 0;  // NW = 4: which 16-byte half this lane reads first
+  const u32 xl0 = (u32)s * (8u * NW) + (u32)hsw * 16u, xl1 = xl0 + 65536u;
+  auto lds_barrier = []() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  // DBG (development builds): wall-clock stamps (100 MHz) per wave: start, tables built, first row done, last row done
+  u64 *st = nullptr;
+  if constexpr (DBG) {
+    st = stamps + ((long long)blockIdx.x * (NT / 64) + (tid >> 6)) * 8;
+    if (lane == 0) st[0] = __builtin_amdgcn_s_memrealtime();
+  }
+
+  // ---- the 256 rows of B first (256 x NW words, one or two coalesced 8-byte loads per thread; rows past l are zero: their
+  // tables select nothing): in-order return lets the build wait for them without waiting for the rows of A requested behind
+  // them.  (Loading each build item's eight words of B straight from global memory instead -- scattered 8-byte loads, 128
+  // instructions per CU ahead of the loads of A -- measured 0.9 us slower to the first table.)
+  constexpr int ITEMS = SETS * TPR * NW * 16, IPT = (ITEMS + NT - 1) / NT;  // build items per phase, per thread
+  constexpr int NB = (256 * NW + NT - 1) / NT;
+  u64 bv[NB];
+#pragma unroll
+  for (int kk = 0; kk < NB; ++kk) {
+    const int idx = tid + kk * NT, brow_ = idx / NW, w = idx % NW;
+    bv[kk] = (idx < 256 * NW && brow_ < l && w < wn) ? B[(long long)brow_ * ldb + w] : 0;
+  }
+  // ---- every row of this lane, whole (words past the inner dimension read as zero).  Only the first row is requested
+  // before the build: a CU holds a limited number of outstanding misses, and waves that cannot issue their loads would
+  // reach the build barrier microseconds late (stamps: tables ready at 7.5 us with all rows requested up front) ----
+  u64 aw[RPT][4];
+  auto load_row = [&](int r) __attribute__((always_inline)) {
+    const long long row = min(row_base + (long long)r * NT + tid, (long long)m - 1);  // clamped: stores are guarded
+    const u64 *ap = A + row * lda;
+    if constexpr (FULL) {  // straight-line code: the compiler can then wait for the rows one by one
+      const uint4 *ap4 = reinterpret_cast<const uint4 *>(__builtin_assume_aligned(ap, 16));
+      const uint4 lo = ap4[0], hi = ap4[1];
+      aw[r][0] = (u64)lo.x | ((u64)lo.y << 32);
+      aw[r][1] = (u64)lo.z | ((u64)lo.w << 32);
+      aw[r][2] = (u64)hi.x | ((u64)hi.y << 32);
+      aw[r][3] = (u64)hi.z | ((u64)hi.w << 32);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) aw[r][q] = q < wl ? ap[q] : 0;
+    }
+  };
+  // EARLY rows are requested before the first build; AHEAD: the others one row ahead of the lookups instead of all at once
+#pragma unroll
+  for (int r = 0; r < EARLY; ++r) load_row(r);
+  u64 *bst = reinterpret_cast<u64 *>(lds + SETS * 65536);
+#pragma unroll
+  for (int kk = 0; kk < NB; ++kk)
+    if (tid + kk * NT < 256 * NW) bst[tid + kk * NT] = bv[kk];
+  lds_barrier();  // LDS operations only: the loads of A stay in flight across the build
+
+  u32 acc[RPT][2 * NW];
+#pragma unroll
+  for (int r = 0; r < RPT; ++r)
+#pragma unroll
+    for (int w = 0; w < 2 * NW; ++w) acc[r][w] = 0;
+
+  auto store_row = [&](int r) {
+    const long long row = row_base + (long long)r * NT + tid;
+    if (row < m) {
+      // NW = 4: lanes that read the upper half first hold words 2, 3 in acc[0..3] and words 0, 1 in acc[4..7]
+      u32 o[2 * NW];
+#pragma unroll
+      for (int i = 0; i < 2 * NW; ++i) o[i] = (NW == 4 && hsw) ? acc[r][i ^ 4] : acc[r][i];
+      if (FULL && NW >= 2 && wn == NW) {  // whole rows of C, 16 bytes per store (FULL also says: ldc even, C 16-byte aligned)
+        const u32 mlo = (u32)maskC, mhi = (u32)(maskC >> 32);
+        o[2 * NW - 2] &= mlo;
+        o[2 * NW - 1] &= mhi;
+        uint4 *dd = reinterpret_cast<uint4 *>(__builtin_assume_aligned(C + row * ldc, 16));
+#pragma unroll
+        for (int q = 0; q < NW / 2; ++q) {
+          uint4 v = make_uint4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+          if (accumulate) v = xor4(v, dd[q]);
+          dd[q] = v;
+        }
+      } else {
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+          if (w < wn) {
+            u64 v = (u64)o[2 * w] | ((u64)o[2 * w + 1] << 32);
+            if (w == wn - 1) v &= maskC;
+            u64 *dd = C + row * ldc + w;
+            if (accumulate) v ^= *dd;
+            *dd = v;
+          }
+      }
+    }
+  };
+
+#pragma unroll
+  for (int ph = 0; ph < PHASES; ++ph) {
+    if (ph * SETS * WRS * 64 >= l) break;  // uniform: nothing of the inner dimension left
+    if (ph) lds_barrier();              // the previous phase's lookups are done
+    // build: 4 select-XORs for the high nibble, 15 Gray-code steps for the 16 entries of the low nibble
+#pragma unroll
+    for (int it = 0; it < IPT; ++it) {
+      const int item = tid + it * NT;
+      if (ITEMS % NT != 0 && item >= ITEMS) break;
+      const int w = item % NW, t = (item / NW) % TPR;
+      const int rest = item / (NW * TPR);
+      const int rs = rest & (SETS - 1), h = rest / SETS;
+      const u64 *rows = bst + (((ph * SETS + rs) * TPR + t) * 8) * NW + w;
+      u64 v = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) v ^= rows[(4 + b) * NW] & (0ull - (u64)((h >> b) & 1));
+      const u64 r0 = rows[0], r1 = rows[NW], r2 = rows[2 * NW], r3 = rows[3 * NW];
+      unsigned char *tb = lds + rs * 65536 + t * (8 * NW) + w * 8;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int gc = i ^ (i >> 1);
+        if (i) {
+          const int flip = __builtin_ctz(i);
+          v ^= flip == 0 ? r0 : flip == 1 ? r1 : flip == 2 ? r2 : r3;
+        }
+        *reinterpret_cast<u64 *>(tb + (h * 16 + gc) * 256) = v;
+      }
+    }
+    lds_barrier();
+    if constexpr (DBG) {
+      if (lane == 0) st[1 + 3 * ph] = __builtin_amdgcn_s_memrealtime();
+    }
+    if (ph == 0 && !AHEAD) {  // the remaining rows: nothing waits behind these requests but this wave's own lookups
+#pragma unroll
+      for (int r = EARLY; r < RPT; ++r) load_row(r);
+    }
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      __builtin_amdgcn_sched_barrier(0);  // one row at a time
+      if (AHEAD && ph == 0 && r + EARLY < RPT) load_row(r + EARLY);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int rs = 0; rs < SETS; ++rs) {
+        const int wi0 = (ph * SETS + rs) * WRS;
+        if (wi0 * 64 < l) {  // uniform
+          u32 d[ND];
+#pragma unroll
+          for (int q = 0; q < WRS; ++q) {
+            u64 x = aw[r][wi0 + q];
+            if (wi0 + q == wl - 1) x &= maskL;
+            d[2 * q] = (u32)x;
+            d[2 * q + 1] = (u32)(x >> 32);
+          }
+          // byte c of the permuted dwords = byte c ^ s of the row set's bytes
+#pragma unroll
+          for (int k = 0; (1 << k) < ND; ++k) {
+            const bool sw = (s >> (2 + k)) & 1;
+            u32 t2[ND];
+#pragma unroll
+            for (int i = 0; i < ND; ++i) t2[i] = sw ? d[i ^ (1 << k)] : d[i];
+#pragma unroll
+            for (int i = 0; i < ND; ++i) d[i] = t2[i];
+          }
+#pragma unroll
+          for (int i = 0; i < ND; ++i) d[i] = __builtin_amdgcn_perm(d[i], d[i], bsel);
+          const u32 xl = rs ? xl1 : xl0;
+#pragma unroll
+          for (int c = 0; c < TPR; c += 2) {
+            const u32 off = __builtin_amdgcn_perm(d[c >> 2], xl ^ (u32)(c * 8 * NW), 0x03020000u | ((4u + (c & 3)) << 8));
+            const u32 off1 = __builtin_amdgcn_perm(d[(c + 1) >> 2], xl ^ (u32)((c + 1) * 8 * NW), 0x03020000u | ((4u + ((c + 1) & 3)) << 8));
+            if constexpr (NW == 1) {
+              const u32x2v v = *reinterpret_cast<lds_cu32x2 *>(off), w = *reinterpret_cast<lds_cu32x2 *>(off1);
+              asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][0]) : "v"(v.x), "v"(w.x));
+              asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][1]) : "v"(v.y), "v"(w.y));
+            } else {
+              const u32x4 v = *reinterpret_cast<lds_cu32x4 *>(off), w = *reinterpret_cast<lds_cu32x4 *>(off1);
+              asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][0]) : "v"(v.x), "v"(w.x));
+              asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][1]) : "v"(v.y), "v"(w.y));
+              asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][2]) : "v"(v.z), "v"(w.z));
+              asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][3]) : "v"(v.w), "v"(w.w));
+            }
+            if constexpr (NW == 4) {
+              const u32x4 v2 = *reinterpret_cast<lds_cu32x4 *>(off ^ 16u), w2 = *reinterpret_cast<lds_cu32x4 *>(off1 ^ 16u);
+              asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][4]) : "v"(v2.x), "v"(w2.x));
+              asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][5]) : "v"(v2.y), "v"(w2.y));
+              asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][6]) : "v"(v2.z), "v"(w2.z));
+              asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][7]) : "v"(v2.w), "v"(w2.w));
+            }
+          }
+        }
+      }
+      // the last phase that holds bits of the inner dimension (uniform): the row is complete
+      if ((ph + 1) * SETS * WRS * 64 >= l) store_row(r);
+      if constexpr (DBG) {
+        if ((r == 0 || r == RPT - 1) && lane == 0) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          st[2 + 3 * ph + (r ? 1 : 0)] = __builtin_amdgcn_s_memrealtime();
+        }
+      }
+    }
+  }
+}
+
 // tall-skinny kernel with conflict-free lookups and no byte permutation ("generation" kernel; n <= 256).
 // The first kernel's lookups collide in the LDS banks (8-byte entries: 32 lanes on 32 random bank pairs, ~3.5 lanes on the
 // busiest); the skewed kernel avoids that by spreading the lanes over 32 / NW tables, which costs a byte permutation of every
@@ -1555,9 +1775,22 @@ __global__ __launch_bounds__(NT) void gf2_tallskinny4_kernel(const u64 *__restri
   u64 *bstage = reinterpret_cast<u64 *>(lds + 128 * 1024);  // the 256 rows of B of a block of four generations (2 NW KiB)
 
   for (int w0 = 0; w0 < wl; w0 += 4) {  // four 64-bit words of the inner dimension = four generations
-    u64 aw[RPT][4];
+    // the block's rows of B first (one or two coalesced loads per thread): in-order return then lets the staging wait for
+    // them without waiting for the rows of A requested behind them
+    constexpr int NBV = (256 * NW + NT - 1) / NT;
+    u64 bvals[NBV];
 #pragma unroll
-    for (int r = 0; r < RPT; ++r) {
+    for (int kk = 0; kk < NBV; ++kk) {
+      const int idx = tid + kk * NT;
+      const long long brow = (long long)w0 * 64 + idx / NW;
+      const int w = idx % NW;
+      bvals[kk] = (idx < 256 * NW && brow < l && w < wn) ? B[brow * ldb + w] : 0;
+    }
+    // HALF of this lane's rows are requested before the barriers, the other half behind them: a CU holds a limited number
+    // of outstanding misses, and with all RPT rows requested up front the waves that could not issue their loads reached
+    // the staging barrier microseconds late (per-wave stamps: first table at 7.5 us instead of 3)
+    u64 aw[RPT][4];
+    auto load_row = [&](int r) __attribute__((always_inline)) {
       const long long row = min(row_base + (long long)r * NT + tid, (long long)m - 1);  // clamped: stores are guarded
       const u64 *ap = A + row * lda;
 #pragma unroll
@@ -1567,14 +1800,17 @@ __global__ __launch_bounds__(NT) void gf2_tallskinny4_kernel(const u64 *__restri
         if (w0 + q == wl - 1) x &= maskL;
         aw[r][q] = x;
       }
-    }
+    };
+    constexpr int EARLY4 = RPT > 1 ? RPT / 2 : 1;
+#pragma unroll
+    for (int r = 0; r < EARLY4; ++r) load_row(r);
     lds_barrier();  // every wave is done with the previous block's rows of B
-    for (int idx = tid; idx < 256 * NW; idx += NT) {
-      const long long brow = (long long)w0 * 64 + idx / NW;
-      const int w = idx % NW;
-      bstage[idx] = (brow < l && w < wn) ? B[brow * ldb + w] : 0;
-    }
+#pragma unroll
+    for (int kk = 0; kk < NBV; ++kk)
+      if (tid + kk * NT < 256 * NW) bstage[tid + kk * NT] = bvals[kk];
     lds_barrier();
+#pragma unroll
+    for (int r = EARLY4; r < RPT; ++r) load_row(r);
     static_for<4>([&](auto gtag) __attribute__((always_inline)) {
       constexpr int g = decltype(gtag)::value;
       constexpr u32 tbase = (g & 1) ? 65536u : 0u;  // w0 is a multiple of 4: generation w0 + g lives in buffer g & 1
@@ -2427,7 +2663,8 @@ extern "C" hipError_t gf2k_tallskinny(const u64 *A, long long lda, const u64 *B,
   // 32-byte entries it runs out of registers (35 against 28 us), so it is used for n <= 64 (M4RI_HIP_TALLSKINNY_GEN4_NW=2: also
   // for n <= 128, A/B runs)
   static const int gen4_max_nw = getenv("M4RI_HIP_TALLSKINNY_GEN4_NW") ? atoi(getenv("M4RI_HIP_TALLSKINNY_GEN4_NW")) : 1;
-  if (forced_gen != 1 && forced_gen != 3 && nw <= (gen4_max_nw < 2 ? gen4_max_nw : 2)) {  // generation kernel (replicated tables, skew inside a 64-bit word)
+  static const int ts5_nw1 = getenv("M4RI_HIP_TS5_NW1") ? atoi(getenv("M4RI_HIP_TS5_NW1")) : 0;
+  if (forced_gen != 1 && forced_gen != 3 && nw <= (gen4_max_nw < 2 ? gen4_max_nw : 2) && !(ts5_nw1 && l <= 256)) {  // generation kernel (replicated tables, skew inside a 64-bit word)
     constexpr int RPT4 = 4, NT4 = 1024;
     const unsigned grid4 = (unsigned)(((long long)m + NT4 * RPT4 - 1) / (NT4 * RPT4));
     const size_t lds4 = 128 * 1024 + 8 * 1024;
@@ -2443,6 +2680,26 @@ extern "C" hipError_t gf2k_tallskinny(const u64 *A, long long lda, const u64 *B,
       GF2_TS4_LAUNCH(2);
     }
 #undef GF2_TS4_LAUNCH
+    return hipGetLastError();
+  }
+  if ((nw >= 2 || ts5_nw1) && l <= 256 && forced_gen == 0) {  // every row of A read once (gf2_tallskinny5_kernel)
+    const size_t lds5 = 128 * 1024 + 256 * 8 * (nw <= 2 ? 2 : 4);
+    const bool full = l > 192 && ((lda | ldc) & 1) == 0 && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(C)) & 15) == 0;
+    hipError_t e5 = hipSuccess;
+#define GF2_TS5_LAUNCH(NWV, RPTV, NTV, FULLV, EV)                                                                             \
+  do {                                                                                                                      \
+    e5 = lds_limit_once(reinterpret_cast<const void *>(&gf2_tallskinny5_kernel<NWV, RPTV, NTV, FULLV, false, EV, true>), (int)lds5); \
+    if (e5 != hipSuccess) return e5;                                                                                        \
+    const unsigned grid5 = (unsigned)(((long long)m + NTV * RPTV - 1) / (NTV * RPTV));                                      \
+    hipLaunchKernelGGL((gf2_tallskinny5_kernel<NWV, RPTV, NTV, FULLV, false, EV, true>), dim3(grid5), dim3(NTV), lds5, stream, A, lda, B, ldb, C, \
+                       ldc, m, l, n, accumulate);                                                                           \
+  } while (0)
+    // rows requested before the first build (EARLY) / the others one row ahead of the lookups: per-wave stamps, cold A
+    if (nw <= 2 && full) GF2_TS5_LAUNCH(2, 4, 1024, true, 1);
+    else if (nw <= 2) GF2_TS5_LAUNCH(2, 4, 1024, false, 1);
+    else if (full) GF2_TS5_LAUNCH(4, 8, 512, true, 2);
+    else GF2_TS5_LAUNCH(4, 8, 512, false, 2);
+#undef GF2_TS5_LAUNCH
     return hipGetLastError();
   }
   if (nw >= 2 && forced_gen != 1) {
@@ -2482,6 +2739,60 @@ extern "C" hipError_t gf2k_tallskinny(const u64 *A, long long lda, const u64 *B,
 #undef GF2_TS_LAUNCH
   return hipGetLastError();
 }
+
+#ifdef GF2K_DEV_VARIANTS
+// development: gf2_tallskinny5_kernel with wall-clock stamps (8 u64 per wave: start, then per phase: built, first row, last row)
+extern "C" hipError_t gf2k_tallskinny5_dbg(const u64 *A, long long lda, const u64 *B, long long ldb, u64 *C, long long ldc, int m,
+                                           int l, int n, u64 *stamps, hipStream_t stream) {
+  const int nw = (n + 63) / 64;
+  const size_t lds5 = (nw == 1 ? 64 : 128) * 1024 + 256 * 8 * nw;
+  const int variant = getenv("TS5_VARIANT") ? atoi(getenv("TS5_VARIANT")) : 0;  // 10 * EARLY + AHEAD
+#define TS5_DBG(NWV, RPTV, NTV, EARLYV, AHEADV)                                                                                   \
+  do {                                                                                                                            \
+    hipError_t e = lds_limit_once(reinterpret_cast<const void *>(&gf2_tallskinny5_kernel<NWV, RPTV, NTV, true, true, EARLYV, AHEADV>), \
+                                  (int)lds5);                                                                                     \
+    if (e != hipSuccess) return e;                                                                                                \
+    hipLaunchKernelGGL((gf2_tallskinny5_kernel<NWV, RPTV, NTV, true, true, EARLYV, AHEADV>), dim3((m + NTV * RPTV - 1) / (NTV * RPTV)), \
+                       dim3(NTV), lds5, stream, A, lda, B, ldb, C, ldc, m, l, n, 0, stamps);                                      \
+  } while (0)
+  if (nw == 1) {
+    switch (variant) {
+      case 111: TS5_DBG(1, 8, 512, 1, true); break;
+      case 121: TS5_DBG(1, 8, 512, 2, true); break;
+      case 211: TS5_DBG(1, 4, 512, 1, true); break;
+      case 221: TS5_DBG(1, 4, 512, 2, true); break;
+      case 240: TS5_DBG(1, 4, 512, 4, false); break;
+      case 311: TS5_DBG(1, 2, 512, 1, true); break;
+      case 320: TS5_DBG(1, 2, 512, 2, false); break;
+      default: TS5_DBG(1, 4, 1024, 1, true); break;
+    }
+  } else if (nw == 2) {
+    switch (variant) {
+      case 10: TS5_DBG(2, 4, 1024, 1, false); break;
+      case 11: TS5_DBG(2, 4, 1024, 1, true); break;
+      case 20: TS5_DBG(2, 4, 1024, 2, false); break;
+      case 21: TS5_DBG(2, 4, 1024, 2, true); break;
+      case 31: TS5_DBG(2, 4, 1024, 3, true); break;
+      case 111: TS5_DBG(2, 8, 512, 1, true); break;
+      case 121: TS5_DBG(2, 8, 512, 2, true); break;
+      case 131: TS5_DBG(2, 8, 512, 3, true); break;
+      case 141: TS5_DBG(2, 8, 512, 4, true); break;
+      default: TS5_DBG(2, 4, 1024, 1, false); break;
+    }
+  } else {
+    switch (variant) {
+      case 10: TS5_DBG(4, 8, 512, 1, false); break;
+      case 11: TS5_DBG(4, 8, 512, 1, true); break;
+      case 21: TS5_DBG(4, 8, 512, 2, true); break;
+      case 31: TS5_DBG(4, 8, 512, 3, true); break;
+      case 41: TS5_DBG(4, 8, 512, 4, true); break;
+      default: TS5_DBG(4, 8, 512, 2, false); break;
+    }
+  }
+#undef TS5_DBG
+  return hipGetLastError();
+}
+#endif
 
 extern "C" hipError_t gf2k_va(const u64 *A, long long lda, const u64 *B, long long ldb, u64 *C, long long ldc, int m, int l,
                               int n, hipStream_t stream) {

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from m4ri_rust_amd import device as dev
-for v in (1, 64, 256):
+for v in (1, 64, 128, 256):
     A, B, C = dev.DMat.random(1 << 20, 256, 1), dev.DMat.random(256, v, 2), dev.DMat(1 << 20, v)
     for _ in range(4):
         dev.mul(A, B, C, algo="naive")
