@@ -253,7 +253,8 @@ def test_workspace_and_level_queries_without_gpu(pkg):
     assert lib.gf2_strassen_levels(65536, 65536, 65536, M4RM, 0) == 0
     assert lib.gf2_strassen_levels(1000, 1000, 1000, AUTO, 0) == 0
     arena = lib.gf2_mul_workspace_bytes(65536, 65536, 65536, AUTO, 0)
-    assert 18 * 2**30 < arena < 20 * 2**30            # 18.7 GiB
+    # 4 levels = three fused + one virtual: 3 x 2401 leaves of 2 MiB + the seven 128 MiB level-1 products = 14.9 GiB
+    assert arena == 8 * (3 * 2401 * 4096 * 64 + 7 * 32768 * 512)
     assert lib.gf2_mul_workspace_bytes(65536, 65536, 65536, M4RM, 0) == 65536 * 1024 * 8   # packed copy of A, same footprint
     assert lib.gf2_mul_workspace_bytes(1000, 1000, 1000, M4RM, 0) == 0
     assert lib.gf2_mul_workspace_bytes(2049, 70, 1024, M4RM, 0) == 2112 * 2 * 8             # rows padded to 64, even word count
