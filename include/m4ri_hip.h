@@ -216,6 +216,17 @@ void gf2_mzd_uncache(mzd_t const *M);
  * waits for the device first.  The library otherwise keeps what it allocated: the arena of a 131072^3 product is 141 GiB. */
 int gf2_trim(void);
 
+/* Size dispatch of the drop-in entry points.  Products of at most M4RI_HIP_HOST_SMALL_WORK
+ * word operations (m * l * ceil(n / 64); default 2^20, 0 = every product goes to the device) and echelon forms of that size
+ * are computed on the host by the library's own word-parallel routines: the reference's bench shapes (10 x 10 ... 1000 x 64 x
+ * 1000, benches/binary_matrix.rs:30-76) take less time there than one PCIe round trip.  The entry points still require a
+ * usable device (no fallback: without one they fail as before).  The routines are exported so that they can be checked
+ * against the oracle without a device; gf2_host_small_calls() counts how often they ran. */
+int gf2_mul_host_small(mzd_t *C, mzd_t const *A, mzd_t const *B, int accumulate);      /* C (+)= A*B; 0 on success */
+int gf2_mul_nt_host_small(mzd_t *C, mzd_t const *A, mzd_t const *Bt, int accumulate);  /* C (+)= A*Bt^T */
+int gf2_echelonize_host_small(mzd_t *A, int full);                                      /* in place; returns the rank */
+long long gf2_host_small_calls(void);
+
 /* compact binary file format for host matrices ("GF2M", version, nrows, ncols, dense little-endian rows);
  * 0 / non-NULL on success.  (the reference only serialises to JSON, binary_matrix.rs:10-35) */
 int gf2_mzd_save(const char *path, mzd_t const *M);

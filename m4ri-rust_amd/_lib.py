@@ -106,6 +106,10 @@ _PROTOS = {
     "gf2_mzd_cache_on_device": (_I, [MzdP]),
     "gf2_mzd_uncache": (None, [MzdP]),
     "gf2_trim": (_I, []),
+    "gf2_mul_host_small": (_I, [MzdP, MzdP, MzdP, _I]),
+    "gf2_mul_nt_host_small": (_I, [MzdP, MzdP, MzdP, _I]),
+    "gf2_echelonize_host_small": (_I, [MzdP, _I]),
+    "gf2_host_small_calls": (ctypes.c_longlong, []),
     "gf2_mzd_save": (_I, [ctypes.c_char_p, MzdP]),
     "gf2_mzd_load": (MzdP, [ctypes.c_char_p]),
     "gf2_prof_enable": (None, [_I]),

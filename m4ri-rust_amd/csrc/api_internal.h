@@ -9,3 +9,6 @@ int gf2_host_transpose_gpu(mzd_t *dst, mzd_t const *src);
 int gf2_device_count(void);
 // drop the device copy kept for M by gf2_mzd_cache_on_device, if any (mzd_free and every in-place writer call this)
 void gf2_cache_forget(mzd_t const *M);
+// size dispatch of the drop-in entry points (gf2_small_host.cpp): M4RI_HIP_HOST_SMALL_WORK word operations, 0 = never
+long long gf2_small_work_limit();
+bool gf2_small_product(long long m, long long l, long long n);

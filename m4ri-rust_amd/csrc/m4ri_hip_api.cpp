@@ -1314,9 +1314,17 @@ mzd_t *host_mul_on(mzd_t *C, const mzd_t *A, const mzd_t *B, int accumulate, int
     return nullptr;
   };
   if (require_device()) return bail("no device");
-  if (!C) C = (A->nrows == 0 || B->ncols == 0) ? mzd_init(A->nrows, B->ncols) : gf2_mzd_init_uncleared(A->nrows, B->ncols);
+  // size dispatch: a product of a few thousand word operations is done on the host by the time a
+  // device call would have uploaded its operands (gf2_small_host.cpp); operands the caller pinned to the device stay there
+  const bool small = !devices && gf2_small_product(A->nrows, A->ncols, B->ncols) && !cache_lookup(A) && !cache_lookup(B);
+  if (!C) C = (small || A->nrows == 0 || B->ncols == 0) ? mzd_init(A->nrows, B->ncols) : gf2_mzd_init_uncleared(A->nrows, B->ncols);
   else gf2_cache_forget(C);  // about to be overwritten
   if (A->nrows == 0 || B->ncols == 0) return C;
+  if (small) {
+    if (gf2_mul_host_small(C, A, B, accumulate) == 0) return C;
+    if (allocated) mzd_free(C);
+    return bail("host product");
+  }
   std::vector<int> devs;
   if (devices) {
     for (int i = 0; i < ndev; ++i) {
@@ -1469,6 +1477,11 @@ extern "C" mzd_t *_mzd_mul_naive(mzd_t *C, mzd_t const *A, mzd_t const *Bt, int 
   }
   if (A->nrows == 0 || Bt->nrows == 0) return C;
   gf2_cache_forget(C);  // about to be overwritten
+  {
+    const long long lim = gf2_small_work_limit();
+    if (lim > 0 && (long long)A->nrows * Bt->nrows * A->width <= lim && !cache_lookup(A) && !cache_lookup(Bt))
+      return gf2_mul_nt_host_small(C, A, Bt, clear == 0) == 0 ? C : nullptr;  // size dispatch, see host_mul_on
+  }
   hipStream_t s;
   if (get_private_stream(&s)) return nullptr;
   int rc;
@@ -1656,6 +1669,11 @@ static int host_echelonize(mzd_t *A, int full, const char *name) {
     return 0;
   };
   if (require_device()) return bail("no device");
+  {
+    const long long lim = gf2_small_work_limit();  // size dispatch, see host_mul_on
+    if (lim > 0 && (long long)A->nrows * A->width * (A->nrows < A->ncols ? A->nrows : A->ncols) <= lim)
+      return gf2_echelonize_host_small(A, full);
+  }
   hipStream_t s;
   if (get_private_stream(&s)) return bail("stream");
   int rank = 0, rc;

@@ -23,7 +23,7 @@ static_assert(offsetof(mzd_t, flags) == 24 && offsetof(mzd_t, high_bitmask) == 4
               "mzd_t field offsets are part of the ABI");
 
 static const wi_t mzd_paddingwidth = 3;
-enum { kAllocMalloc = 0, kAllocPinned = 1 };
+enum { kAllocMalloc = 0, kAllocPinned = 1, kAllocInline = 2 };  // inline: header, block record, rows and row pointers in ONE allocation
 
 [[noreturn]] void gf2_die(const char *msg) {
   // M4RI's m4ri_die: print and abort (dimension mismatches are programming errors upstream too)
@@ -107,13 +107,21 @@ mzd_t *gf2_mzd_init_uncleared(rci_t r, rci_t c) { return mzd_init_impl(r, c, fal
 
 static mzd_t *mzd_init_impl(rci_t r, rci_t c, bool zero) {
   if (r < 0 || c < 0) gf2_die("mzd_init: negative dimension");
+  const wi_t width = (c + m4ri_radix - 1) / m4ri_radix;
+  const wi_t rowstride = (width < mzd_paddingwidth || (width & 1) == 0) ? width : width + 1;
+  const size_t bytes = (size_t)r * (size_t)rowstride * sizeof(word);
+  // Small matrices (the reference's vector <-> matrix conversions create and drop several 1 x n and n x 1 matrices per product,
+  // binary_matrix.rs:416-431,332-361) live in ONE allocation: header | block record | rows | row pointers.
+  const bool inl = r && c && bytes <= (size_t)64 * 1024;
+  const size_t data_off = 192, rows_off = inl ? data_off + ((bytes + 63) & ~(size_t)63) : 0;
+  const size_t total = inl ? rows_off + ((size_t)r + 1) * sizeof(word *) : sizeof(mzd_t);
   mzd_t *A = nullptr;
-  if (posix_memalign(reinterpret_cast<void **>(&A), 64, sizeof(mzd_t)) != 0) gf2_die("out of memory");
+  if (posix_memalign(reinterpret_cast<void **>(&A), 64, total) != 0) gf2_die("out of memory");
   std::memset(A, 0, sizeof(mzd_t));
   A->nrows = r;
   A->ncols = c;
-  A->width = (c + m4ri_radix - 1) / m4ri_radix;
-  A->rowstride = (A->width < mzd_paddingwidth || (A->width & 1) == 0) ? A->width : A->width + 1;
+  A->width = width;
+  A->rowstride = rowstride;
   A->high_bitmask = (c % m4ri_radix) ? ((m4ri_one << (c % m4ri_radix)) - 1) : m4ri_ffff;
   A->flags = (A->high_bitmask != m4ri_ffff) ? mzd_flag_nonzero_excess : 0;
   A->offset_vector = 0;
@@ -122,17 +130,27 @@ static mzd_t *mzd_init_impl(rci_t r, rci_t c, bool zero) {
   while (((long long)1 << lg) < (long long)(r > 1 ? r : 1)) ++lg;
   A->blockrows_log = lg;  // single block: (row_offset + row) >> blockrows_log == 0 for every row
   if (r && c) {
-    const size_t bytes = (size_t)r * (size_t)A->rowstride * sizeof(word);
-    mzd_block_t *blocks = static_cast<mzd_block_t *>(std::calloc(2, sizeof(mzd_block_t)));  // [1] = terminator
-    if (!blocks) gf2_die("out of memory");
+    mzd_block_t *blocks;
     uint8_t kind;
-    blocks[0].begin = static_cast<word *>(block_alloc(bytes, &kind, zero));
+    if (inl) {
+      unsigned char *base = reinterpret_cast<unsigned char *>(A);
+      blocks = reinterpret_cast<mzd_block_t *>(base + 64);
+      std::memset(blocks, 0, 2 * sizeof(mzd_block_t));  // [1] = terminator
+      blocks[0].begin = reinterpret_cast<word *>(base + data_off);
+      if (zero) std::memset(blocks[0].begin, 0, bytes);
+      kind = kAllocInline;
+      A->rows = reinterpret_cast<word **>(base + rows_off);
+    } else {
+      blocks = static_cast<mzd_block_t *>(std::calloc(2, sizeof(mzd_block_t)));  // [1] = terminator
+      if (!blocks) gf2_die("out of memory");
+      blocks[0].begin = static_cast<word *>(block_alloc(bytes, &kind, zero));
+      A->rows = static_cast<word **>(std::malloc(((size_t)r + 1) * sizeof(word *)));
+      if (!A->rows) gf2_die("out of memory");
+    }
     blocks[0].size = bytes;
     blocks[0].end = blocks[0].begin + (size_t)r * A->rowstride;
     A->padding[0] = kind;
     A->blocks = blocks;
-    A->rows = static_cast<word **>(std::malloc(((size_t)r + 1) * sizeof(word *)));
-    if (!A->rows) gf2_die("out of memory");
     for (rci_t i = 0; i < r; ++i) A->rows[i] = blocks[0].begin + (size_t)i * A->rowstride;
     A->rows[r] = nullptr;
   }
@@ -149,6 +167,10 @@ extern "C" void mzd_free(mzd_t *A) {
   // the operand cache is keyed by the block: it goes with the block's owner (a later block may get the same address);
   // freeing a window of a cached parent leaves the parent's device copy alone
   if (owns_blocks(A) || !A->blocks) gf2_cache_forget(A);
+  if (owns_blocks(A) && A->padding[0] == kAllocInline) {  // one allocation holds everything
+    std::free(A);
+    return;
+  }
   std::free(A->rows);
   if (owns_blocks(A)) {
     block_free(A->blocks[0].begin, A->padding[0], A->blocks[0].size);
@@ -287,6 +309,25 @@ extern "C" mzd_t *mzd_transpose(mzd_t *DST, mzd_t const *A) {
   }
   if (!DST) DST = mzd_init(A->ncols, A->nrows);
   if (A->nrows == 0 || A->ncols == 0) return DST;
+  // column <-> row vectors: what the friendly layer's vector products do twice per call (binary_matrix.rs:426,335)
+  if (A->ncols == 1) {  // n x 1 -> 1 x n: bit 0 of every row
+    word *d = DST->rows[0];
+    for (wi_t j = 0; j < DST->width; ++j) {
+      word v = 0;
+      const rci_t lim = (A->nrows - 64 * j < 64) ? (A->nrows - 64 * j) : 64;
+      for (rci_t r = 0; r < lim; ++r) v |= (A->rows[64 * j + r][0] & 1) << r;
+      d[j] = (j == DST->width - 1) ? ((d[j] & ~DST->high_bitmask) | (v & DST->high_bitmask)) : v;
+    }
+    return DST;
+  }
+  if (A->nrows == 1) {  // 1 x n -> n x 1
+    const word *a = A->rows[0];
+    for (rci_t c = 0; c < A->ncols; ++c) {
+      word *d = DST->rows[c];
+      *d = (*d & ~DST->high_bitmask) | ((a[c >> 6] >> (c & 63)) & 1);
+    }
+    return DST;
+  }
   word blk[64];
   for (rci_t bi = 0; bi < A->nrows; bi += 64) {
     const int nr = (A->nrows - bi < 64) ? (A->nrows - bi) : 64;

@@ -448,6 +448,50 @@ def test_multi_device_pipelined_shares(pkg, dev):
     assert np.array_equal(got, pkg.BinMatrix(single).to_words())
 
 
+# ---- size dispatch of the drop-in entry points ---------------------------------------
+
+def test_size_dispatch_of_tiny_products(pkg, monkeypatch):
+    """With the default threshold the reference's bench shapes (benches/binary_matrix.rs:30-76) are computed by the
+    library's host routines (no PCIe round trip), larger products and everything under M4RI_HIP_HOST_SMALL_WORK=0 (what
+    this suite runs with) by the HIP kernels; the bits are the same either way and equal the golden vectors."""
+    L = pkg._lib.lib()
+    shapes = sorted(glob.glob(os.path.join(GOLDEN, "bench_*.npz")))
+    assert len(shapes) >= 11
+    for path in shapes:
+        z = np.load(path)
+        m, l, n = (int(x) for x in z["dims"])
+        A, B = pkg.BinMatrix.from_words(z["a"], l), pkg.BinMatrix.from_words(z["b"], n)
+        for fn in (lambda: L.mzd_mul(None, A.mzd, B.mzd, 0), lambda: L.mzd_mul_m4rm(None, A.mzd, B.mzd, 0),
+                   lambda: L.mzd_mul_naive(None, A.mzd, B.mzd)):
+            monkeypatch.setenv("M4RI_HIP_HOST_SMALL_WORK", "0")
+            before = L.gf2_host_small_calls()
+            dev_c = pkg.BinMatrix(fn()).to_words()
+            assert L.gf2_host_small_calls() == before, "the device path was asked for"
+            monkeypatch.delenv("M4RI_HIP_HOST_SMALL_WORK")
+            host_c = pkg.BinMatrix(fn()).to_words()
+            assert L.gf2_host_small_calls() == before + 1, "default threshold: host routine"
+            assert np.array_equal(dev_c, z["c"]) and np.array_equal(host_c, z["c"]), os.path.basename(path)
+    # above the threshold nothing changes; rank of a tiny matrix takes the host elimination
+    monkeypatch.delenv("M4RI_HIP_HOST_SMALL_WORK", raising=False)
+    a, b = g.random_words(2048, 2048, 1), g.random_words(2048, 2048, 2)
+    before = L.gf2_host_small_calls()
+    Abig, Bbig = pkg.BinMatrix.from_words(a, 2048), pkg.BinMatrix.from_words(b, 2048)  # (kept alive across the call)
+    c = pkg.BinMatrix(L.mzd_mul(None, Abig.mzd, Bbig.mzd, 0)).to_words()
+    assert L.gf2_host_small_calls() == before and np.array_equal(c, g.o_mul_m4rm(a, b, 2048, 2048, 2048))
+    low = g.o_mul_naive(g.random_words(40, 7, 3), g.random_words(7, 50, 4), 40, 7, 50)
+    assert pkg.BinMatrix.from_words(low, 50).rank() == g.o_echelonize(low, 40, 50)[1] and L.gf2_host_small_calls() == before + 1
+    # an operand the caller cached on the device keeps its products there
+    A = pkg.BinMatrix.from_words(g.random_words(100, 64, 5), 64)
+    assert L.gf2_mzd_cache_on_device(A.mzd) == 0
+    before = L.gf2_host_small_calls()
+    Bm = pkg.BinMatrix.from_words(g.random_words(64, 10, 6), 10)
+    c = pkg.BinMatrix(L.mzd_mul(None, A.mzd, Bm.mzd, 0)).to_words()
+    assert L.gf2_host_small_calls() == before
+    assert np.array_equal(c, g.o_mul_naive(A.to_words(), Bm.to_words(), 100, 64, 10))
+    L.gf2_mzd_uncache(A.mzd)
+    monkeypatch.setenv("M4RI_HIP_HOST_SMALL_WORK", "0")
+
+
 # ---- re-entrancy: BinMatrix is Send + Sync (binary_matrix.rs:38-39) -------------------------------
 
 def test_concurrent_host_threads(pkg):

@@ -3,6 +3,7 @@ declares, keeps M4RI's mzd_t layout, and its host-side container functions behav
 reference's tests expect (m4ri-sys/src/mzd.rs:374-461, binary_matrix.rs:588-774, binary_vector.rs:217-288).
 No compute call is made (no GPU here): the multiply entry points must fail loudly instead."""
 import ctypes
+import glob
 import os
 import re
 import subprocess
@@ -278,3 +279,89 @@ def test_product_opt_k_follows_graycode_rs(built):
     for a, b, c in table:
         assert L.m4ri_opt_k(a, b, c) == rule(a, b, c), (a, b, c)
     assert L.m4ri_opt_k(1000, 1024, 1000) == 8 and L.m4ri_opt_k(65536, 65536, 1) == 12
+
+
+# ---- size dispatch: the host routines for tiny products (gf2_small_host.cpp), no device needed to check them ----
+
+def _bm(pkg_words, ncols):
+    import m4ri_rust_amd as pkg
+    return pkg.BinMatrix.from_words(pkg_words, ncols)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz"))),
+                         ids=os.path.basename)
+def test_host_small_product_on_golden_vectors(built, path):
+    """The host routine of the size dispatch against every committed golden vector (the reference's bench shapes,
+    m4ri-rust/benches/binary_matrix.rs:30-76, ragged sizes, LPN samples) and against the oracle; accumulate form too."""
+    from m4ri_rust_amd import _lib
+    L = _lib.lib()
+    z = np.load(path)
+    m, l, n = (int(x) for x in z["dims"])
+    A, B = _bm(z["a"], l), _bm(z["b"], n)
+    C = _bm(g.random_words(m, n, 5), n)
+    assert L.gf2_mul_host_small(C.mzd, A.mzd, B.mzd, 0) == 0
+    assert np.array_equal(C.to_words(), z["c"])
+    assert np.array_equal(C.to_words(), g.o_mul_m4rm(z["a"], z["b"], m, l, n))
+    c0 = g.random_words(m, n, 6)
+    C = _bm(c0, n)
+    assert L.gf2_mul_host_small(C.mzd, A.mzd, B.mzd, 1) == 0
+    assert np.array_equal(C.to_words(), c0 ^ z["c"])
+
+
+def test_host_small_product_shapes_windows_and_nt(built):
+    import m4ri_rust_amd as pkg
+    from m4ri_rust_amd import _lib
+    L = _lib.lib()
+    for (m, l, n) in [(1, 1, 1), (97, 8, 64), (96, 9, 65), (200, 130, 129), (300, 64, 1), (5, 700, 300), (128, 1, 200), (3, 0, 5)]:
+        a, b = g.random_words(m, l, 7 + m), g.random_words(l, n, 8 + n)
+        A, B = pkg.BinMatrix.from_words(a, l) if l else pkg.BinMatrix(L.mzd_init(m, 0)), \
+            pkg.BinMatrix.from_words(b, n) if l else pkg.BinMatrix(L.mzd_init(0, n))
+        C = pkg.BinMatrix.from_words(g.random_words(m, n, 9), n)
+        assert L.gf2_mul_host_small(C.mzd, A.mzd, B.mzd, 0) == 0
+        ref = g.o_mul_naive(a, b, m, l, n) if l else np.zeros((m, g.width(n)), dtype=np.uint64)
+        assert np.array_equal(C.to_words(), ref), (m, l, n)
+        if l:
+            bt = g.o_transpose(b, l, n)
+            Bt = pkg.BinMatrix.from_words(bt, l)
+            C2 = pkg.BinMatrix.from_words(g.random_words(m, n, 10), n)
+            assert L.gf2_mul_nt_host_small(C2.mzd, A.mzd, Bt.mzd, 0) == 0
+            assert np.array_equal(C2.to_words(), ref), ("nt", m, l, n)
+    # a window as destination keeps the parent's bits around it; windows as sources carry foreign bits past their width
+    big = g.random_words(40, 300, 11)
+    P = pkg.BinMatrix.from_words(big, 300)
+    W = L.mzd_init_window(P.mzd, 5, 64, 25, 164)     # 20 x 100 window
+    a, b = g.random_words(20, 70, 12), g.random_words(70, 100, 13)
+    assert L.gf2_mul_host_small(W, pkg.BinMatrix.from_words(a, 70).mzd, pkg.BinMatrix.from_words(b, 100).mzd, 0) == 0
+    got = g.words_to_bits(P.to_words(), 300)
+    exp = g.words_to_bits(big, 300)
+    exp[5:25, 64:164] = g.words_to_bits(g.o_mul_naive(a, b, 20, 70, 100), 100)
+    assert np.array_equal(got, exp)
+    srcA = L.mzd_init_window(P.mzd, 0, 0, 30, 36)      # 30 x 36: its only word also holds columns 36..63 of the parent
+    srcB = L.mzd_init_window(P.mzd, 0, 128, 36, 228)   # 36 x 100: its last word holds columns 228..255 of the parent
+    wa, wb = g.bits_to_words(exp[0:30, 0:36]), g.bits_to_words(exp[0:36, 128:228])
+    C = pkg.BinMatrix.zero(30, 100)
+    assert L.gf2_mul_host_small(C.mzd, srcA, srcB, 0) == 0
+    assert np.array_equal(C.to_words(), g.o_mul_naive(wa, wb, 30, 36, 100))
+    for wdw in (W, srcA, srcB):
+        L.mzd_free(wdw)
+
+
+@pytest.mark.parametrize("m,n,r", [(10, 10, 10), (64, 64, 64), (30, 200, 30), (200, 30, 12), (65, 129, 40), (1, 100, 1), (50, 50, 0)])
+def test_host_small_echelon_form(built, m, n, r):
+    import m4ri_rust_amd as pkg
+    from m4ri_rust_amd import _lib
+    L = _lib.lib()
+    if r == 0:
+        a = np.zeros((m, g.width(n)), dtype=np.uint64)
+    elif r >= min(m, n):
+        a = g.random_words(m, n, 20 + m)
+    else:
+        a = g.o_mul_naive(g.random_words(m, r, 21), g.random_words(r, n, 22), m, r, n)
+    ref, orank, _ = g.o_echelonize(a, m, n, full=True)
+    M = pkg.BinMatrix.from_words(a, n)
+    assert L.gf2_echelonize_host_small(M.mzd, 1) == orank
+    assert np.array_equal(M.to_words(), ref)
+    M = pkg.BinMatrix.from_words(a, n)
+    assert L.gf2_echelonize_host_small(M.mzd, 0) == orank
+    again, rank2, _ = g.o_echelonize(M.to_words(), m, n, full=True)   # same row space: its reduced form is the unique one
+    assert rank2 == orank and np.array_equal(again, ref)
