@@ -85,6 +85,8 @@ hipError_t gf2k_va(const uint64_t *A, long long lda, const uint64_t *B, long lon
                    int l, int n, hipStream_t stream);
 hipError_t gf2k_xor2d(uint64_t *C, long long ldc, const uint64_t *A, long long lda, const uint64_t *B, long long ldb,
                       int rows, int words, hipStream_t stream);
+hipError_t gf2k_padcopy(uint64_t *dst, long long ldd, int drows, int dwords, const uint64_t *src, long long lds_, int srows,
+                        int swords, hipStream_t stream);
 hipError_t gf2k_fill_random(uint64_t *M, long long ld, int rows, int cols, uint64_t seed, long long row0, long long fullw,
                             long long colw0, hipStream_t stream);
 hipError_t gf2k_diff(const uint64_t *A, long long lda, const uint64_t *B, long long ldb, int rows, int cols, int *diff,

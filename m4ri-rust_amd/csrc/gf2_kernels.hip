@@ -1959,6 +1959,17 @@ __global__ __launch_bounds__(256) void gf2_xor2d_kernel(u64 *__restrict__ C, lon
   }
 }
 
+// dst (drows x dwords words, dense) = src (srows x swords) in its top left corner, zeros elsewhere: operands padded up to
+// dimensions that divide by the Strassen level plan (m4ri_hip_api.cpp, mul_strassen_padded)
+__global__ __launch_bounds__(256) void gf2_padcopy_kernel(u64 *__restrict__ dst, long long ldd, int drows, int dwords,
+                                                          const u64 *__restrict__ src, long long lds_, int srows, int swords) {
+  const long long total = (long long)drows * dwords;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(idx / dwords), w = (int)(idx % dwords);
+    dst[(long long)r * ldd + w] = (r < srows && w < swords) ? src[(long long)r * lds_ + w] : 0;
+  }
+}
+
 // splitmix64 counter stream, identical to oracle_fill_random (test/bench input generator;
 // stands in for mzd_randomize, mzd.rs:183-184)
 // M holds rows [row0, row0+rows) x words [colw0, colw0 + ceil(cols/64)) of a seeded matrix that is `fullw` words wide
@@ -2818,6 +2829,15 @@ extern "C" hipError_t gf2k_xor2d(u64 *C, long long ldc, const u64 *A, long long 
   if (rows <= 0 || words <= 0) return hipSuccess;
   const long long total = (long long)rows * ((words + 1) / 2);
   hipLaunchKernelGGL(gf2_xor2d_kernel, dim3(grid_for(total)), dim3(256), 0, stream, C, ldc, A, lda, B, ldb, rows, words);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t gf2k_padcopy(u64 *dst, long long ldd, int drows, int dwords, const u64 *src, long long lds_, int srows,
+                                   int swords, hipStream_t stream) {
+  if (drows <= 0 || dwords <= 0) return hipSuccess;
+  const long long total = (long long)drows * dwords;
+  hipLaunchKernelGGL(gf2_padcopy_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, stream, dst, ldd, drows, dwords, src, lds_,
+                     srows, swords);
   return hipGetLastError();
 }
 

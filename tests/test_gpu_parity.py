@@ -624,6 +624,29 @@ def test_strassen_level_plans(dev, monkeypatch, m, l, n, levels):
         assert dev.equal(C2, expect), (fuse3, "accumulate")
 
 
+@pytest.mark.parametrize("m,l,n,levels", [(5000, 4000, 4100, 2), (6000, 6100, 6200, 3), (1030, 2049, 2050, 1), (12000, 12000, 12000, 0),
+                                          (8192, 8256, 8192, 0), (4097, 8192, 8192, 4), (8256, 8256, 8256, 2), (16448, 16500, 16390, 0),
+                                          (8200, 8192, 8192, 3), (8192, 8192, 8300, 3)])
+def test_strassen_on_dimensions_that_do_not_divide(dev, monkeypatch, m, l, n, levels):
+    """mzd_mul takes any shape (strassen.rs:8-18; upstream peels): shapes that do not divide by the level plan are padded
+    with zeros instead of losing their Strassen levels.  Same bits as plain Four Russians and as the oracle; accumulate
+    form; with the padding switched off (M4RI_HIP_STRASSEN_PAD is read once per process, so only the result is compared)."""
+    A, B = dev.DMat.random(m, l, 21), dev.DMat.random(l, n, 22)
+    ref = dev.mul(A, B, algo="m4rm")
+    rows = [0, 1, m // 2, m - 1]
+    a_rows = np.ascontiguousarray(g.random_words(m, l, 21)[rows])
+    assert np.array_equal(ref.to_words()[rows], g.o_mul_m4rm(a_rows, g.random_words(l, n, 22), len(rows), l, n))
+    C1 = dev.mul(A, B, algo="strassen", param=levels)
+    assert dev.equal(C1, ref)
+    w = C1.to_words()
+    if n % 64:
+        assert not (w[:, -1] >> np.uint64(n % 64)).any()  # excess bits stay zero
+    C2 = dev.DMat.random(m, n, 23)
+    expect = dev.add(C2, ref)
+    dev.mul(A, B, C=C2, accumulate=True, algo="auto", param=levels)
+    assert dev.equal(C2, expect)
+
+
 @pytest.mark.parametrize("kind", ["sparse", "ones", "zero_a", "identity_b"])
 def test_extreme_densities(pkg, dev, kind):
     """Sparse (density 1/64), all-ones and degenerate operands: the table kernels are data-independent, the split-K and
