@@ -343,15 +343,21 @@ def test_packed_plain_product_2gib_operand(dev):
     assert np.array_equal(dev.mul(Aw, B, algo="m4rm").to_words(), C1.to_words()[r0:r0 + rows])
 
 
-def test_host_product_pipelined_over_row_blocks(pkg, dev):
-    """Host products with >= 16384 rows are pipelined over four row blocks of A and C (uploads, products and downloads on two
-    streams).  Same bits as the device-resident product; ragged column counts; back-to-back calls reuse the streams and events."""
-    m, l, n = 16384, 16384 + 192, 16384 + 77
+@pytest.mark.parametrize("l", [16384 + 192, 16384], ids=["whole_B", "B_in_two_halves"])
+def test_host_product_pipelined_over_row_blocks(pkg, dev, l):
+    """Host products with >= 16384 rows are pipelined over four row blocks of A and C and, when the inner dimension allows,
+    two halves of it (uploads, products and downloads on three streams).  Same bits as the device-resident product; ragged
+    column counts; back-to-back calls reuse the streams and events."""
+    m, n = 16384, 16384 + 77
     A, B = pkg.BinMatrix.random(m, l), pkg.BinMatrix.random(l, n)
     a, b = A.to_words(), B.to_words()
     ref = dev.mul(dev.DMat.from_words(a, l), dev.DMat.from_words(b, n)).to_words()
     for _ in range(2):
         assert np.array_equal((A * B).to_words(), ref)
+    Lc = pkg._lib.lib()
+    for fn in (Lc.mzd_mul_m4rm, Lc.mzd_mul):
+        assert np.array_equal(pkg.BinMatrix(fn(None, A.mzd, B.mzd, 0)).to_words(), ref)
+    assert np.array_equal(pkg.BinMatrix(Lc.mzd_mul_naive(None, A.mzd, B.mzd)).to_words(), ref)
     rows = np.array([0, 4095, 4096, 8191, 12288, m - 1])
     assert np.array_equal(ref[rows], g.o_mul_m4rm(np.ascontiguousarray(a[rows]), b, len(rows), l, n))
     # three threads at once (every thread has its own pair of streams and events)
