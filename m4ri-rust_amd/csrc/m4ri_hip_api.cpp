@@ -542,7 +542,10 @@ static int pick_levels(int m, int l, int n, int req, int leaf_min) {
       best = L;
       continue;
     }
-    double t = m4rm_time_model(m >> L, l >> L, n >> L, (int)pow7(L), strassen_packs_a(m, L));
+    // a plain product packs A itself when it is tall and wide enough (mul_m4rm_plain): one more pass over A
+    const bool plain_packs = L == 0 && m >= 2048 && n >= 1024;
+    double t = m4rm_time_model(m >> L, l >> L, n >> L, (int)pow7(L), L == 0 ? plain_packs : strassen_packs_a(m, L));
+    if (plain_packs) t += 2.0 * (double)m * l / 8.0 / bw + 3e-6;
     if (L > 0) t += strassen_pass_bytes(m, l, n, L) / bw + 3 * 3e-6 * (double)strassen_plan(L).size();
     if (L == 0 || t < best_t) {
       best = L;
@@ -781,7 +784,12 @@ struct ShapePlan {
   int L = 0, mp = 0, lp = 0, np = 0;  // padded or core dimensions
   double t = 0;
 };
-static double plain_model(int m, int l, int n) { return m > 0 && l > 0 && n > 0 ? m4rm_time_model(m, l, n, 1, m >= 2048 && n >= 1024) : 0.0; }
+static double plain_model(int m, int l, int n) {
+  if (m <= 0 || l <= 0 || n <= 0) return 0.0;
+  static const double bw = (double)env_int("M4RI_HIP_STREAM_GBS", 5000) * 1e9;
+  const bool packs = m >= 2048 && n >= 1024;
+  return m4rm_time_model(m, l, n, 1, packs) + (packs ? 2.0 * (double)m * l / 8.0 / bw + 3e-6 : 0.0);
+}
 
 static ShapePlan plan_shape(int m, int l, int n, int req, int leaf_min) {
   static const double bw = (double)env_int("M4RI_HIP_STREAM_GBS", 5000) * 1e9;

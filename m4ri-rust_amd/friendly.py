@@ -324,6 +324,7 @@ class BinMatrix:
         return BinMatrix(_lib.lib().mzd_submatrix(None, self.mzd, start_row, start_col, high_row, high_col))
 
     def set_window(self, start_row, start_col, other):
+        _lib.lib().gf2_mzd_uncache(self.mzd)  # plain stores below: a device copy kept for this matrix would go stale
         z = self.mzd.contents
         for r in range(other.nrows()):
             for c in range(other.ncols()):
