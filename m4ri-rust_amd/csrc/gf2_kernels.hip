@@ -1184,21 +1184,15 @@ __global__ __launch_bounds__(256) void gf2_narrow_kernel(const u64 *__restrict__
   u64 *bt = reinterpret_cast<u64 *>(lds);  // n rows x wl words
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wl = (l + 63) >> 6;
-  for (int tw = wave; tw < wl; tw += 4) {
-    const int r = 64 * tw + lane;
-    const u64 v = (r < l) ? B[(long long)r * ldb] : 0;
-    for (int j = 0; j < n; ++j) {
-      const u64 mk = __ballot((v >> j) & 1);
-      if (lane == 0) bt[j * wl + tw] = mk;
-    }
-  }
-  __syncthreads();
   const u64 maskL = (l & 63) ? ((1ull << (l & 63)) - 1) : ~0ull;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x) {
-    const u64 *ar = A + i * lda;
-    u64 out = 0;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  // rows are fetched one iteration ahead, and the first one BEFORE the transpose of B: its latency then overlaps B's
+  constexpr int NA = WL > 0 ? WL : 1;
+  u64 cur[NA];
+  auto load_row = [&](long long row, u64 (&a)[NA]) __attribute__((always_inline)) {
     if constexpr (WL > 0) {
-      u64 a[WL];
+      const u64 *ar = A + row * lda;
       if constexpr (WL % 2 == 0) {
 #pragma unroll
         for (int t = 0; t < WL; t += 2) {
@@ -1215,9 +1209,25 @@ __global__ __launch_bounds__(256) void gf2_narrow_kernel(const u64 *__restrict__
 #pragma unroll
         for (int t = 0; t < WL; ++t) a[t] = (t < wl) ? ar[t] : 0;
       }
+    }
+  };
+  if (WL > 0 && i < m) load_row(i, cur);
+  for (int tw = wave; tw < wl; tw += 4) {
+    const int r = 64 * tw + lane;
+    const u64 v = (r < l) ? B[(long long)r * ldb] : 0;
+    for (int j = 0; j < n; ++j) {
+      const u64 mk = __ballot((v >> j) & 1);
+      if (lane == 0) bt[j * wl + tw] = mk;
+    }
+  }
+  __syncthreads();
+  for (; i < m; i += stride) {
+    u64 out = 0;
+    if constexpr (WL > 0) {
+      u64 a[WL];
 #pragma unroll
-      for (int t = 0; t < WL; ++t)
-        if (t == wl - 1) a[t] &= maskL;
+      for (int t = 0; t < WL; ++t) a[t] = (t == wl - 1) ? (cur[t] & maskL) : cur[t];
+      if (i + stride < m) load_row(i + stride, cur);
       for (int j = 0; j < n; ++j) {
         u64 x = 0;
 #pragma unroll
@@ -1226,6 +1236,7 @@ __global__ __launch_bounds__(256) void gf2_narrow_kernel(const u64 *__restrict__
         out |= (u64)(__popcll(x) & 1) << j;
       }
     } else {
+      const u64 *ar = A + i * lda;
       for (int j = 0; j < n; ++j) {
         u64 x = 0;
         for (int t = 0; t < wl; ++t) {
