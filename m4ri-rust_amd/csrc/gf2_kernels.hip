@@ -1733,6 +1733,124 @@ __global__ __launch_bounds__(NT) void gf2_tallskinny5_kernel(const u64 *__restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// tall-skinny kernel with 4-BIT tables (n <= 256, l <= 256): small workgroups that stream.
+// The kernels above build 8-bit tables (64 KiB per 256 bits of l at n = 64, up to 256 KiB at n = 256): one 512- or 1024-thread
+// workgroup per CU, whose phases -- wait for B, build, wait for rows, look up, store -- every wave of the chip goes through at
+// the same time, so that the HBM pipe idles during the build and the stores come in one burst.  With FOUR bits per table the
+// tables of all 256 bits are 8 / 16 / 32 KiB for NW = 1 / 2 / 4 words per entry: a 256-thread workgroup builds them in a
+// microsecond, eight (four) such workgroups fit a CU and run out of phase, and the rows stream through a grid-stride loop
+// with the next row in flight -- the shape of gf2_narrow_kernel, which reaches the rate of a plain copy.  Twice the lookups
+// (64 per row), but a 16-entry table spans each LDS bank at most once, so ANY mix of entries within a wave is conflict-free
+// without skewing or byte permutations: lookup = shift, and, ds_read with the table's offset as an immediate.
+// ---------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(256) void gf2_tallskinny6_kernel(const u64 *__restrict__ A, long long lda, const u64 *__restrict__ B,
+                                                              long long ldb, u64 *__restrict__ C, long long ldc, int m, int l,
+                                                              int n, int accumulate, int vec_ok) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  constexpr int EB = 8 * NW;           // bytes per entry
+  constexpr int TB = 16 * EB;          // bytes per table
+  const int tid = threadIdx.x;
+  const int wl = (l + 63) >> 6, wn = (n + 63) >> 6;
+  const u64 maskL = (l & 63) ? ((1ull << (l & 63)) - 1) : ~0ull;
+  const u64 maskC = (n & 63) ? ((1ull << (n & 63)) - 1) : ~0ull;
+  const long long stride = (long long)gridDim.x * 256;
+  long long i = (long long)blockIdx.x * 256 + tid;
+  u64 *bst = reinterpret_cast<u64 *>(lds + 64 * TB);  // the 256 rows of B, NW words each
+
+  // B first (in-order return: the build then does not wait for the row requested behind it), then this lane's first row
+  u64 bv[NW];
+#pragma unroll
+  for (int w = 0; w < NW; ++w) bv[w] = (tid < l && w < wn) ? B[(long long)tid * ldb + w] : 0;
+  u64 cur[4];
+  auto load_row = [&](long long row, u64 (&a)[4]) __attribute__((always_inline)) {
+    const u64 *ar = A + row * lda;
+    if (vec_ok) {  // l > 192, 16-byte aligned rows: two 16-byte loads
+      const uint4 lo = *reinterpret_cast<const uint4 *>(ar), hi = *reinterpret_cast<const uint4 *>(ar + 2);
+      a[0] = (u64)lo.x | ((u64)lo.y << 32);
+      a[1] = (u64)lo.z | ((u64)lo.w << 32);
+      a[2] = (u64)hi.x | ((u64)hi.y << 32);
+      a[3] = (u64)hi.z | ((u64)hi.w << 32);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a[q] = q < wl ? ar[q] : 0;
+    }
+  };
+  if (i < m) load_row(i, cur);
+#pragma unroll
+  for (int w = 0; w < NW; ++w) bst[tid * NW + w] = bv[w];
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0) only
+  __builtin_amdgcn_s_barrier();
+  // build: 64 tables x 16 entries; entry e of table t = XOR of rows 4t + b of B for the set bits b of e
+  for (int idx = tid; idx < 64 * 16; idx += 256) {
+    const int t = idx >> 4, e = idx & 15;
+    u64 v[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v[w] = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const u64 sel = 0ull - (u64)((e >> b) & 1);
+#pragma unroll
+      for (int w = 0; w < NW; ++w) v[w] ^= bst[(4 * t + b) * NW + w] & sel;
+    }
+    u64 *dst = reinterpret_cast<u64 *>(lds + idx * EB);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) dst[w] = v[w];
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_s_barrier();
+
+  for (; i < m; i += stride) {
+    u32 d[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const u64 x = (q == wl - 1) ? (cur[q] & maskL) : cur[q];
+      d[2 * q] = (u32)x;
+      d[2 * q + 1] = (u32)(x >> 32);
+    }
+    if (i + stride < m) load_row(i + stride, cur);  // the next row of this lane: in flight during the lookups
+    u32 acc[2 * NW];
+#pragma unroll
+    for (int w = 0; w < 2 * NW; ++w) acc[w] = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+#pragma unroll
+      for (int k = 0; k < 8; k += 2) {  // nibbles k and k + 1 of dword q: tables 8 q + k, 8 q + k + 1 (offsets fold to immediates)
+        const u32 t0 = (u32)(8 * q + k) * TB, t1 = t0 + TB;
+        const u32 o0 = ((d[q] >> (4 * k)) & 15u) * EB, o1 = ((d[q] >> (4 * k + 4)) & 15u) * EB;
+        if constexpr (NW == 1) {
+          const u32x2v x = *reinterpret_cast<lds_cu32x2 *>(o0 + t0), y = *reinterpret_cast<lds_cu32x2 *>(o1 + t1);
+          asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[0]) : "v"(x.x), "v"(y.x));
+          asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[1]) : "v"(x.y), "v"(y.y));
+        } else {
+          const u32x4 x = *reinterpret_cast<lds_cu32x4 *>(o0 + t0), y = *reinterpret_cast<lds_cu32x4 *>(o1 + t1);
+          asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[0]) : "v"(x.x), "v"(y.x));
+          asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[1]) : "v"(x.y), "v"(y.y));
+          asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[2]) : "v"(x.z), "v"(y.z));
+          asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[3]) : "v"(x.w), "v"(y.w));
+          if constexpr (NW == 4) {
+            const u32x4 x2 = *reinterpret_cast<lds_cu32x4 *>(o0 + t0 + 16u), y2 = *reinterpret_cast<lds_cu32x4 *>(o1 + t1 + 16u);
+            asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[4]) : "v"(x2.x), "v"(y2.x));
+            asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[5]) : "v"(x2.y), "v"(y2.y));
+            asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[6]) : "v"(x2.z), "v"(y2.z));
+            asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[7]) : "v"(x2.w), "v"(y2.w));
+          }
+        }
+      }
+    }
+    u64 *dd = C + i * ldc;
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+      if (w < wn) {
+        u64 v = (u64)acc[2 * w] | ((u64)acc[2 * w + 1] << 32);
+        if (w == wn - 1) v &= maskC;
+        if (accumulate) v ^= dd[w];
+        dd[w] = v;
+      }
+  }
+}
+
 // tall-skinny kernel with conflict-free lookups and no byte permutation ("generation" kernel; n <= 256).
 // The first kernel's lookups collide in the LDS banks (8-byte entries: 32 lanes on 32 random bank pairs, ~3.5 lanes on the
 // busiest); the skewed kernel avoids that by spreading the lanes over 32 / NW tables, which costs a byte permutation of every
@@ -2685,6 +2803,27 @@ extern "C" hipError_t gf2k_tallskinny(const u64 *A, long long lda, const u64 *B,
   // 32-byte entries it runs out of registers (35 against 28 us), so it is used for n <= 64 (M4RI_HIP_TALLSKINNY_GEN4_NW=2: also
   // for n <= 128, A/B runs)
   static const int gen4_max_nw = getenv("M4RI_HIP_TALLSKINNY_GEN4_NW") ? atoi(getenv("M4RI_HIP_TALLSKINNY_GEN4_NW")) : 1;
+  // 4-bit tables, small streaming workgroups (gf2_tallskinny6_kernel): M4RI_HIP_TS6 = bit mask of the entry widths (1, 2, 4 words) it
+  // takes.  Measured cold at 2^20 x 256 (us): 8-byte entries 11.8 against 15.0 for the generation kernel -- taken; 16-byte entries
+  // 16.0 against 14.7 and 32-byte entries 35.7 against 20.9 for gf2_tallskinny5_kernel (twice the LDS bytes per row) -- not taken
+  static const int ts6 = getenv("M4RI_HIP_TS6") ? atoi(getenv("M4RI_HIP_TS6")) : 1;
+  if (l <= 256 && forced_gen == 0 && (ts6 & (nw == 3 ? 4 : nw))) {
+    const int vec_ok = l > 192 && (lda & 1) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
+    long long blocks = ((long long)m + 255) / 256;
+    const long long cap = nw <= 2 ? 2048 : 1024;  // 8 (4) workgroups per CU
+    if (blocks > cap) blocks = cap;
+#define GF2_TS6_LAUNCH(NWV)                                                                                                       \
+  do {                                                                                                                            \
+    const size_t lds6 = 64 * 16 * 8 * NWV + 256 * 8 * NWV;                                                                        \
+    hipLaunchKernelGGL((gf2_tallskinny6_kernel<NWV>), dim3((unsigned)blocks), dim3(256), lds6, stream, A, lda, B, ldb, C, ldc, m, l, n, \
+                       accumulate, vec_ok);                                                                                       \
+  } while (0)
+    if (nw == 1) GF2_TS6_LAUNCH(1);
+    else if (nw == 2) GF2_TS6_LAUNCH(2);
+    else GF2_TS6_LAUNCH(4);
+#undef GF2_TS6_LAUNCH
+    return hipGetLastError();
+  }
   static const int ts5_nw1 = getenv("M4RI_HIP_TS5_NW1") ? atoi(getenv("M4RI_HIP_TS5_NW1")) : 0;
   if (forced_gen != 1 && forced_gen != 3 && nw <= (gen4_max_nw < 2 ? gen4_max_nw : 2) && !(ts5_nw1 && l <= 256)) {  // generation kernel (replicated tables, skew inside a 64-bit word)
     constexpr int RPT4 = 4, NT4 = 1024;
