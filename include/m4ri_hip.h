@@ -185,6 +185,9 @@ int gf2_inverse_dev(gf2_dmat *Ainv, gf2_dmat const *A, int *singular, void *stre
 /* Strassen levels a product of this shape would use right now (0 = plain M4RM): the cost model's choice, lowered until the
  * operand arena of that many levels fits into free device memory (without a device: the cost model's choice) */
 int gf2_strassen_levels(int m, int l, int n, int algo, int param);
+/* How a device product of this shape would run, by the cost model (no device needed): returns the Strassen level count;
+ * *kind = 0 the shape as given, 1 zero-padded up to dims[0..2], 2 peeled down to the core dims[0..2] (border strips plain) */
+int gf2_mul_plan(int m, int l, int n, int algo, int param, int *kind, int dims[3]);
 /* bytes the Strassen split / merge passes of a product with that many levels read and write (0 for levels == 0): every pass
  * kernel reads its sources once and writes its destinations once, so this is exact; bench.py prices the passes with it */
 double gf2_strassen_pass_bytes(int m, int l, int n, int levels);

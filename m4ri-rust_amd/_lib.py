@@ -94,6 +94,7 @@ _PROTOS = {
     "gf2_dmat_fill_random_block": (_I, [DMatP, ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64, _I, ctypes.c_void_p]),
     "gf2_strassen_levels": (_I, [_I, _I, _I, _I, _I]),
     "gf2_strassen_pass_bytes": (ctypes.c_double, [_I, _I, _I, _I]),
+    "gf2_mul_plan": (_I, [_I, _I, _I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "gf2_mul_dev": (_I, [DMatP, DMatP, DMatP, _I, _I, _I, ctypes.c_void_p]),
     "gf2_mul_nt_dev": (_I, [DMatP, DMatP, DMatP, _I, ctypes.c_void_p]),
     "gf2_add_dev": (_I, [DMatP, DMatP, DMatP, ctypes.c_void_p]),

@@ -1121,6 +1121,32 @@ extern "C" double gf2_strassen_pass_bytes(int m, int l, int n, int levels) {
   return levels > 0 ? strassen_pass_bytes(m, l, n, levels) : 0.0;
 }
 
+// How a device product of this shape would run (no device needed: the cost model's answer, before the memory cap):
+// *kind = 0 as given (levels Strassen levels, 0 = plain M4RM), 1 zero-padded to dims[0..2], 2 peeled to the core dims[0..2]
+// with the border strips through the plain kernels.  Returns the number of Strassen levels.
+extern "C" int gf2_mul_plan(int m, int l, int n, int algo, int param, int *kind, int dims[3]) {
+  int k = 0, L = 0, d[3] = {m, l, n};
+  if (algo == GF2_ALGO_AUTO || algo == GF2_ALGO_STRASSEN) {
+    static const int leaf_min = env_int("M4RI_HIP_STRASSEN_LEAF_MIN", 2048);
+    static const int pad_on = env_int("M4RI_HIP_STRASSEN_PAD", 1);
+    L = pick_levels(m, l, n, param, leaf_min);
+    const bool divides = L > 0 && (param <= 0 || L == (param > 6 ? 6 : param));
+    if (pad_on && !divides && m >= 1024 && (long long)l * n >= (1ll << 22)) {
+      const ShapePlan pp = plan_shape(m, l, n, param, leaf_min);
+      if (pp.kind && pp.L > L) {
+        k = pp.kind;
+        L = pp.L;
+        d[0] = pp.mp;
+        d[1] = pp.lp;
+        d[2] = pp.np;
+      }
+    }
+  }
+  if (kind) *kind = k;
+  if (dims) dims[0] = d[0], dims[1] = d[1], dims[2] = d[2];
+  return L;
+}
+
 extern "C" int gf2_strassen_levels(int m, int l, int n, int algo, int param) {
   if (algo != GF2_ALGO_AUTO && algo != GF2_ALGO_STRASSEN) return 0;
   static const int leaf_min = env_int("M4RI_HIP_STRASSEN_LEAF_MIN", 2048);

@@ -365,3 +365,29 @@ def test_host_small_echelon_form(built, m, n, r):
     assert L.gf2_echelonize_host_small(M.mzd, 0) == orank
     again, rank2, _ = g.o_echelonize(M.to_words(), m, n, full=True)   # same row space: its reduced form is the unique one
     assert rank2 == orank and np.array_equal(again, ref)
+
+
+def test_shape_plans_without_gpu(built):
+    """The cost model's plan for shapes that do and do not divide: dividing shapes run as given, shapes a
+    little short of a multiple are padded up, shapes a little above one are peeled down to a dividing core."""
+    import ctypes
+    from m4ri_rust_amd import _lib
+    L = _lib.lib()
+
+    def plan(m, l, n, algo=0, param=0):
+        kind, dims = ctypes.c_int(-1), (ctypes.c_int * 3)()
+        lv = L.gf2_mul_plan(m, l, n, algo, param, ctypes.byref(kind), dims)
+        return lv, kind.value, tuple(dims)
+
+    assert plan(65536, 65536, 65536) == (4, 0, (65536, 65536, 65536))
+    assert plan(32768, 32768, 32768) == (3, 0, (32768, 32768, 32768))
+    assert plan(8192, 65536, 65536)[0] == 0                       # two row tiles: too short for a level to pay
+    lv, kind, dims = plan(60000, 60000, 60000)
+    assert kind == 1 and lv in (3, 4) and all(60000 <= d <= 61440 for d in dims)   # padded up to the next multiples
+    assert dims[0] % (64 << lv) == 0 and dims[1] % (128 << lv) == 0 and dims[2] % (128 << lv) == 0
+    lv, kind, dims = plan(65600, 65600, 65600)
+    assert kind == 2 and lv == 4 and dims == (65536, 65536, 65536)   # peeled: 64 rows / columns of border
+    assert plan(1000, 1000, 1000) == (0, 0, (1000, 1000, 1000))
+    assert plan(65536, 65536, 65536, algo=1) == (0, 0, (65536, 65536, 65536))   # mzd_mul_m4rm: no levels
+    lv, kind, dims = plan(5000, 4000, 4100, algo=2, param=2)         # explicit level count on a shape that does not divide
+    assert lv == 2 and kind in (1, 2) and all(d % 256 == 0 for d in dims)
