@@ -594,7 +594,7 @@ def test_host_transpose_large_uses_device_and_matches(pkg):
 @pytest.mark.parametrize("m,l,n", [(2048, 256, 64), (2048, 256, 65), (2500, 256, 128), (3000, 256, 256), (5000, 100, 1),
                                    (4097, 300, 200), (2049, 1000, 129), (9000, 64, 255), (2300, 129, 130), (70000, 256, 37),
                                    (2048, 8, 256), (6000, 513, 64), (5000, 200, 192), (4100, 193, 100), (8197, 256, 255), (65536, 256, 128),
-                                   (4096, 255, 256), (12289, 192, 129)])
+                                   (4096, 255, 256), (12289, 192, 129), (66000, 256, 256), (65536, 250, 200), (73729, 256, 129)])
 def test_tall_skinny_shapes(pkg, dev, m, l, n):
     """n <= 256 with many rows (batches of LPN-style products): both tall-skinny kernels (one lane per row for entries
     up to 16 bytes, one quad per row above), all entry widths, ragged everything, with and without accumulation."""

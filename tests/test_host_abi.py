@@ -391,3 +391,26 @@ def test_shape_plans_without_gpu(built):
     assert plan(65536, 65536, 65536, algo=1) == (0, 0, (65536, 65536, 65536))   # mzd_mul_m4rm: no levels
     lv, kind, dims = plan(5000, 4000, 4100, algo=2, param=2)         # explicit level count on a shape that does not divide
     assert lv == 2 and kind in (1, 2) and all(d % 256 == 0 for d in dims)
+
+
+def test_host_small_product_fuzz(built):
+    """Seeded random shapes through the three strategies of the host routine (row XOR, byte tables, AND/parity) against the
+    oracle's bit-level product; every shape of the size dispatch's range of work."""
+    import m4ri_rust_amd as pkg
+    from m4ri_rust_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(2024)
+    for it in range(60):
+        m = int(rng.integers(1, 400))
+        l = int(rng.integers(1, 300))
+        n = int(rng.choice([1, 2, 7, 63, 64, 65, 100, 128, 200, 257]))
+        a, b = g.random_words(m, l, 1000 + it), g.random_words(l, n, 2000 + it)
+        if it % 5 == 0:
+            a[:] = 0  # an all-zero operand
+        A, B = pkg.BinMatrix.from_words(a, l), pkg.BinMatrix.from_words(b, n)
+        c0 = g.random_words(m, n, 3000 + it)
+        C = pkg.BinMatrix.from_words(c0, n)
+        acc = it % 2
+        assert L.gf2_mul_host_small(C.mzd, A.mzd, B.mzd, acc) == 0
+        ref = g.o_mul_bits(a, b, m, l, n) if m * l * n < 200000 else g.o_mul_naive(a, b, m, l, n)
+        assert np.array_equal(C.to_words(), ref ^ c0 if acc else ref), (m, l, n, acc)
