@@ -11,24 +11,24 @@
 // mzd.rs:246-269), row stride `ld` words (even), excess bits of the last word zero.
 //
 // Design notes:
-//  * gf2_m4rm_kernel: one workgroup owns an R x 2048-column tile of C held entirely in VGPRs
+//  * M4RM tile kernels: one workgroup owns an R x 2048-column tile of C held entirely in VGPRs
 //    (R = WAVES*RPW rows).  The inner dimension is consumed 8 bits at a time: the workgroup builds
 //    the 256-entry Four-Russians table of 8 rows of B (256 entries x 256 B = 64 KiB, double buffered
 //    in LDS, Gray-code order per half-wave), then every 16-lane group looks up the table row selected
 //    by a byte of A with one conflict-free ds_read_b128 and XORs it into its accumulators.  The table
 //    row is exactly one LDS bank row (64 banks x 4 B), so any mix of entries is conflict free.
 //    The LDS byte address is formed by ONE v_perm_b32: {0, table-select, A byte, lane offset}.
-//    Generations: gf2_m4rm_kernel (first), _v3 (instruction-count minimal; used for m <= 1024), _v5 (two chunks per lookup
-//    step folded with v_bitop3_b32, 2048 x 1024 tile), _v6 (v5 with one row of A per lane; default for plain products),
-//    _v7 (four chunks per table generation, 4096 x 512 tile; default on row-group-packed A, i.e. Strassen leaves and
-//    packed plain products).
+//    Shipped generations: _v3 (instruction-count minimal; used for m <= 1024), _v6 (two chunks per lookup step folded with
+//    v_bitop3_b32, 2048 x 1024 tile, one row of A per lane), _v7 (four chunks per table generation, 4096 x 512 tile; default on
+//    row-group-packed A, i.e. Strassen leaves and packed plain products).  The first generation and v5 live in
+//    tools/gf2_kernels_legacy.inc (development builds only).
 //  * few-tile products cut the inner dimension into slices (split-K); gf2_splitk_reduce_kernel XORs the partial tiles.
-//  * products with n <= 256 and many rows (batches of matrix x vector products) have their own Four-Russians kernels
-//    with tables over ALL of B in LDS (gf2_tallskinny4_kernel for n <= 64, gf2_tallskinny3_kernel above; gf2_tallskinny_kernel
-//    is the first form, kept for A/B runs); n <= 8 uses an AND/popcount
-//    kernel (gf2_narrow_kernel) that streams A at HBM speed.
-//  * everything else (Strassen split / merge passes, transpose, XOR, compare, fill) is an HBM-streaming kernel with
-//    16-byte accesses.  The elimination kernels live in gf2_elim.hip.
+//  * products with n <= 256, many rows and a short inner dimension (batches of matrix x vector products) have their own
+//    Four-Russians kernels with tables over B in LDS: gf2_tallskinny6_kernel (n <= 64: 4-bit tables, small streaming workgroups),
+//    gf2_tallskinny5_kernel (64 < n <= 256: 8-bit tables, every row read once), gf2_tallskinny4 / 3_kernel for 256 < l <= 1024;
+//    n <= 8 uses an AND/popcount kernel (gf2_narrow_kernel) that streams A at HBM speed.
+//  * the Strassen passes fuse three levels (and a virtual fourth) per kernel in registers (gf2_strassen_split3 / merge3_kernel);
+//    transpose, XOR, compare, fill, padding are HBM-streaming kernels with 16- or 8-byte accesses.  The elimination kernels live in gf2_elim.hip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -1254,101 +1254,12 @@ __global__ __launch_bounds__(256) void gf2_narrow_kernel(const u64 *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// tall-skinny kernel: C (m x n) (+)= A (m x l) * B (l x n) with n <= 256 and m large -- a BATCH of LPN-style
-// matrix x vector products (BASELINE config 5: A is 2^20 x 256, B holds the vectors as columns).
-// Four-Russians with the roles the shape dictates: B is tiny, so EVERY 8-bit chunk of the inner dimension gets its
-// 256-entry table of n-bit rows (NW words each) in LDS, as many chunks at a time as fit in 128 KiB; each lane owns
-// RPT rows of A, whose words it reads exactly once with 16-byte loads, and XORs the table entries selected by the
-// bytes of its rows into NW 64-bit accumulators per row.  One workgroup = 256 lanes x RPT rows; tables are rebuilt
-// per workgroup (256*l/8 entries against 256*RPT*l/8 lookups).
-// ---------------------------------------------------------------------------------------------
-
-template <int NW, int RPT, int NT>
-__global__ __launch_bounds__(NT) void gf2_tallskinny_kernel(const u64 *__restrict__ A, long long lda, const u64 *__restrict__ B,
-                                                             long long ldb, u64 *__restrict__ C, long long ldc, int m, int l,
-                                                             int n, int accumulate) {
-  extern __shared__ __align__(16) unsigned char lds[];
-  constexpr int kEntryBytes = 8 * NW;
-  constexpr int kChunksPerGroup = (128 * 1024) / (256 * kEntryBytes);  // 64 / NW chunks = 512 / NW bits of l per group
-  constexpr int kWordsPerGroup = kChunksPerGroup / 8;
-  const int tid = threadIdx.x;
-  const int wl = (l + 63) >> 6, wn = (n + 63) >> 6;
-  const u64 maskL = (l & 63) ? ((1ull << (l & 63)) - 1) : ~0ull;
-  const long long row_base = (long long)blockIdx.x * (NT * RPT);
-  u64 acc[RPT][NW];
-#pragma unroll
-  for (int r = 0; r < RPT; ++r)
-#pragma unroll
-    for (int w = 0; w < NW; ++w) acc[r][w] = 0;
-
-  for (int w0 = 0; w0 < wl; w0 += kWordsPerGroup) {  // group of 64-bit words of the inner dimension
-    const int gw = min(kWordsPerGroup, wl - w0);
-    __syncthreads();  // previous group's lookups are done
-    // stage the group's rows of B (gw*64 rows x NW words, a few KiB) behind the tables, coalesced
-    u64 *bst = reinterpret_cast<u64 *>(lds + 128 * 1024);
-    for (int idx = tid; idx < gw * 64 * NW; idx += NT) {
-      const int rr_ = idx / NW, w = idx % NW;
-      const int brow = w0 * 64 + rr_;
-      bst[idx] = (brow < l && w < wn) ? B[(long long)brow * ldb + w] : 0;
-    }
-    __syncthreads();
-    // build: thread e writes entry e of every chunk table of the group (rows come from LDS as broadcast reads)
-    const int ent_id = tid & 255;
-    for (int c = tid >> 8; c < gw * 8; c += NT / 256) {
-      u64 ent[NW];
-#pragma unroll
-      for (int w = 0; w < NW; ++w) ent[w] = 0;
-#pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        const u64 sel = 0ull - (u64)((ent_id >> b) & 1);
-#pragma unroll
-        for (int w = 0; w < NW; ++w) ent[w] ^= bst[(c * 8 + b) * NW + w] & sel;
-      }
-      u64 *dst = reinterpret_cast<u64 *>(lds + (size_t)c * 256 * kEntryBytes + (size_t)ent_id * kEntryBytes);
-#pragma unroll
-      for (int w = 0; w < NW; ++w) dst[w] = ent[w];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) {
-      const long long row = row_base + (long long)r * NT + tid;
-      if (row < m) {
-        const u64 *ar = A + row * lda + w0;
-#pragma unroll
-        for (int wq = 0; wq < kWordsPerGroup; ++wq) {
-          if (wq < gw) {
-            u64 aw = ar[wq];
-            if (w0 + wq == wl - 1) aw &= maskL;
-#pragma unroll
-            for (int by = 0; by < 8; ++by) {
-              const unsigned e = (unsigned)(aw >> (8 * by)) & 0xffu;
-              const u64 *tp = reinterpret_cast<const u64 *>(lds + (size_t)(wq * 8 + by) * 256 * kEntryBytes + (size_t)e * kEntryBytes);
-#pragma unroll
-              for (int w = 0; w < NW; ++w) acc[r][w] ^= tp[w];
-            }
-          }
-        }
-      }
-    }
-  }
-  const u64 maskC = (n & 63) ? ((1ull << (n & 63)) - 1) : ~0ull;
-#pragma unroll
-  for (int r = 0; r < RPT; ++r) {
-    const long long row = row_base + (long long)r * NT + tid;
-    if (row < m) {
-#pragma unroll
-      for (int w = 0; w < NW; ++w)
-        if (w < wn) {
-          u64 v = acc[r][w];
-          if (w == wn - 1) v &= maskC;
-          u64 *d = C + row * ldc + w;
-          if (accumulate) v ^= *d;
-          *d = v;
-        }
-    }
-  }
-}
-
+// tall-skinny kernels: C (m x n) (+)= A (m x l) * B (l x n) with n <= 256 and m large -- a BATCH of LPN-style matrix x vector
+// products (BASELINE config 5: A is 2^20 x 256, B holds the vectors as columns).  Four-Russians with the roles the shape
+// dictates: B is tiny, so the chunks of the inner dimension get their tables of n-bit rows (NW words each) in LDS; each lane
+// owns rows of A and XORs the table entries selected by the bytes (or nibbles) of its rows into NW 64-bit accumulators per row.
+// (The first form of this kernel -- 8-byte-aligned entries stored table after table, bank-conflicted lookups -- was removed in
+// round 2; its successors follow.)
 // ---------------------------------------------------------------------------------------------
 // tall-skinny kernel with skewed lookups (used for n > 64): one lane per row like the first kernel, but with
 // conflict-free LDS lookups.  A 256-B LDS row holds entry e of TPR = 32/NW tables side by side (two such row sets =
@@ -2790,25 +2701,22 @@ extern "C" hipError_t gf2k_narrow(const u64 *A, long long lda, const u64 *B, lon
 }
 
 // n <= 256; returns hipErrorInvalidValue otherwise
+// Which kernel takes a tall-skinny product (n <= 256; measured cold at 2^20 x 256, us):
+//   l <= 256, n <= 64        gf2_tallskinny6_kernel<1>   4-bit tables, small streaming workgroups       11.8  (generation kernel 15.0)
+//   l <= 256, 64 < n <= 128  gf2_tallskinny5_kernel<2>   8-bit tables, whole rows read once, one phase  14.7  (4-bit form 16.0)
+//   l <= 256, 128 < n        gf2_tallskinny5_kernel<4>   the same in two phases, 512 threads x 8 rows   20.9  (4-bit form 35.7)
+//   256 < l, n <= 64         gf2_tallskinny4_kernel<1>   generations of 64 bits of l, one built while the previous is looked up
+//   256 < l, 64 < n          gf2_tallskinny3_kernel<NW>  row sets of 32 / NW tables, rows re-fetched per row set
+// (The caller keeps l <= 1024: beyond that the tile kernel with split-K is faster.)  M4RI_HIP_TS6 = mask of the entry widths
+// (1, 2, 4 words) the 4-bit kernel takes instead (default 1); M4RI_HIP_TALLSKINNY_OLD=1 sends l <= 256 to the round-1 kernels (A/B runs).
 extern "C" hipError_t gf2k_tallskinny(const u64 *A, long long lda, const u64 *B, long long ldb, u64 *C, long long ldc, int m,
                                       int l, int n, int accumulate, hipStream_t stream) {
   if (m <= 0 || n <= 0) return hipSuccess;
   if (n > 256 || l <= 0) return hipErrorInvalidValue;
   const int nw = (n + 63) / 64;
-  // measured on 2^20 x 256 times 256 x V (us): first kernel 14.4 / 20.2 / 50.6 for V = 64 / 128 / 256, skewed kernel
-  // 22.1 / 17.5 / 33.2: the skew pays off once the entries are 16 bytes or wider (the first kernel then loses to LDS bank
-  // conflicts), below that its byte permutation costs more than the conflicts.  M4RI_HIP_TALLSKINNY_GEN=1 forces the first
-  // kernel for every width (A/B runs).
-  static const int forced_gen = getenv("M4RI_HIP_TALLSKINNY_GEN") ? atoi(getenv("M4RI_HIP_TALLSKINNY_GEN")) : 0;
-  // generation kernel: 13.6 -> 10.4 us for V = 64; for V = 128 it ties with the skewed kernel (15.9 against 16.0 us) and with
-  // 32-byte entries it runs out of registers (35 against 28 us), so it is used for n <= 64 (M4RI_HIP_TALLSKINNY_GEN4_NW=2: also
-  // for n <= 128, A/B runs)
-  static const int gen4_max_nw = getenv("M4RI_HIP_TALLSKINNY_GEN4_NW") ? atoi(getenv("M4RI_HIP_TALLSKINNY_GEN4_NW")) : 1;
-  // 4-bit tables, small streaming workgroups (gf2_tallskinny6_kernel): M4RI_HIP_TS6 = bit mask of the entry widths (1, 2, 4 words) it
-  // takes.  Measured cold at 2^20 x 256 (us): 8-byte entries 11.8 against 15.0 for the generation kernel -- taken; 16-byte entries
-  // 16.0 against 14.7 and 32-byte entries 35.7 against 20.9 for gf2_tallskinny5_kernel (twice the LDS bytes per row) -- not taken
+  static const int old_only = getenv("M4RI_HIP_TALLSKINNY_OLD") ? atoi(getenv("M4RI_HIP_TALLSKINNY_OLD")) : 0;
   static const int ts6 = getenv("M4RI_HIP_TS6") ? atoi(getenv("M4RI_HIP_TS6")) : 1;
-  if (l <= 256 && forced_gen == 0 && (ts6 & (nw == 3 ? 4 : nw))) {
+  if (l <= 256 && !old_only && (ts6 & (nw == 3 ? 4 : nw))) {
     const int vec_ok = l > 192 && (lda & 1) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
     long long blocks = ((long long)m + 255) / 256;
     const long long cap = nw <= 2 ? 2048 : 1024;  // 8 (4) workgroups per CU
@@ -2825,26 +2733,7 @@ extern "C" hipError_t gf2k_tallskinny(const u64 *A, long long lda, const u64 *B,
 #undef GF2_TS6_LAUNCH
     return hipGetLastError();
   }
-  static const int ts5_nw1 = getenv("M4RI_HIP_TS5_NW1") ? atoi(getenv("M4RI_HIP_TS5_NW1")) : 0;
-  if (forced_gen != 1 && forced_gen != 3 && nw <= (gen4_max_nw < 2 ? gen4_max_nw : 2) && !(ts5_nw1 && l <= 256)) {  // generation kernel (replicated tables, skew inside a 64-bit word)
-    constexpr int RPT4 = 4, NT4 = 1024;
-    const unsigned grid4 = (unsigned)(((long long)m + NT4 * RPT4 - 1) / (NT4 * RPT4));
-    const size_t lds4 = 128 * 1024 + 8 * 1024;
-    hipError_t e4;
-#define GF2_TS4_LAUNCH(NWV)                                                                                              \
-  e4 = lds_limit_once(reinterpret_cast<const void *>(&gf2_tallskinny4_kernel<NWV, RPT4, NT4>), (int)lds4);              \
-  if (e4 != hipSuccess) return e4;                                                                                       \
-  hipLaunchKernelGGL((gf2_tallskinny4_kernel<NWV, RPT4, NT4>), dim3(grid4), dim3(NT4), lds4, stream, A, lda, B, ldb, C, ldc, m, \
-                     l, n, accumulate)
-    if (nw == 1) {
-      GF2_TS4_LAUNCH(1);
-    } else {
-      GF2_TS4_LAUNCH(2);
-    }
-#undef GF2_TS4_LAUNCH
-    return hipGetLastError();
-  }
-  if ((nw >= 2 || ts5_nw1) && l <= 256 && forced_gen == 0) {  // every row of A read once (gf2_tallskinny5_kernel)
+  if (nw >= 2 && l <= 256 && !old_only) {  // every row of A read once (gf2_tallskinny5_kernel)
     const size_t lds5 = 128 * 1024 + 256 * 8 * (nw <= 2 ? 2 : 4);
     const bool full = l > 192 && ((lda | ldc) & 1) == 0 && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(C)) & 15) == 0;
     hipError_t e5 = hipSuccess;
@@ -2857,48 +2746,38 @@ extern "C" hipError_t gf2k_tallskinny(const u64 *A, long long lda, const u64 *B,
                        ldc, m, l, n, accumulate);                                                                           \
   } while (0)
     // rows requested before the first build (EARLY) / the others one row ahead of the lookups: per-wave stamps, cold A
-    if (nw <= 2 && full) GF2_TS5_LAUNCH(2, 4, 1024, true, 1);
-    else if (nw <= 2) GF2_TS5_LAUNCH(2, 4, 1024, false, 1);
+    if (nw == 2 && full) GF2_TS5_LAUNCH(2, 4, 1024, true, 1);
+    else if (nw == 2) GF2_TS5_LAUNCH(2, 4, 1024, false, 1);
     else if (full) GF2_TS5_LAUNCH(4, 8, 512, true, 2);
     else GF2_TS5_LAUNCH(4, 8, 512, false, 2);
 #undef GF2_TS5_LAUNCH
     return hipGetLastError();
   }
-  if (nw >= 2 && forced_gen != 1) {
-    constexpr int RPT3 = 4, NT3 = 1024;
-    const unsigned grid3 = (unsigned)(((long long)m + NT3 * RPT3 - 1) / (NT3 * RPT3));
-    const size_t lds3 = 128 * 1024 + 4 * 1024;
-    hipError_t e3;
+  if (nw == 1) {  // generation kernel (replicated tables, skew inside a 64-bit word)
+    constexpr int RPT4 = 4, NT4 = 1024;
+    const unsigned grid4 = (unsigned)(((long long)m + NT4 * RPT4 - 1) / (NT4 * RPT4));
+    const size_t lds4 = 128 * 1024 + 8 * 1024;
+    hipError_t e4 = lds_limit_once(reinterpret_cast<const void *>(&gf2_tallskinny4_kernel<1, RPT4, NT4>), (int)lds4);
+    if (e4 != hipSuccess) return e4;
+    hipLaunchKernelGGL((gf2_tallskinny4_kernel<1, RPT4, NT4>), dim3(grid4), dim3(NT4), lds4, stream, A, lda, B, ldb, C, ldc, m, l, n,
+                       accumulate);
+    return hipGetLastError();
+  }
+  constexpr int RPT3 = 4, NT3 = 1024;
+  const unsigned grid3 = (unsigned)(((long long)m + NT3 * RPT3 - 1) / (NT3 * RPT3));
+  const size_t lds3 = 128 * 1024 + 4 * 1024;
+  hipError_t e3;
 #define GF2_TS3_LAUNCH(NWV)                                                                                              \
   e3 = lds_limit_once(reinterpret_cast<const void *>(&gf2_tallskinny3_kernel<NWV, RPT3, NT3>), (int)lds3);              \
   if (e3 != hipSuccess) return e3;                                                                                       \
   hipLaunchKernelGGL((gf2_tallskinny3_kernel<NWV, RPT3, NT3>), dim3(grid3), dim3(NT3), lds3, stream, A, lda, B, ldb, C, ldc, m, \
                      l, n, accumulate)
-    if (nw == 2) {
-      GF2_TS3_LAUNCH(2);
-    } else {
-      GF2_TS3_LAUNCH(4);
-    }
-#undef GF2_TS3_LAUNCH
-    return hipGetLastError();
-  }
-  constexpr int RPT = 4, NT = 1024;
-  const unsigned grid = (unsigned)(((long long)m + NT * RPT - 1) / (NT * RPT));
-  const size_t lds = 128 * 1024 + 8 * 64 * 8;  // tables + staged rows of B (8 words x 64 rows x NW/NW ... = 4 KiB)
-  hipError_t e;
-#define GF2_TS_LAUNCH(NWV)                                                                                             \
-  e = lds_limit_once(reinterpret_cast<const void *>(&gf2_tallskinny_kernel<NWV, RPT, NT>), (int)lds);                    \
-  if (e != hipSuccess) return e;                                                                                       \
-  hipLaunchKernelGGL((gf2_tallskinny_kernel<NWV, RPT, NT>), dim3(grid), dim3(NT), lds, stream, A, lda, B, ldb, C, ldc, m, l, n, \
-                     accumulate)
-  if (nw == 1) {
-    GF2_TS_LAUNCH(1);
-  } else if (nw == 2) {
-    GF2_TS_LAUNCH(2);
+  if (nw == 2) {
+    GF2_TS3_LAUNCH(2);
   } else {
-    GF2_TS_LAUNCH(4);
+    GF2_TS3_LAUNCH(4);
   }
-#undef GF2_TS_LAUNCH
+#undef GF2_TS3_LAUNCH
   return hipGetLastError();
 }
 
