@@ -90,6 +90,8 @@ int mzd_is_zero(mzd_t const *A);                                   /* mzd.rs:233
 void mzd_row_swap(mzd_t *M, rci_t rowa, rci_t rowb);               /* mzd.rs:130 */
 void mzd_copy_row(mzd_t *B, rci_t i, mzd_t const *A, rci_t j);     /* mzd.rs:141 */
 int m4ri_opt_k(int a, int b, int c);                               /* graycode.rs:56 */
+/* T[L[v]] = XOR of the rows r + j of M with bit j of v set, for every k-bit v; Gray-code order; host. brilliantrussian.rs:8-17 */
+void mzd_make_table(mzd_t const *M, rci_t r, rci_t c, int k, mzd_t *T, rci_t *L);
 
 /* --- the hot path: every product below runs on the GPU --- */
 

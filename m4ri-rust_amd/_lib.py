@@ -69,6 +69,7 @@ _PROTOS = {
     "mzd_row_swap": (None, [MzdP, _I, _I]),
     "mzd_copy_row": (None, [MzdP, _I, MzdP, _I]),
     "m4ri_opt_k": (_I, [_I, _I, _I]),
+    "mzd_make_table": (None, [MzdP, _I, _I, _I, MzdP, ctypes.POINTER(_I)]),
     "mzd_echelonize": (_I, [MzdP, _I]),
     "mzd_echelonize_m4ri": (_I, [MzdP, _I, _I]),
     "mzd_echelonize_pluq": (_I, [MzdP, _I]),

@@ -435,6 +435,31 @@ extern "C" void mzd_copy_row(mzd_t *B, rci_t i, mzd_t const *A, rci_t j) {
   copy_row_masked(B->rows[i], A->rows[j], A->width, A->high_bitmask);
 }
 
+// mzd_make_table (brilliantrussian.rs:8-17): T (2^k rows, preallocated, M->ncols columns) receives every XOR combination of the k
+// rows r .. r + k - 1 of M, L (2^k entries) the row of T that holds the combination selected by a k-bit value v (bit j of v <->
+// row r + j): T[L[v]] = XOR of the rows r + j with bit j of v set.  Rows of T are generated in Gray-code order (each from its
+// predecessor by ONE row addition), as the declaration says; only the words from column c on are written, like upstream
+// (the elimination routines that call it never look left of their current column).  The device kernels build their tables
+// in LDS themselves (gf2_kernels.hip); this host form completes the declared surface of section 8 row a9.
+extern "C" void mzd_make_table(mzd_t const *M, rci_t r, rci_t c, int k, mzd_t *T, rci_t *L) {
+  if (k < 0 || k > 24 || r < 0 || c < 0 || r + k > M->nrows || T->nrows < (1 << k) || T->ncols < M->ncols)
+    gf2_die("mzd_make_table: bad arguments");
+  gf2_cache_forget(T);
+  const wi_t w0 = c / m4ri_radix, w = M->width;
+  for (wi_t j = w0; j < w; ++j) T->rows[0][j] = 0;
+  L[0] = 0;
+  unsigned combo = 0;  // the k-bit value whose combination the current row holds
+  for (unsigned i = 1; i < (1u << k); ++i) {
+    const int flip = __builtin_ctz(i);  // the bit in which Gray-code words i - 1 and i differ
+    combo ^= 1u << flip;
+    const word *src = M->rows[r + flip], *prev = T->rows[i - 1];
+    word *dst = T->rows[i];
+    for (wi_t j = w0; j + 1 < w; ++j) dst[j] = prev[j] ^ src[j];
+    if (w > w0) dst[w - 1] = prev[w - 1] ^ (src[w - 1] & M->high_bitmask);
+    L[combo] = (rci_t)i;
+  }
+}
+
 extern "C" int m4ri_opt_k(int a, int b, int c) {
   // graycode.rs:44-56: "0.75 log_2(n) where n is min(a,b) for inversion and b for multiplication" (c != 0 = multiplication).
   // Only a hint on this side of the ABI: the tile kernels' tables are fixed at 8 bits by the LDS bank-row geometry.

@@ -414,3 +414,37 @@ def test_host_small_product_fuzz(built):
         assert L.gf2_mul_host_small(C.mzd, A.mzd, B.mzd, acc) == 0
         ref = g.o_mul_bits(a, b, m, l, n) if m * l * n < 200000 else g.o_mul_naive(a, b, m, l, n)
         assert np.array_equal(C.to_words(), ref ^ c0 if acc else ref), (m, l, n, acc)
+
+
+def test_mzd_make_table(built):
+    """brilliantrussian.rs:8-17: every XOR combination of k rows, Gray-code order (each row of T one row addition away from its
+    predecessor), L maps the k-bit selector to the row of T; checked against sums formed bit by bit with numpy."""
+    import m4ri_rust_amd as pkg
+    from m4ri_rust_amd import _lib
+    L = _lib.lib()
+    for (rows, cols, r, c, k) in [(20, 200, 3, 0, 5), (9, 64, 1, 0, 8), (40, 300, 30, 128, 6), (4, 70, 0, 64, 1), (3, 10, 2, 0, 0)]:
+        a = g.random_words(rows, cols, 50 + k)
+        M = pkg.BinMatrix.from_words(a, cols)
+        junk = g.random_words(1 << k, cols, 60 + k)
+        T = pkg.BinMatrix.from_words(junk, cols)
+        Larr = (ctypes.c_int * (1 << k))(*([-1] * (1 << k)))
+        L.mzd_make_table(M.mzd, r, c, k, T.mzd, Larr)
+        t = T.to_words()
+        w0 = c // 64
+        bits = g.words_to_bits(a, cols)
+        seen = set()
+        for v in range(1 << k):
+            expect = np.zeros(cols, dtype=np.uint8)
+            for j in range(k):
+                if (v >> j) & 1:
+                    expect ^= bits[r + j]
+            row = Larr[v]
+            assert 0 <= row < (1 << k) and row not in seen
+            seen.add(row)
+            got = g.words_to_bits(t[row:row + 1], cols)[0]
+            assert np.array_equal(got[64 * w0:], expect[64 * w0:]), (rows, cols, r, c, k, v)
+            assert np.array_equal(t[row, :w0], junk[row, :w0])       # words left of column c are not touched
+        assert Larr[0] == 0
+        for i in range(1, 1 << k):  # Gray order: consecutive rows differ by exactly one row of M
+            d = t[i, w0:] ^ t[i - 1, w0:]
+            assert any(np.array_equal(d, a[r + j, w0:]) for j in range(k))
