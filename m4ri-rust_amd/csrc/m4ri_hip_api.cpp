@@ -526,12 +526,12 @@ static double strassen_pass_bytes(double m, double l, double n, int L) {
 //   t(L) = modelled time of the batched leaf launch (rounds of 256 workgroups x chunks x measured cycles per
 //          chunk, split-K included)  +  bytes moved by the split / merge passes / bw
 // `leaf_min` bounds the leaf dimensions from below (mzd_mul's cutoff argument, strassen.rs:8-18).
-static int pick_levels(int m, int l, int n, int req, int leaf_min) {
+static int pick_levels(int m, int l, int n, int req, int leaf_min, double *t_out = nullptr) {
   static const int max_auto = env_int("M4RI_HIP_STRASSEN_MAX_LEVELS", 5);
   static const double bw = (double)env_int("M4RI_HIP_STREAM_GBS", 5000) * 1e9;        // streaming B/s
   const int cap = req > 0 ? (req > 6 ? 6 : req) : max_auto;
   int best = 0;
-  double best_t = 0;
+  double best_t = 0, t0 = 0;
   for (int L = 0; L <= cap; ++L) {
     if (L > 0) {
       const int d = 1 << L;
@@ -547,11 +547,16 @@ static int pick_levels(int m, int l, int n, int req, int leaf_min) {
     double t = m4rm_time_model(m >> L, l >> L, n >> L, (int)pow7(L), L == 0 ? plain_packs : strassen_packs_a(m, L));
     if (plain_packs) t += 2.0 * (double)m * l / 8.0 / bw + 3e-6;
     if (L > 0) t += strassen_pass_bytes(m, l, n, L) / bw + 3 * 3e-6 * (double)strassen_plan(L).size();
+    if (L == 0) t0 = t;
     if (L == 0 || t < best_t) {
       best = L;
       best_t = t;
     }
   }
+  // the model is coarse for products of a few hundred microseconds (12288^3 measured 0.47 ms with one level against 0.39 ms
+  // plain although the model preferred the level): levels must promise 8 % to be taken
+  if (req <= 0 && best > 0 && best_t > 0.92 * t0) best = 0, best_t = t0;
+  if (t_out) *t_out = best_t;
   return best;
 }
 
@@ -791,36 +796,58 @@ static double plain_model(int m, int l, int n) {
   return m4rm_time_model(m, l, n, 1, packs) + (packs ? 2.0 * (double)m * l / 8.0 / bw + 3e-6 : 0.0);
 }
 
+// a border strip runs through the automatic choice among the level counts that divide it (no further padding / peeling)
+static double strip_model(int m, int l, int n, int leaf_min) {
+  if (m <= 0 || l <= 0 || n <= 0) return 0.0;
+  double t = 0;
+  (void)pick_levels(m, l, n, 0, leaf_min, &t);
+  return t + 3e-6;
+}
+
 static ShapePlan plan_shape(int m, int l, int n, int req, int leaf_min) {
   static const double bw = (double)env_int("M4RI_HIP_STREAM_GBS", 5000) * 1e9;
   static const int max_auto = env_int("M4RI_HIP_STRASSEN_MAX_LEVELS", 5);
   static const int debug = env_int("M4RI_HIP_DEBUG_PLAN", 0);
   ShapePlan best;
-  best.t = plain_model(m, l, n);
+  const double plain = plain_model(m, l, n);
+  best.t = plain;
   if (debug) std::fprintf(stderr, "m4ri_hip plan %d x %d x %d: plain %.3f ms\n", m, l, n, best.t * 1e3);
   const int lo = req > 0 ? (req > 6 ? 6 : req) : 1, hi = req > 0 ? lo : max_auto;
   bool forced_done = false;
+  auto consider = [&](int kind, int L, long long mm, long long ll, long long nn, double t) {
+    if (debug) std::fprintf(stderr, "  L=%d %s %lld x %lld x %lld: %.3f ms\n", L, kind == 1 ? "pad " : "peel", mm, ll, nn, t * 1e3);
+    // (not forced:) the model is coarse: a plan must promise 8 % over plain M4RM to be taken
+    if ((req > 0 && !forced_done) || (t < best.t && (req > 0 || t < 0.92 * plain))) best = {kind, L, (int)mm, (int)ll, (int)nn, t}, forced_done = true;
+  };
   for (int L = lo; L <= hi; ++L) {
     const long long um = 64ll << L, uw = 128ll << L;
     auto core_time = [&](long long mm, long long ll, long long nn) {
-      return m4rm_time_model((int)(mm >> L), (int)(ll >> L), (int)(nn >> L), (int)pow7(L), true) +
+      return m4rm_time_model((int)(mm >> L), (int)(ll >> L), (int)(nn >> L), (int)pow7(L), strassen_packs_a((int)mm, L)) +
              strassen_pass_bytes((double)mm, (double)ll, (double)nn, L) / bw + 3 * 3e-6 * (double)strassen_plan(L).size();
+    };
+    auto leaves_ok = [&](long long mm, long long ll, long long nn) {
+      return req > 0 || ((mm >> L) >= 1024 && (ll >> L) >= leaf_min && (nn >> L) >= leaf_min);
     };
     // pad: round up
     const long long mu = ((long long)m + um - 1) / um * um, lu = ((long long)l + uw - 1) / uw * uw, nu = ((long long)n + uw - 1) / uw * uw;
-    if (mu <= 0x7fffffff && lu <= 0x7fffffff && nu <= 0x7fffffff &&
-        (req > 0 || ((mu >> L) >= 1024 && (lu >> L) >= leaf_min && (nu >> L) >= leaf_min))) {
-      const double t = core_time(mu, lu, nu) + 2.0 * ((double)mu * lu + (double)lu * nu + (double)mu * nu) / 8.0 / bw + 3 * 3e-6;
-      if (debug) std::fprintf(stderr, "  L=%d pad  %lld x %lld x %lld: %.3f ms\n", L, mu, lu, nu, t * 1e3);
-      if (t < best.t || (req > 0 && !forced_done)) best = {1, L, (int)mu, (int)lu, (int)nu, t}, forced_done = true;
-    }
-    // peel: round down
+    if (mu <= 0x7fffffff && lu <= 0x7fffffff && nu <= 0x7fffffff && leaves_ok(mu, lu, nu))
+      consider(1, L, mu, lu, nu, core_time(mu, lu, nu) + 2.0 * ((double)mu * lu + (double)lu * nu + (double)mu * nu) / 8.0 / bw + 3 * 3e-6);
+    // peel: round down -- to the plan's unit, and to whole tiles of the leaf kernel (4096 rows, 512 columns per leaf: a 4352-row
+    // leaf occupies two row tiles, so 70000 is better served by a 65536-row core than by a 69632-row one)
+    auto peel = [&](long long md, long long ld, long long nd) {
+      if (md <= 0 || ld <= 0 || nd <= 0 || !leaves_ok(md, ld, nd)) return;
+      if (md == m && ld == l && nd == n) return;  // the shape as given: pick_levels' business
+      consider(2, L, md, ld, nd,
+               core_time(md, ld, nd) + strip_model((int)md, l - (int)ld, (int)nd, leaf_min) + strip_model((int)md, l, n - (int)nd, leaf_min) +
+                   strip_model(m - (int)md, l, n, leaf_min));
+    };
     const long long md = (long long)m / um * um, ld = (long long)l / uw * uw, nd = (long long)n / uw * uw;
-    if (md > 0 && ld > 0 && nd > 0 && (req > 0 || ((md >> L) >= 1024 && (ld >> L) >= leaf_min && (nd >> L) >= leaf_min))) {
-      const double t = core_time(md, ld, nd) + plain_model((int)md, l - (int)ld, (int)nd) + plain_model((int)md, l, n - (int)nd) +
-                       plain_model(m - (int)md, l, n) + 4 * 3e-6;
-      if (debug) std::fprintf(stderr, "  L=%d peel %lld x %lld x %lld: %.3f ms\n", L, md, ld, nd, t * 1e3);
-      if (t < best.t || (req > 0 && best.kind == 1 && t < best.t)) best = {2, L, (int)md, (int)ld, (int)nd, t}, forced_done = true;
+    peel(md, ld, nd);
+    const long long tm = 4096ll << L, tn = 512ll << L;
+    const long long md2 = (long long)m / tm * tm, nd2 = (long long)n / tn * tn;
+    if (md2 != md || nd2 != nd) {
+      peel(md2 ? md2 : md, ld, nd2 ? nd2 : nd);
+      if (md2 && md2 != md && nd2 != nd) peel(md2, ld, nd);
     }
   }
   if (debug) std::fprintf(stderr, "  -> kind %d L=%d (%d x %d x %d) %.3f ms\n", best.kind, best.L, best.mp, best.lp, best.np, best.t * 1e3);
@@ -828,6 +855,7 @@ static ShapePlan plan_shape(int m, int l, int n, int req, int leaf_min) {
 }
 
 static int mul_strassen(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int accumulate, int L, hipStream_t s, bool sync_free);
+static int cap_levels_by_memory(int m, int l, int n, int L, hipStream_t s);
 
 static int mul_strassen_padded(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int accumulate, const ShapePlan &pp, hipStream_t s) {
   const int m = A->nrows, l = A->ncols, n = B->ncols;
@@ -851,17 +879,24 @@ static int mul_strassen_peeled(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B
   const int mc = pp.mp, lc = pp.lp, nc = pp.np;
   gf2_dmat Ac{A->data, A->ld, mc, lc}, Bc{B->data, B->ld, lc, nc}, Cc{C->data, C->ld, mc, nc};
   if (int rc = mul_strassen(&Cc, &Ac, &Bc, accumulate, pp.L, s, false)) return rc;
+  // a border strip: the level count among those that divide it (no further padding / peeling), capped by memory
+  auto strip = [&](gf2_dmat *Cs, const gf2_dmat *As, const gf2_dmat *Bs, int acc) -> int {
+    static const int leaf_min = env_int("M4RI_HIP_STRASSEN_LEAF_MIN", 2048);
+    int Ls = pick_levels(As->nrows, As->ncols, Bs->ncols, 0, leaf_min);
+    Ls = cap_levels_by_memory(As->nrows, As->ncols, Bs->ncols, Ls, s);
+    return mul_strassen(Cs, As, Bs, acc, Ls, s, false);
+  };
   if (l > lc) {  // tail of the inner dimension: core block of C ^= A[0:mc, lc:l] * B[lc:l, 0:nc]
     gf2_dmat At{A->data + lc / 64, A->ld, mc, l - lc}, Bt{B->data + (long long)lc * B->ld, B->ld, l - lc, nc};
-    if (int rc = mul_m4rm_plain(&Cc, &At, &Bt, 1, s)) return rc;
+    if (int rc = strip(&Cc, &At, &Bt, 1)) return rc;
   }
   if (n > nc) {  // right columns
     gf2_dmat Ar{A->data, A->ld, mc, l}, Br{B->data + nc / 64, B->ld, l, n - nc}, Cr{C->data + nc / 64, C->ld, mc, n - nc};
-    if (int rc = mul_m4rm_plain(&Cr, &Ar, &Br, accumulate, s)) return rc;
+    if (int rc = strip(&Cr, &Ar, &Br, accumulate)) return rc;
   }
   if (m > mc) {  // bottom rows
     gf2_dmat Ab{A->data + (long long)mc * A->ld, A->ld, m - mc, l}, Cb{C->data + (long long)mc * C->ld, C->ld, m - mc, n};
-    if (int rc = mul_m4rm_plain(&Cb, &Ab, B, accumulate, s)) return rc;
+    if (int rc = strip(&Cb, &Ab, B, accumulate)) return rc;
   }
   return 0;
 }
