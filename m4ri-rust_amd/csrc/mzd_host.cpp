@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <emmintrin.h>
 #include <map>
 #include <mutex>
 
@@ -310,12 +311,21 @@ extern "C" mzd_t *mzd_transpose(mzd_t *DST, mzd_t const *A) {
   if (!DST) DST = mzd_init(A->ncols, A->nrows);
   if (A->nrows == 0 || A->ncols == 0) return DST;
   // column <-> row vectors: what the friendly layer's vector products do twice per call (binary_matrix.rs:426,335)
-  if (A->ncols == 1) {  // n x 1 -> 1 x n: bit 0 of every row
+  if (A->ncols == 1) {  // n x 1 -> 1 x n: bit 0 of every row (as_vector of every `&A * &v`: 2^20 rows in the LPN configuration)
     word *d = DST->rows[0];
+    const bool dense = A->rowstride == 1 && !(A->flags & mzd_flag_windowed_zerooffset);  // one word per row, rows back to back
     for (wi_t j = 0; j < DST->width; ++j) {
       word v = 0;
       const rci_t lim = (A->nrows - 64 * j < 64) ? (A->nrows - 64 * j) : 64;
-      for (rci_t r = 0; r < lim; ++r) v |= (A->rows[64 * j + r][0] & 1) << r;
+      if (dense && lim == 64) {  // two rows per step: bit 0 moved to the sign position, gathered by movmskpd (SSE2: x86-64 baseline)
+        const word *src = A->rows[64 * j];
+        for (int r = 0; r < 64; r += 2) {
+          const __m128i x = _mm_slli_epi64(_mm_loadu_si128(reinterpret_cast<const __m128i *>(src + r)), 63);
+          v |= (word)_mm_movemask_pd(_mm_castsi128_pd(x)) << r;
+        }
+      } else {
+        for (rci_t r = 0; r < lim; ++r) v |= (A->rows[64 * j + r][0] & 1) << r;
+      }
       d[j] = (j == DST->width - 1) ? ((d[j] & ~DST->high_bitmask) | (v & DST->high_bitmask)) : v;
     }
     return DST;
