@@ -436,6 +436,34 @@ def test_multi_device_shares_through_c_abi(pkg, dev, monkeypatch, m, l, n, share
     assert not L.gf2_mul_multi(None, A.mzd, B.mzd, dev.ALGO_AUTO, 0, bad, 2)
 
 
+def test_multi_device_shares_from_several_host_threads(pkg, dev, monkeypatch):
+    """BinMatrix is Send + Sync: several host threads issue products that are each divided among device shares (worker threads,
+    leased streams, per-share buffers) at the same time."""
+    import threading
+    L = pkg._lib.lib()
+    nvis = dev.device_count()
+    monkeypatch.setenv("M4RI_HIP_DEVICES", ",".join(str(i % nvis) for i in range(3)))
+    cases = []
+    for k, (m, l, n) in enumerate([(3100, 2050, 1030), (4096, 1024, 2048), (2500, 300, 5000)]):
+        a, b = g.random_words(m, l, 50 + k), g.random_words(l, n, 60 + k)
+        cases.append((pkg.BinMatrix.from_words(a, l), pkg.BinMatrix.from_words(b, n), g.o_mul_m4rm(a, b, m, l, n)))
+    bad = []
+
+    def worker(k):
+        for it in range(4):
+            A, B, ref = cases[(k + it) % len(cases)]
+            c = (L.mzd_mul, L.mzd_mul_m4rm)[it & 1](None, A.mzd, B.mzd, 0)
+            if not c or not np.array_equal(pkg.BinMatrix(c).to_words(), ref):
+                bad.append((k, it))
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t_ in ts:
+        t_.start()
+    for t_ in ts:
+        t_.join()
+    assert not bad, bad
+
+
 def test_multi_device_pipelined_shares(pkg, dev):
     """Shares large enough for the per-device upload / compute / download pipeline (>= 16384 rows each)."""
     import ctypes
