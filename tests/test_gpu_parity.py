@@ -381,6 +381,22 @@ def test_host_product_pipelined_over_row_blocks(pkg, dev, l):
     assert np.array_equal((A2 * B).to_words(), ref2)
 
 
+def test_algebraic_identities_on_random_shapes(dev):
+    """(AB)^T = B^T A^T, (AB)C = A(BC), A(B + B') = AB + AB', A I = A -- on seeded random shapes through every
+    algorithm selector, device resident (each identity mixes kernels: tile / tall-skinny / narrow / v*A, transpose, XOR)."""
+    rng = np.random.default_rng(77)
+    for it in range(12):
+        m, l, n, k = (int(rng.choice([1, 7, 64, 65, 300, 1000, 2048, 3000, 4500])) for _ in range(4))
+        A, B, B2, C = dev.DMat.random(m, l, 4 * it), dev.DMat.random(l, n, 4 * it + 1), dev.DMat.random(l, n, 4 * it + 2), dev.DMat.random(n, k, 4 * it + 3)
+        algo = ("auto", "m4rm", "naive")[it % 3]
+        AB = dev.mul(A, B, algo=algo)
+        assert dev.equal(dev.transpose(AB), dev.mul(dev.transpose(B), dev.transpose(A), algo=algo)), ("transpose", m, l, n)
+        assert dev.equal(dev.mul(AB, C, algo=algo), dev.mul(A, dev.mul(B, C, algo=algo), algo=algo)), ("associativity", m, l, n, k)
+        assert dev.equal(dev.mul(A, dev.add(B, B2), algo=algo), dev.add(AB, dev.mul(A, B2, algo=algo))), ("distributivity", m, l, n)
+        I = dev.DMat.from_words(g.bits_to_words(np.eye(l, dtype=np.uint8)), l)
+        assert dev.equal(dev.mul(A, I, algo=algo), A), ("identity", m, l)
+
+
 def test_dev_properties_full_size(dev):
     """Size-independent properties at a BASELINE config size (32768): linearity in B and
     associativity with a vector, (A*B)*x == A*(B*x)."""
