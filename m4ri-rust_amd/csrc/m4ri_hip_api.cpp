@@ -438,8 +438,27 @@ static int m4rm_ksplit_for(int m, int l, int n, int batch, int cfg) {
   static const int forced = env_int("M4RI_HIP_M4RM_KSPLIT", 0);
   if (forced > 0) return forced;
   const long long wg = tiles_of(tile_geom(cfg), m, n) * batch;
-  if (wg >= 192) return 1;
   const int nw32 = (l + 31) / 32;
+  if (wg >= 192) {
+    // All tiles of a launch take the same time, so 520 workgroups cost three rounds of 256 where 2.03 would do.  A single plain
+    // product may cut the inner dimension into a few slices to even the rounds out (the slices' partial tiles cost one write and
+    // one read of C per slice): rounds(ks) / ks tile-times + ks passes over C, minimised over ks <= 8.
+    static const int balance = env_int("M4RI_HIP_SPLITK_BALANCE", 1);
+    static const long long cap = (long long)env_int("M4RI_HIP_SPLITK_WS_MIB", 2048) << 20;
+    if (!balance || batch != 1 || wg > 2048) return 1;
+    const TileGeom g = tile_geom(cfg, cfg == 8 || cfg == 9);
+    const double tile_cyc = (double)nw32 * 4.0 * g.cyc_per_chunk;                       // one whole-k tile
+    const double pass_cyc = 2.0 * (double)m * (double)n / 8.0 / 5.0e12 * 2.4e9;         // write + read of one slice's partial C
+    int best = 1;
+    double best_c = std::ceil(wg / 256.0) * (tile_cyc + 20000.0);
+    for (int ks = 2; ks <= 8; ++ks) {
+      if (nw32 / ks < 16) break;                                                        // slices of at least 512 bits
+      if ((long long)ks * m * ((words_of(n) + 1) & ~1) * 8 > cap) break;
+      const double c = std::ceil(wg * ks / 256.0) * (tile_cyc / ks + 20000.0) + ks * pass_cyc;
+      if (c < 0.93 * best_c) best = ks, best_c = c;
+    }
+    return best;
+  }
   long long ks = 256 / wg;  // one round of workgroups: 256 long slices beat 512 short ones (8192x65536x16384: 2.25 vs 2.52 ms)
   if (ks > nw32 / 4) ks = nw32 / 4;  // slices of at least 128 bits
   return ks < 1 ? 1 : (int)ks;
@@ -630,7 +649,7 @@ static int mul_m4rm_plain(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int
   a.accumulate = accumulate;
   a.ksplit = m4rm_ksplit_for(m, l, n, 1, cfg);
   if (a.ksplit > 1) {  // slices store partial products that a second kernel combines (atomic XOR costs about 3x as much)
-    static const long long cap = (long long)env_int("M4RI_HIP_SPLITK_WS_MIB", 512) << 20;
+    static const long long cap = (long long)env_int("M4RI_HIP_SPLITK_WS_MIB", 2048) << 20;
     a.ldp = (words_of(n) + 1) & ~1ll;
     a.sP = (long long)m * a.ldp;
     const long long bytes = a.sP * a.ksplit * (long long)sizeof(u64);
