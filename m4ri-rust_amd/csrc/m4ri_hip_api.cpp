@@ -1399,13 +1399,24 @@ int host_mul_range(mzd_t *C, const mzd_t *A, const mzd_t *B, int r0, int r1, int
     if (!rc) rc = to_device(dB, B, side->s2, K == 1);  // K == 2: allocated here, uploaded in halves below
     if (!rc) rc = to_device_rows(dA, A, r0, r1, s, false);
     if (!rc) rc = to_device_rows(dC, C, r0, r1, s, false);
-    const int R = rows / pipe_blocks;
+    // block boundaries: four equal blocks, or -- when a quarter still has 16384 rows -- a quarter, a half and a quarter: the
+    // half-size block multiplies at the rate of the big tiles (32768 x 32768 x 65536: 8.2 ms against 2 x 4.5 ms for two quarters)
+    // while the first and the last block stay short (quick start, short tail of the download)
+    std::vector<int> bnd;
+    {
+      const int q = rows / pipe_blocks;
+      if (pipe_blocks == 4 && q >= 16384) bnd = {0, q, 3 * q, rows};
+      else
+        for (int i = 0; i <= pipe_blocks; ++i) bnd.push_back(i * q);
+    }
+    const int NBLK = (int)bnd.size() - 1;
     auto rows_bytes = [](const mzd_t *M, int nr) { return ((size_t)(nr - 1) * M->rowstride + M->width) * sizeof(word); };
     if (!rc && (dA.d.ld != A->rowstride || dC.d.ld != C->rowstride || (K == 2 && dB.d.ld != B->rowstride)))
       rc = fail_msg("host pipeline: unexpected device stride");
     hipEvent_t *evA = side ? side->ev.data() : nullptr, *evC = evA + pipe_blocks, *evB = evC + pipe_blocks;
     auto upload_a = [&](int i) {
-      if (hipMemcpyAsync(dA.d.data + (size_t)i * R * dA.d.ld, A->rows[r0 + i * R], rows_bytes(A, R), hipMemcpyHostToDevice, side->s2) != hipSuccess ||
+      if (hipMemcpyAsync(dA.d.data + (size_t)bnd[i] * dA.d.ld, A->rows[r0 + bnd[i]], rows_bytes(A, bnd[i + 1] - bnd[i]), hipMemcpyHostToDevice,
+                         side->s2) != hipSuccess ||
           hipEventRecord(evA[i], side->s2) != hipSuccess)
         rc = fail(hipGetLastError(), "host pipeline: upload of A");
     };
@@ -1416,15 +1427,16 @@ int host_mul_range(mzd_t *C, const mzd_t *A, const mzd_t *B, int r0, int r1, int
         rc = fail(hipGetLastError(), "host pipeline: upload of B");
       if (!rc && hipEventRecord(evB[k], side->s2) != hipSuccess) rc = fail(hipGetLastError(), "host pipeline: event");
     }
-    for (int i = 1; !rc && i < pipe_blocks; ++i) upload_a(i);
-    for (int i = 0; !rc && i < pipe_blocks; ++i) {
+    for (int i = 1; !rc && i < NBLK; ++i) upload_a(i);
+    for (int i = 0; !rc && i < NBLK; ++i) {
+      const int R = bnd[i + 1] - bnd[i];
       gf2_dmat c = dC.d;
-      c.data += (size_t)i * R * c.ld;
+      c.data += (size_t)bnd[i] * c.ld;
       c.nrows = R;
       if (hipStreamWaitEvent(s, evA[i], 0) != hipSuccess) rc = fail(hipGetLastError(), "host pipeline: wait");
       for (int k = 0; !rc && k < K; ++k) {
         gf2_dmat a = dA.d, b = dB.d;
-        a.data += (size_t)i * R * a.ld + (size_t)k * (l / K) / 64;
+        a.data += (size_t)bnd[i] * a.ld + (size_t)k * (l / K) / 64;
         a.nrows = R;
         a.ncols = l / K;
         b.data += (size_t)k * (l / K) * b.ld;
@@ -1433,7 +1445,7 @@ int host_mul_range(mzd_t *C, const mzd_t *A, const mzd_t *B, int r0, int r1, int
         if (!rc) rc = mul_dispatch(&c, &a, &b, k > 0, algo, param, s, /*sync_free=*/false);
       }
       if (!rc && (hipEventRecord(evC[i], s) != hipSuccess || hipStreamWaitEvent(side->s3, evC[i], 0) != hipSuccess ||
-                  hipMemcpyAsync(C->rows[r0 + i * R], c.data, rows_bytes(C, R), hipMemcpyDeviceToHost, side->s3) != hipSuccess))
+                  hipMemcpyAsync(C->rows[r0 + bnd[i]], c.data, rows_bytes(C, R), hipMemcpyDeviceToHost, side->s3) != hipSuccess))
         rc = fail(hipGetLastError(), "host pipeline: download");
     }
     if (side && hipStreamSynchronize(side->s2) != hipSuccess && !rc) rc = fail(hipGetLastError(), "host pipeline: upload stream");
