@@ -97,6 +97,107 @@ def _cpu_baseline(args):
     return out, c
 
 
+def _golden_digests():
+    """Committed full-size digests (tests/golden/digests_large.json, written by tests/golden/make_golden_large.py): data, not
+    the oracle -- the bench compares the products it has just timed with them."""
+    out = {}
+    for name in ("digests.json", "digests_large.json"):
+        try:
+            with open(os.path.join(ROOT, "tests", "golden", name)) as f:
+                out.update(json.load(f))
+        except (OSError, ValueError):
+            pass
+    return out
+
+
+def _sha256_of(dmat, stream):
+    import hashlib
+    return hashlib.sha256(dmat.to_words(stream).tobytes()).hexdigest()
+
+
+def _timed(fn, reps, torch):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(reps):
+        fn(i)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def _extra_configs(device, torch, stream):
+    """The other single-GPU BASELINE.json configurations, timed in the same run as the headline (device resident, wall clock
+    around `reps` back-to-back products on the bench stream) and hashed against the committed digests:
+      config 2  4096^3, M4RM kernel only;  config 3  32768^3, Strassen over M4RM;
+      config 5  2^20 x 256 times 256 x V, V = 1 / 64 / 256, COLD: ten A (and C) buffers visited round-robin, 320 MiB of A
+                between two uses of the same buffer -- more than the 256 MiB Infinity Cache holds."""
+    dig = _golden_digests()
+    out = []
+
+    def entry(name, m, l, n, algo, dt, sha, key, extra=None):
+        wl, wn = (l + 63) // 64, (n + 63) // 64
+        layout = 8.0 * (m * wl + l * wn + m * wn)  # operands in the M4RI layout (rows padded to 64-bit words), each moved once
+        e = {"workload": name, "m": m, "l": l, "n": n, "algo": algo, "ms": dt * 1e3, "bit_ops_per_s": 2.0 * m * l * n / dt,
+             "roofline": {"bound": "hbm", "achieved": layout / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": layout / dt / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": layout},
+             "strassen_levels": device._lib.lib().gf2_strassen_levels(m, l, n, device.ALGOS[algo], 0)}
+        if extra:
+            e.update(extra)
+        want = dig.get(key, {}).get("sha256_c")
+        e["parity_sha256_ok"] = (sha == want) if want else None
+        out.append(e)
+
+    def onchip(m, l, n, dt):  # every 8 bits of the inner dimension cost one 16-byte LDS read per 128 columns (M4RM, k = 8)
+        lds = m * (l / 8.0) * (n / 128.0) * 16.0
+        return {"roofline_onchip": {"bound": "lds", "achieved": lds / dt / 1e12, "peak": LDS_PEAK_TBS, "unit": "TB/s",
+                                    "frac": lds / dt / 1e12 / LDS_PEAK_TBS,
+                                    "note": "plain M4RM read count; Strassen levels lower the reads actually made"}}
+
+    for name, nn, algo, reps, key in (("config 2: 4096^3, M4RM kernel only", 4096, "m4rm", 200, "sq_4096"),
+                                      ("config 3: 32768^3, Strassen over M4RM", 32768, "auto", 10, "sq_32768")):
+        A, B, C = device.DMat.random(nn, nn, 1, stream), device.DMat.random(nn, nn, 2, stream), device.DMat(nn, nn)
+        for _ in range(3):
+            device.mul(A, B, C=C, algo=algo, stream=stream)
+        dt = _timed(lambda i: device.mul(A, B, C=C, algo=algo, stream=stream), reps, torch)
+        entry(name, nn, nn, nn, algo, dt, _sha256_of(C, stream), key, onchip(nn, nn, nn, dt))
+        del A, B, C
+    m, l, nbuf = 1 << 20, 256, 10
+    As = [device.DMat.random(m, l, 1 if i == 0 else 100 + i, stream) for i in range(nbuf)]
+    for V in (1, 64, 256):
+        X = device.DMat.random(l, V, 2, stream)
+        Cs = [device.DMat(m, V) for _ in range(nbuf)]
+        for i in range(2 * nbuf):
+            device.mul(As[i % nbuf], X, C=Cs[i % nbuf], algo="naive", stream=stream)
+        dt = _timed(lambda i: device.mul(As[i % nbuf], X, C=Cs[i % nbuf], algo="naive", stream=stream), 20 * nbuf, torch)
+        entry("config 5: LPN 2^20 x 256 times 256 x %d (mzd_mul_naive entry), cold: %d rotating A buffers" % (V, nbuf),
+              m, l, V, "naive", dt, _sha256_of(Cs[0], stream), "lpn_1048576x256x%d" % V)
+        del Cs, X
+    del As
+    return out
+
+
+def _sharded_self_check(device, sharded, torch, Bp, Cfull_t, n, world, stream):
+    """Cheap default check of a multi-GPU step (rank 0): eight consecutive rows out of every rank's row block (at least 32
+    rows in all, offsets from a fixed seed) are re-multiplied by rank 0 alone from the seeded generator and compared with the
+    rows of C the ranks produced and RCCL gathered."""
+    import random
+    rng = random.Random(20261004)
+    rows = n // world
+    grp = max(8, -(-32 // world))
+    starts = [r * rows + rng.randrange(0, rows - grp + 1) for r in range(world)]
+    As_t = torch.empty((grp * world, n // 64), dtype=torch.int64, device="cuda")
+    for k, r0 in enumerate(starts):
+        sharded.fill_row_block(device.DMat.from_torch(As_t[k * grp:(k + 1) * grp], n), seed=1, row0=r0, stream=stream)
+    idx = torch.tensor([r0 + j for r0 in starts for j in range(grp)], device="cuda")
+    As = device.DMat.from_torch(As_t, n)
+    import numpy as np
+    ok = True
+    for pnl in range(len(Bp)):
+        ref = device.mul(As, Bp[pnl], algo="m4rm", stream=stream).to_words(stream)
+        got = Cfull_t[pnl][idx].cpu().numpy().view(np.uint64)
+        ok = ok and bool(np.array_equal(got, ref))
+    return {"rows_checked": int(idx.numel()), "row_starts": starts, "ok": bool(ok)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,6 +218,9 @@ def main():
                     help="how a panel of B reaches the ranks: one broadcast, or scatter from rank 0 + all-gather")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--check", action="store_true", help="spot-check rows of C against the oracle after timing")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="N = 1: skip the other single-GPU BASELINE configurations (2, 3, 5) that are timed after the headline loop")
+    ap.add_argument("--no-parity", action="store_true", help="skip the sha256 / sampled-row self-checks of the timed products")
     ap.add_argument("--density", default="half", choices=["half", "sparse", "ones"],
                     help="N = 1 only: bit density of the synthetic operands -- half = i.i.d. Bernoulli(1/2) (the metric's "
                          "workload), sparse = 1/64, ones = all ones (clock / data-dependence sanity runs, SURVEY.md section 8d)")
@@ -237,11 +341,18 @@ def main():
     device.prof_enable(False)
     launches, kernel_ms = device.prof_read(reset=True)
 
+    dt_local = dt
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    rank_info = None
+    if world > 1:
+        mine = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(),
+                "name": torch.cuda.get_device_name(torch.cuda.current_device()), "ms": dt_local * 1e3}
+        rank_info = [None] * world
+        dist.all_gather_object(rank_info, mine)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -259,6 +370,15 @@ def main():
             ref = device.mul(A_full, Bp[pnl], algo=args.algo, param=args.levels, stream=stream)
             sharded_ok = sharded_ok and device.equal(ref, device.DMat.from_torch(Cfull_t[pnl], ncp), stream)
         del A_full
+
+    self_check = None
+    if world > 1 and not args.no_parity:
+        self_check = _sharded_self_check(device, sharded, torch, Bp, Cfull_t, n, world, stream)
+    parity = None
+    if world == 1 and not args.no_parity and args.density == "half":
+        want = _golden_digests().get("sq_%d" % n, {}).get("sha256_c")
+        if want:
+            parity = _sha256_of(C, stream) == want  # the product of the LAST timed step
 
     # dominant kernel: the (batched) M4RM tile kernel. Algorithmic bytes of ONE launch = what that
     # launch's products read and write once: batch * (m*l + l*n + m*n)/8 with the leaf dims.
@@ -330,6 +450,16 @@ def main():
     }
     if sharded_ok is not None:
         out["sharded_result_matches_single_gpu"] = bool(sharded_ok)
+    if parity is not None:
+        out["parity_sha256_ok"] = bool(parity)
+        out["parity_note"] = "sha256 of the last timed %d^3 product == tests/golden/digests_large.json[sq_%d]" % (n, n)
+    if world > 1:
+        out["ranks_seen"] = dist.get_world_size()
+        out["backend"] = dist.get_backend()
+        out["ranks"] = rank_info
+        if self_check is not None:
+            out["self_check"] = self_check
+            out["parity_rows_ok"] = self_check["ok"]
     if world == 1 and levels > 0 and launches:
         # the rest of a step is the Strassen split / merge passes (same stream, serial): HBM-streaming kernels whose
         # bytes are known exactly (every pass reads its sources once and writes its destinations once; the library's own count)
@@ -350,6 +480,8 @@ def main():
             Ad, Bd = device.DMat.random(cn, cn, 1), device.DMat.random(cn, cn, 2)
             out["cpu_baseline"]["gpu_matches_cpu_sample"] = bool(
                 np.array_equal(device.mul(Ad, Bd, algo=args.algo, param=args.levels).to_words(), cpu_sample))
+    if world == 1 and not args.no_configs and args.density == "half":
+        out["configs"] = _extra_configs(device, torch, stream)
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

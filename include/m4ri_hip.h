@@ -89,6 +89,10 @@ mzd_t *mzd_submatrix(mzd_t *S, mzd_t const *M, rci_t lowr, rci_t lowc, rci_t hig
 int mzd_is_zero(mzd_t const *A);                                   /* mzd.rs:233 */
 void mzd_row_swap(mzd_t *M, rci_t rowa, rci_t rowb);               /* mzd.rs:130 */
 void mzd_copy_row(mzd_t *B, rci_t i, mzd_t const *A, rci_t j);     /* mzd.rs:141 */
+void mzd_col_swap(mzd_t *M, rci_t cola, rci_t colb);               /* mzd.rs:144 */
+void mzd_row_clear_offset(mzd_t *M, rci_t row, rci_t coloffset);   /* mzd.rs:235-240 */
+/* inverse of A by elimination of [A | identity] (identity NULL: built here; inv NULL: allocated); NULL if A is singular. mzd.rs:214-218 */
+mzd_t *mzd_invert_naive(mzd_t *inv, mzd_t const *A, mzd_t const *identity);
 int m4ri_opt_k(int a, int b, int c);                               /* graycode.rs:56 */
 /* T[L[v]] = XOR of the rows r + j of M with bit j of v set, for every k-bit v; Gray-code order; host. brilliantrussian.rs:8-17 */
 void mzd_make_table(mzd_t const *M, rci_t r, rci_t c, int k, mzd_t *T, rci_t *L);

@@ -68,6 +68,9 @@ _PROTOS = {
     "mzd_is_zero": (_I, [MzdP]),
     "mzd_row_swap": (None, [MzdP, _I, _I]),
     "mzd_copy_row": (None, [MzdP, _I, MzdP, _I]),
+    "mzd_col_swap": (None, [MzdP, _I, _I]),
+    "mzd_row_clear_offset": (None, [MzdP, _I, _I]),
+    "mzd_invert_naive": (MzdP, [MzdP, MzdP, MzdP]),
     "m4ri_opt_k": (_I, [_I, _I, _I]),
     "mzd_make_table": (None, [MzdP, _I, _I, _I, MzdP, ctypes.POINTER(_I)]),
     "mzd_echelonize": (_I, [MzdP, _I]),

@@ -160,22 +160,18 @@ void dev_free(void *p, size_t bytes) {
   pool.cached += bytes;
 }
 
-struct TlsStream {
-  hipStream_t s = nullptr;
-  int dev = -1;
-};
-thread_local TlsStream tls_stream;
+// private per-thread streams of the host (mzd_t) entry points, one per device: concurrent calls from several host threads
+// (BinMatrix is Send + Sync) never serialise on, or race through, a shared stream.  A thread that alternates between
+// devices (a pinned multiply, then an elimination on the original device) gets the SAME stream back for each of them,
+// so the per-stream arenas (g_ws) are reused instead of being stranded behind a replaced stream.
+thread_local hipStream_t tls_streams[16] = {};
 
-// private per-thread stream of the host (mzd_t) entry points: concurrent calls from several host threads
-// (BinMatrix is Send + Sync) never serialise on, or race through, a shared stream
 int get_private_stream(hipStream_t *out) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
-  if (!tls_stream.s || tls_stream.dev != dev) {
-    HIP_TRY(hipStreamCreateWithFlags(&tls_stream.s, hipStreamNonBlocking));
-    tls_stream.dev = dev;
-  }
-  *out = tls_stream.s;
+  if (dev < 0 || dev >= 16) return fail_msg("device ordinal out of range (0..15)");
+  if (!tls_streams[dev]) HIP_TRY(hipStreamCreateWithFlags(&tls_streams[dev], hipStreamNonBlocking));
+  *out = tls_streams[dev];
   return 0;
 }
 
@@ -215,7 +211,10 @@ void reap_deferred(bool wait) {
 int free_after(hipStream_t s, void *p, size_t bytes) {
   hipEvent_t ev;
   HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-  HIP_TRY(hipEventRecord(ev, s));
+  if (hipError_t e = hipEventRecord(ev, s); e != hipSuccess) {  // e.g. a destroyed stream or one of another device
+    (void)hipEventDestroy(ev);
+    return fail(e, "hipEventRecord");
+  }
   std::lock_guard<std::mutex> lk(g_deferred_mu);
   g_deferred.push_back({ev, p, bytes});
   return 0;
@@ -874,7 +873,7 @@ static ShapePlan plan_shape(int m, int l, int n, int req, int leaf_min) {
 }
 
 static int mul_strassen(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int accumulate, int L, hipStream_t s, bool sync_free);
-static int cap_levels_by_memory(int m, int l, int n, int L, hipStream_t s);
+static int cap_levels_by_memory(int m, int l, int n, int L, hipStream_t s, size_t extra_bytes = 0);
 
 static int mul_strassen_padded(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int accumulate, const ShapePlan &pp, hipStream_t s) {
   const int m = A->nrows, l = A->ncols, n = B->ncols;
@@ -962,7 +961,8 @@ static std::mutex g_enqueue_mu;
 
 // The operand arena of L levels must fit: what the driver reports free plus what this library already holds (its block
 // cache and this stream's current arena are handed back before a larger one is allocated).
-static int cap_levels_by_memory(int m, int l, int n, int L, hipStream_t s) {
+// `extra_bytes`: what the caller allocates besides the arena (the zero-padded copies of a padded product).
+static int cap_levels_by_memory(int m, int l, int n, int L, hipStream_t s, size_t extra_bytes) {
   if (L <= 0) return L;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
@@ -983,7 +983,7 @@ static int cap_levels_by_memory(int m, int l, int n, int L, hipStream_t s) {
     mine += pool.cached;
   }
   const size_t avail = (size_t)((free_b + mine) * 0.95);
-  while (L > 0 && strassen_ws_words(m, l, n, L) * sizeof(u64) > avail) --L;
+  while (L > 0 && strassen_ws_words(m, l, n, L) * sizeof(u64) + extra_bytes > avail) --L;
   return L;
 }
 
@@ -1011,7 +1011,9 @@ static int mul_dispatch(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int a
       if (pad_on && !divides && m >= 1024 && (long long)l * n >= (1ll << 22)) {  // lost levels to divisibility (or to odd strides)?
         ShapePlan pp = plan_shape(m, l, n, param, leaf_min);
         if (pp.kind == 2 && !even) pp.kind = 0;  // peeling works on views of the caller's buffers
-        if (pp.kind && pp.L > L && cap_levels_by_memory(pp.mp, pp.lp, pp.np, pp.L, s) == pp.L) {
+        // a padded product also holds the three padded copies (slot 3) next to the arena
+        const size_t pad_bytes = pp.kind == 1 ? ((size_t)pp.mp * (pp.lp / 64) + (size_t)pp.lp * (pp.np / 64) + (size_t)pp.mp * (pp.np / 64)) * sizeof(u64) : 0;
+        if (pp.kind && pp.L > L && cap_levels_by_memory(pp.mp, pp.lp, pp.np, pp.L, s, pad_bytes) == pp.L) {
           int rc = pp.kind == 1 ? mul_strassen_padded(C, A, B, accumulate, pp, s) : mul_strassen_peeled(C, A, B, accumulate, pp, s);
           if (rc == 0 && sync_free && hipStreamSynchronize(s) != hipSuccess) rc = fail(hipGetLastError(), "hipStreamSynchronize");
           return rc;
@@ -1463,25 +1465,37 @@ int host_mul_range(mzd_t *C, const mzd_t *A, const mzd_t *B, int r0, int r1, int
   return rc;
 }
 
-// Devices a host product of this shape is spread over.  M4RI_HIP_DEVICES: unset / "auto" = every visible device once the
-// product is large enough to pay for a copy of B per device; "all"; or a comma-separated list of device ordinals (an
-// ordinal may repeat: two shares on one device -- how the one-GPU test box exercises this path).
+// Devices a host product of this shape is spread over.  M4RI_HIP_DEVICES: unset = the current device only (the fan-out is
+// opt-in: it has not been measured on a multi-GPU box yet, and under torchrun every rank sees every GPU); "auto" = every
+// visible device once the product is large enough to pay for a copy of B per device -- ignored inside a torch.distributed
+// job (WORLD_SIZE > 1), where the ranks already own a device each; "all"; or a comma-separated list of device ordinals
+// (an ordinal may repeat: two shares on one device -- how the one-GPU test box exercises this path; ONE ordinal pins every
+// host entry point -- products, elimination, transpose, operand cache -- to that device).
+std::vector<int> parse_device_list(const char *e) {
+  std::vector<int> out;
+  const int nvis = gf2_device_count();
+  for (const char *p = e; p && *p;) {
+    char *end = nullptr;
+    const long d = std::strtol(p, &end, 10);
+    if (end == p) break;
+    if (d >= 0 && d < nvis) out.push_back((int)d);
+    p = (*end == ',') ? end + 1 : end;
+    if (*end && *end != ',') break;
+  }
+  return out;
+}
+
 std::vector<int> pick_devices(long long m, long long l, long long n) {
   const char *e = std::getenv("M4RI_HIP_DEVICES");
   std::vector<int> out;
+  if (!e || !*e) return out;
   const int nvis = gf2_device_count();
-  if (e && *e && std::strcmp(e, "auto") != 0 && std::strcmp(e, "all") != 0) {
-    for (const char *p = e; *p;) {
-      char *end = nullptr;
-      const long d = std::strtol(p, &end, 10);
-      if (end == p) break;
-      if (d >= 0 && d < nvis) out.push_back((int)d);
-      p = (*end == ',') ? end + 1 : end;
-      if (*end && *end != ',') break;
-    }
-    return out;
+  const bool autom = std::strcmp(e, "auto") == 0, all = std::strcmp(e, "all") == 0;
+  if (!autom && !all) return parse_device_list(e);
+  if (autom) {
+    const char *ws = std::getenv("WORLD_SIZE");
+    if (ws && std::atoi(ws) > 1) return out;  // one process per GPU already
   }
-  const bool all = e && std::strcmp(e, "all") == 0;
   // automatic: a share should keep >= 4096 rows (tall tiles) and the product should outweigh moving B once more per device
   if (nvis > 1 && (all || (2.0 * (double)m * (double)l * (double)n >= 7.0e13 && m >= 8192))) {
     int k = nvis;
@@ -1490,6 +1504,28 @@ std::vector<int> pick_devices(long long m, long long l, long long n) {
   }
   return out;
 }
+
+// M4RI_HIP_DEVICES = one ordinal: every host entry point runs on that device.  RAII: sets it, restores the caller's.
+struct PinnedDevice {
+  int prev = -1;
+  bool switched = false;
+  PinnedDevice() {
+    const char *e = std::getenv("M4RI_HIP_DEVICES");
+    if (!e || !*e || std::strcmp(e, "auto") == 0 || std::strcmp(e, "all") == 0) return;
+    const std::vector<int> d = parse_device_list(e);
+    if (d.size() != 1) return;
+    if (hipGetDevice(&prev) != hipSuccess) {
+      (void)hipGetLastError();
+      return;
+    }
+    if (prev != d[0] && hipSetDevice(d[0]) == hipSuccess) switched = true;
+  }
+  ~PinnedDevice() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+  PinnedDevice(const PinnedDevice &) = delete;
+  PinnedDevice &operator=(const PinnedDevice &) = delete;
+};
 
 // C (+)= A*B with the rows of A and C divided among `devs` (one worker thread per share; each uploads its rows of A and
 // its own copy of B over its own PCIe link, multiplies, and downloads its rows of C).  Shares are independent: the inner
@@ -1626,6 +1662,7 @@ extern "C" int gf2_mzd_cache_on_device(mzd_t const *M) {
   if (int rc = require_device()) return rc;
   if (!M || M->nrows == 0 || M->ncols == 0) return fail_msg("gf2_mzd_cache_on_device: empty matrix");
   gf2_cache_forget(M);
+  PinnedDevice pin;  // M4RI_HIP_DEVICES = one ordinal: run there
   hipStream_t s;
   if (int rc = get_private_stream(&s)) return rc;
   DMatOwner o;
@@ -1648,6 +1685,7 @@ extern "C" void gf2_mzd_uncache(mzd_t const *M) { gf2_cache_forget(M); }
 
 int gf2_host_transpose_gpu(mzd_t *dst, mzd_t const *src) {
   if (require_device()) return -1;
+  PinnedDevice pin;  // M4RI_HIP_DEVICES = one ordinal: run there
   hipStream_t s;
   if (get_private_stream(&s)) return -1;
   DMatOwner dS, dD;
@@ -1714,6 +1752,7 @@ extern "C" mzd_t *_mzd_mul_naive(mzd_t *C, mzd_t const *A, mzd_t const *Bt, int 
     if (lim > 0 && (long long)A->nrows * Bt->nrows * A->width <= lim && !cache_lookup(A) && !cache_lookup(Bt))
       return gf2_mul_nt_host_small(C, A, Bt, clear == 0) == 0 ? C : nullptr;  // size dispatch, see host_mul_on
   }
+  PinnedDevice pin;  // M4RI_HIP_DEVICES = one ordinal: run there
   hipStream_t s;
   if (get_private_stream(&s)) return nullptr;
   int rc;
@@ -1906,6 +1945,7 @@ static int host_echelonize(mzd_t *A, int full, const char *name) {
     if (lim > 0 && (long long)A->nrows * A->width * (A->nrows < A->ncols ? A->nrows : A->ncols) <= lim)
       return gf2_echelonize_host_small(A, full);
   }
+  PinnedDevice pin;  // M4RI_HIP_DEVICES = one ordinal: run there
   hipStream_t s;
   if (get_private_stream(&s)) return bail("stream");
   int rank = 0, rc;
@@ -1938,6 +1978,7 @@ extern "C" mzd_t *mzd_inv_m4ri(mzd_t *dst, mzd_t const *src, int k) {
   if (require_device()) return bail("no device");
   const int n = src->nrows;
   if (n == 0) return dst ? dst : mzd_init(0, 0);
+  PinnedDevice pin;  // M4RI_HIP_DEVICES = one ordinal: run there
   hipStream_t s;
   if (get_private_stream(&s)) return bail("stream");
   int rc, singular = 0;
@@ -1973,6 +2014,7 @@ extern "C" int mzd_solve_left(mzd_t *A, mzd_t *B, int cutoff, int inconsistency_
     return -1;
   };
   if (require_device()) return bail("no device");
+  PinnedDevice pin;  // M4RI_HIP_DEVICES = one ordinal: run there
   hipStream_t s;
   if (get_private_stream(&s)) return bail("stream");
   const int nw = words_of(n), bw = words_of(kb);

@@ -445,6 +445,64 @@ extern "C" void mzd_copy_row(mzd_t *B, rci_t i, mzd_t const *A, rci_t j) {
   copy_row_masked(B->rows[i], A->rows[j], A->width, A->high_bitmask);
 }
 
+// mzd_col_swap (m4ri-sys/src/mzd.rs:144): swap two columns in every row.
+extern "C" void mzd_col_swap(mzd_t *M, rci_t cola, rci_t colb) {
+  if (M) gf2_cache_forget(M);  // written below: a device copy kept for it is stale
+  if (cola == colb) return;
+  if (cola < 0 || colb < 0 || cola >= M->ncols || colb >= M->ncols) gf2_die("mzd_col_swap: column out of range");
+  const wi_t wa = cola / m4ri_radix, wb = colb / m4ri_radix;
+  const int sa = cola % m4ri_radix, sb = colb % m4ri_radix;
+  for (rci_t i = 0; i < M->nrows; ++i) {
+    word *row = M->rows[i];
+    const word d = ((row[wa] >> sa) ^ (row[wb] >> sb)) & m4ri_one;  // 1 where the two bits differ
+    row[wa] ^= d << sa;
+    row[wb] ^= d << sb;
+  }
+}
+
+// mzd_row_clear_offset (m4ri-sys/src/mzd.rs:235-240): clear row `row` from column `coloffset` to its end.
+extern "C" void mzd_row_clear_offset(mzd_t *M, rci_t row, rci_t coloffset) {
+  if (M) gf2_cache_forget(M);
+  if (row < 0 || row >= M->nrows || coloffset < 0) gf2_die("mzd_row_clear_offset: out of range");
+  if (coloffset >= M->ncols) return;
+  const wi_t w0 = coloffset / m4ri_radix;
+  const int s = coloffset % m4ri_radix;
+  word *r = M->rows[row];
+  const word keep = s ? ((m4ri_one << s) - 1) : 0;  // bits below the offset inside its word
+  if (w0 == M->width - 1) {
+    r[w0] &= keep | ~M->high_bitmask;  // a window's foreign bits past its width stay
+    return;
+  }
+  r[w0] &= keep;
+  for (wi_t j = w0 + 1; j < M->width - 1; ++j) r[j] = 0;
+  r[M->width - 1] &= ~M->high_bitmask;
+}
+
+// mzd_invert_naive (m4ri-sys/src/mzd.rs:214-218): inverse by Gaussian elimination of [A | I]; `identity` may be passed in to
+// save building it, `inv` may be NULL (allocated).  The elimination is this library's own mzd_echelonize (device, or the
+// host routine of the size dispatch); returns NULL for a singular matrix.
+extern "C" mzd_t *mzd_invert_naive(mzd_t *inv, mzd_t const *A, mzd_t const *identity) {
+  if (!A || A->nrows != A->ncols) gf2_die("mzd_invert_naive: matrix must be square");
+  const rci_t n = A->nrows;
+  if (identity && (identity->nrows != n || identity->ncols != n)) gf2_die("mzd_invert_naive: identity has wrong dimensions");
+  if (inv && (inv->nrows != n || inv->ncols != n)) gf2_die("mzd_invert_naive: inv has wrong dimensions");
+  if (n == 0) return inv ? inv : mzd_init(0, 0);
+  mzd_t *I = nullptr;
+  if (!identity) {
+    I = mzd_init(n, n);
+    mzd_set_ui(I, 1);
+  }
+  mzd_t *H = mzd_concat(nullptr, A, identity ? identity : I);
+  if (I) mzd_free(I);
+  const rci_t rank = mzd_echelonize(H, 1);
+  bool ok = rank >= n;
+  for (rci_t i = 0; ok && i < n; ++i) ok = read_bit(H, i, i) == 1;  // reduced form of a full-rank left block: the identity
+  mzd_t *out = nullptr;
+  if (ok) out = mzd_submatrix(inv, H, 0, n, n, 2 * n);
+  mzd_free(H);
+  return out;
+}
+
 // mzd_make_table (brilliantrussian.rs:8-17): T (2^k rows, preallocated, M->ncols columns) receives every XOR combination of the k
 // rows r .. r + k - 1 of M, L (2^k entries) the row of T that holds the combination selected by a k-bit value v (bit j of v <->
 // row r + j): T[L[v]] = XOR of the rows r + j with bit j of v set.  Rows of T are generated in Gray-code order (each from its

@@ -203,15 +203,28 @@ class BinVector:
 class BinMatrix:
     """Owns an mzd_t* (binary_matrix.rs:33-45); freed with mzd_free on drop."""
 
-    __slots__ = ("mzd",)
+    __slots__ = ("_mzd",)
 
     def __init__(self, mzd):
         if not mzd:
             raise PanicError("Can't be NULL")
-        self.mzd = mzd
+        self._mzd = mzd
+
+    @property
+    def mzd(self):
+        """The mzd_t* for C-ABI calls.  Every access hands out a FRESH ctypes pointer that holds a reference to this
+        owner, so `lib.mzd_mul(None, BinMatrix.from_words(...).mzd, ...)` keeps the temporary matrix alive until the call
+        has returned (a bare pointer would outlive its owner: the temporary is collected -- mzd_free -- as soon as `.mzd`
+        has been read, and the callee reads freed memory; round 2 hit exactly that in a test)."""
+        if not self._mzd:
+            return None
+        p = ctypes.cast(self._mzd, _lib.MzdP)
+        p._owner = self
+        return p
 
     def __del__(self):
-        mzd, self.mzd = getattr(self, "mzd", None), None
+        mzd = getattr(self, "_mzd", None)
+        self._mzd = None
         if mzd:
             try:
                 _lib.lib().mzd_free(mzd)

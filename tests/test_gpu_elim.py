@@ -377,3 +377,38 @@ def test_concurrent_host_threads_elimination(pkg):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("small_work", ["0", str(1 << 20)], ids=["device", "host-dispatch"])
+def test_invert_naive(pkg, monkeypatch, small_work):
+    """mzd_invert_naive (mzd.rs:214-218) against the oracle's inverse, through the device elimination and through the host
+    routine of the size dispatch (the shipped default); with a caller-supplied identity, a preallocated result, and a
+    singular input (NULL)."""
+    import ctypes
+    monkeypatch.setenv("M4RI_HIP_HOST_SMALL_WORK", small_work)
+    L = pkg._lib.lib()
+    done = 0
+    for n, seed in [(1, 1), (7, 2), (64, 3), (65, 4), (100, 5), (130, 6), (700, 7)]:
+        for s2 in range(seed, seed + 40):
+            a = g.random_words(n, n, 1000 * n + s2)
+            inv = g.o_inverse(a, n)
+            if inv is not None:
+                break
+        else:
+            continue
+        A = pkg.BinMatrix.from_words(a, n)
+        r = L.mzd_invert_naive(None, A.mzd, None)
+        assert r
+        R = pkg.BinMatrix(r)
+        assert np.array_equal(R.to_words(), inv), n
+        I = pkg.BinMatrix.identity(n)
+        out = pkg.BinMatrix.from_words(g.random_words(n, n, 9), n)
+        r2 = L.mzd_invert_naive(out.mzd, A.mzd, I.mzd)
+        assert r2 and ctypes.addressof(r2.contents) == ctypes.addressof(out.mzd.contents)
+        assert np.array_equal(out.to_words(), inv)
+        done += 1
+    assert done >= 4
+    z = np.zeros((20, 1), dtype=np.uint64)
+    z[3, 0] = 5
+    Z = pkg.BinMatrix.from_words(z, 20)
+    assert not L.mzd_invert_naive(None, Z.mzd, None)

@@ -452,6 +452,68 @@ def test_multi_device_shares_through_c_abi(pkg, dev, monkeypatch, m, l, n, share
     assert not L.gf2_mul_multi(None, A.mzd, B.mzd, dev.ALGO_AUTO, 0, bad, 2)
 
 
+def test_multi_device_two_distinct_devices(pkg, dev, monkeypatch):
+    """The code that only matters ACROSS devices -- hipSetDevice per worker thread, blocks freed into another device's pool,
+    portable pinned host blocks read by device 1, the pipelined share (>= 16384 rows) on each -- with devices = [0, 1].
+    Skipped on a one-GPU box (there the shares repeat ordinal 0, test_multi_device_shares_through_c_abi)."""
+    import ctypes
+    if dev.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    L = pkg._lib.lib()
+    arr = (ctypes.c_int * 2)(0, 1)
+    for (m, l, n) in [(5000, 3000, 2100), (32768, 8192, 4096)]:
+        a, b = g.random_words(m, l, 81), g.random_words(l, n, 82)
+        ref = g.o_mul_fast(a, b, m, l, n) if m * l * n > 1 << 34 else g.o_mul_m4rm(a, b, m, l, n)
+        A, B = pkg.BinMatrix.from_words(a, l), pkg.BinMatrix.from_words(b, n)
+        for algo in (dev.ALGO_AUTO, dev.ALGO_M4RM):
+            c = L.gf2_mul_multi(None, A.mzd, B.mzd, algo, 0, arr, 2)
+            assert c and np.array_equal(pkg.BinMatrix(c).to_words(), ref), (m, l, n, algo)
+        # everything pinned to device 1 from the environment: product, elimination and the operand cache run there
+        monkeypatch.setenv("M4RI_HIP_DEVICES", "1")
+        c = L.mzd_mul(None, A.mzd, B.mzd, 0)
+        assert c and np.array_equal(pkg.BinMatrix(c).to_words(), ref)
+        A.cache_on_device()
+        c = L.mzd_mul(None, A.mzd, B.mzd, 0)
+        assert c and np.array_equal(pkg.BinMatrix(c).to_words(), ref)
+        A.uncache()
+        monkeypatch.delenv("M4RI_HIP_DEVICES")
+
+
+def test_pinned_single_ordinal_keeps_one_stream_per_device(pkg, dev, monkeypatch):
+    """M4RI_HIP_DEVICES = one ordinal pins products, elimination, transpose and the operand cache of the host entry points to
+    that device, and a thread that alternates between pinned and unpinned calls gets the same private stream (and its
+    arenas) back each time: the library's device memory must not grow with the number of alternations (round-2 advice)."""
+    L = pkg._lib.lib()
+    n = 2048
+    a, b = g.random_words(n, n, 91), g.random_words(n, n, 92)
+    ref = g.o_mul_m4rm(a, b, n, n, n)
+    A, B = pkg.BinMatrix.from_words(a, n), pkg.BinMatrix.from_words(b, n)
+    import torch
+    last = dev.device_count() - 1
+
+    def round_trip():
+        monkeypatch.setenv("M4RI_HIP_DEVICES", str(last))
+        c = L.mzd_mul_m4rm(None, A.mzd, B.mzd, 0)
+        assert c and np.array_equal(pkg.BinMatrix(c).to_words(), ref)
+        assert pkg.BinMatrix.from_words(a, n).rank() == g.o_echelonize(a, n, n)[1]
+        A.cache_on_device()
+        c = L.mzd_mul(None, A.mzd, B.mzd, 0)
+        assert c and np.array_equal(pkg.BinMatrix(c).to_words(), ref)
+        A.uncache()
+        monkeypatch.delenv("M4RI_HIP_DEVICES")
+        assert pkg.BinMatrix.from_words(a, n).rank() == g.o_echelonize(a, n, n)[1]
+
+    for _ in range(2):
+        round_trip()
+    torch.cuda.synchronize()
+    free0 = [torch.cuda.mem_get_info(d)[0] for d in range(dev.device_count())]
+    for _ in range(6):
+        round_trip()
+    torch.cuda.synchronize()
+    free1 = [torch.cuda.mem_get_info(d)[0] for d in range(dev.device_count())]
+    assert all(f0 - f1 < (64 << 20) for f0, f1 in zip(free0, free1)), (free0, free1)
+
+
 def test_multi_device_shares_from_several_host_threads(pkg, dev, monkeypatch):
     """BinMatrix is Send + Sync: several host threads issue products that are each divided among device shares (worker threads,
     leased streams, per-share buffers) at the same time."""

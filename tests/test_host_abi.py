@@ -451,3 +451,50 @@ def test_mzd_make_table(built):
         for i in range(1, 1 << k):  # Gray order: consecutive rows differ by exactly one row of M
             d = t[i, w0:] ^ t[i - 1, w0:]
             assert any(np.array_equal(d, a[r + j, w0:]) for j in range(k))
+
+
+def test_col_swap_and_row_clear_offset(pkg):
+    """mzd_col_swap (mzd.rs:144) and mzd_row_clear_offset (mzd.rs:235-240) against plain bit arithmetic, including columns
+    in the last (partial) word and a window whose parent keeps its bits."""
+    L = pkg._lib.lib()
+    rng = np.random.default_rng(5)
+    for (m, n) in [(1, 1), (5, 64), (9, 65), (40, 130), (33, 200)]:
+        a = g.random_words(m, n, 20 + n)
+        bits = g.words_to_bits(a, n)
+        M = pkg.BinMatrix.from_words(a, n)
+        for _ in range(12):
+            ca, cb = (int(x) for x in rng.integers(0, n, 2))
+            L.mzd_col_swap(M.mzd, ca, cb)
+            bits[:, [ca, cb]] = bits[:, [cb, ca]]
+        assert np.array_equal(M.to_words(), g.bits_to_words(bits)), (m, n)
+        for off in sorted({0, 1, n // 2, max(n - 1, 0), n, 63 % n, 64 % n}):
+            r = int(rng.integers(0, m))
+            L.mzd_row_clear_offset(M.mzd, r, off)
+            bits[r, off:] = 0
+            assert np.array_equal(M.to_words(), g.bits_to_words(bits)), (m, n, off)
+    # window: clearing a row of the window must not touch the parent's bits right of it
+    big = g.random_words(10, 200, 3)
+    P = pkg.BinMatrix.from_words(big, 200)
+    W = L.mzd_init_window(P.mzd, 2, 64, 8, 150)
+    L.mzd_row_clear_offset(W, 1, 10)
+    L.mzd_col_swap(W, 0, 85)
+    pb = g.words_to_bits(big, 200)
+    pb[3, 74:150] = 0
+    pb[2:8, [64, 149]] = pb[2:8, [149, 64]]
+    assert np.array_equal(P.to_words(), g.bits_to_words(pb))
+    L.mzd_free(W)
+
+
+def test_mzd_pointer_keeps_its_owner_alive(pkg):
+    """`BinMatrix(...).mzd` as a call argument: the temporary owner must survive until the call has returned.  (Round 2's
+    one unexplained abort, gpurun_out/t8.log, was this: `L.mzd_mul(None, BinMatrix.from_words(..).mzd, ..)` read a matrix
+    whose owner had already been collected and freed.)  Every `.mzd` access now returns a pointer that references its owner."""
+    import gc
+    L = pkg._lib.lib()
+    a = g.random_words(300, 300, 4)
+    p = pkg.BinMatrix.from_words(a, 300).mzd  # the owner is a temporary
+    junk = [pkg.BinMatrix.from_words(g.random_words(300, 300, 5 + i), 300) for i in range(8)]  # would reuse a freed block
+    gc.collect()
+    assert p.contents.nrows == 300 and L.mzd_equal(p, pkg.BinMatrix.from_words(a, 300).mzd) == 1
+    assert L.mzd_equal(pkg.BinMatrix.from_words(a, 300).mzd, pkg.BinMatrix.from_words(a, 300).mzd) == 1
+    del junk
