@@ -194,6 +194,17 @@ int gf2_strassen_levels(int m, int l, int n, int algo, int param);
 /* How a device product of this shape would run, by the cost model (no device needed): returns the Strassen level count;
  * *kind = 0 the shape as given, 1 zero-padded up to dims[0..2], 2 peeled down to the core dims[0..2] (border strips plain) */
 int gf2_mul_plan(int m, int l, int n, int algo, int param, int *kind, int dims[3]);
+/* How ONE (batched) tile-kernel launch of `batch` products m x l x n would run, by the cost model (no device needed); `packed`:
+ * A is handed over row-group packed.  out[0] = kernel variant (7 / 20: 1024- / 256-row tiles x 2048 columns; 8: 2048 x 1024;
+ * 9 / 10 / 11 / 12: 4096 / 2048 / 1024 / 512 rows x 512 columns), out[1] = uniform slices of the inner dimension (variants 7, 8,
+ * 20), out[2] = tiles cut into stream-K segments and out[3] = number of segments (variants 9-12), out[4] = bytes of scratch
+ * for partial tiles; a batched launch may be cut in two -- out[5] = products in the second launch (0: one launch), out[6] / out[7] /
+ * out[8] = its variant, tiles cut and segments; returns the modelled time in seconds.  Diagnostic: tools and tests read the
+ * launcher's choice from here. */
+double gf2_tile_plan(int m, int l, int n, int batch, int packed, long long out[9]);
+/* modelled seconds of a device product of this shape with exactly `levels` Strassen levels (0: plain M4RM); -1 if that many
+ * levels do not divide the shape.  Diagnostic (tools/levels_sweep.py prints it beside the measured time). */
+double gf2_model_time(int m, int l, int n, int levels);
 /* bytes the Strassen split / merge passes of a product with that many levels read and write (0 for levels == 0): every pass
  * kernel reads its sources once and writes its destinations once, so this is exact; bench.py prices the passes with it */
 double gf2_strassen_pass_bytes(int m, int l, int n, int levels);

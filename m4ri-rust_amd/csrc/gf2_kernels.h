@@ -26,6 +26,12 @@ struct gf2k_mul_args {
   long long ldp, sP;
   // A is stored row-group packed (gf2k_strassen_split2 with side 2): u64 index ((r / 64) * lda + c) * 64 + r % 64, ceil(m / 64) * 64 rows
   int a_packed;
+  // stream-K split of a v8 launch (cfg 9-12; gf2_kernels.hip, gf2_m4rm_kernel_v8).  Caller: n_rem = tiles (counted from the END
+  // of the tile order) to be cut into segments, nseg = how many segments it would like (0: 256), P / p_words = scratch for
+  // the partial tiles (gf2k_m4rm_streamk_words).  The launcher fills in the rest; n_rem = 0 or P = nullptr: whole tiles only.
+  int n_rem, nseg;
+  long long p_words;  // capacity of P in 64-bit words
+  int n_full, seg_slabs, tile_slabs;  // (launcher) whole-tile workgroups; 64-bit slabs per segment / per tile
 };
 
 // Device-side record of a blocked elimination (gf2_elim.hip): the kernels of a step read their ranges from it, so a
@@ -65,6 +71,8 @@ hipError_t gf2k_scatter_rows(uint64_t *X, long long ldx, const uint64_t *R, long
                              int rank, hipStream_t s);
 hipError_t gf2k_any_nonzero(const uint64_t *M, long long ld, int row_lo, int rows, int words, int *flag, hipStream_t s);
 int gf2k_m4rm_rows_per_tile(int cfg);
+// 64-bit words of partial-tile scratch a stream-K launch of variant `cfg` with `nseg` segments needs (two slots per segment)
+long long gf2k_m4rm_streamk_words(int cfg, int nseg);
 int gf2k_m4rm_cols_per_tile(int cfg);
 // row-group-packed copy of A for gf2k_mul_args::a_packed: dst holds ceil(m/64)*64 rows of wp (even, >= w) words
 hipError_t gf2k_packA(uint64_t *dst, long long wp, const uint64_t *src, long long lds_, int m, int w, hipStream_t stream);

@@ -33,6 +33,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <algorithm>
 #include <mutex>
 #include <set>
 #include <type_traits>
@@ -752,18 +753,31 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v6(const gf2k_mul_
 }
 
 // ---------------------------------------------------------------------------------------------
-// M4RM tile kernel v7: FOUR chunks (one 32-bit word of the inner dimension) per table generation, tile of 4096 rows x 512
-// columns.  Same work per lookup as v6 (one v_perm_b32, one ds_read_b128, two v_bitop3_b32 per 16 bytes), but a table row
-// (one ds_write_addtid_b32: 4 chunks x 64 bytes) and a fetched row of B now serve 4096 rows of A instead of 2048: half
-// the table writes, half the B loads and half the barriers per unit of work.
-// A 256-byte LDS row holds entry e of the four chunks' tables side by side (16 slots of 16 bytes: slot = 4 chunk + piece).
-// Lane L owns rows {64 r + L}, r < 8, of its wave's 512 rows; in step (r, k) it reads, for c = 0..3, slot
-// 4 (c ^ cl) + (k ^ l3) with cl = (L >> 2) & 3, l3 = L & 3: the 16 lanes served together hit 16 different slots, acc[r][k]
-// holds piece k ^ l3 of the row's 64 bytes, and the four reads of a step belong to four different chunks (byte c ^ cl of
-// the A word selects the entry).
+// M4RM tile kernel v8: FOUR chunks (one 32-bit word of the inner dimension) per table generation, tile of 512 RG rows x 512
+// columns (RG = 8, 4, 2, 1 chosen at launch), stream-K scheduling of the launch's last round.
+// Lookup scheme (unchanged from the round-1/2 kernel v7, tools/gf2_kernels_legacy_v7.inc): one v_perm_b32, one ds_read_b128
+// and two v_bitop3_b32 per 16 bytes; a table row (one ds_write_addtid_b32: 4 chunks x 64 bytes) and a fetched row of B serve
+// all rows of the tile.  A 256-byte LDS row holds entry e of the four chunks' tables side by side (16 slots of 16 bytes:
+// slot = 4 chunk + piece).  Lane L owns rows {64 r + L}, r < RG, of its wave's 64 RG rows; in step (r, k) it reads, for
+// c = 0..3, slot 4 (c ^ cl) + (k ^ l3) with cl = (L >> 2) & 3, l3 = L & 3: the 16 lanes served together hit 16 different
+// slots, acc[r][k] holds piece k ^ l3 of the row's 64 bytes, and the four reads of a step belong to four different chunks
+// (byte c ^ cl of the A word selects the entry).
+//
+// Tile height.  The table of a generation costs 256 ds_write_addtid_b32 per workgroup whatever the tile's height, so a
+// tall tile amortises it best (4096 rows: 12 % of the LDS cycles) -- but a product with few rows, or few tiles, fills the
+// chip only with shorter tiles: 4096^3 has 8 tiles of 4096 x 512 and 32 of 1024 x 512.
+//
+// Stream-K.  Every tile of a launch takes the same time, so T tiles on 256 CUs cost ceil(T / 256) rounds.  The launcher
+// may therefore declare the last n_rem tiles "remainder": workgroups [0, n_full) compute whole tiles as before, workgroups
+// n_full + s (s < nseg) compute SEGMENTS -- seg_slabs consecutive 64-bit slabs of the remainder tiles' inner dimensions laid
+// end to end, so a segment is a slice of one tile or the tail of one tile plus the head of the next.  A segment stores each
+// of its (at most two) partial tiles into its own slot of a scratch buffer, straight from the accumulator registers (slot
+// layout: 16 bytes of step s of thread t at (s * 512 + t) * 16 -- no transposition, 1 KiB per wave instruction), and
+// gf2_streamk_reduce_kernel XORs the slots of every remainder tile into C.  No workgroup ever waits for another one.
+// With T < 256 everything is remainder: that is split-K with slices that need not divide the inner dimension evenly.
 // ---------------------------------------------------------------------------------------------
-constexpr int v7_wait_count(int st_wait, int target, int G, int STEPS, int RPS) {
-  int after = 0;
+constexpr int v8_wait_count(int st_wait, int target, int G, int STEPS, int RPS, int WPS) {
+  int after = 0;  // LDS operations issued after the last read of step `target` when step `st_wait` waits for it
   bool seen = false;
   for (int k = 0; k < G && k < STEPS; ++k) {
     if (seen) after += RPS;
@@ -774,53 +788,67 @@ constexpr int v7_wait_count(int st_wait, int target, int G, int STEPS, int RPS) 
       if (seen) after += RPS;
       if (s + G == target) seen = true;
     }
-    if (seen) after += 1;
+    if (seen) after += WPS;
   }
   return after > 15 ? 15 : after;
 }
 
 static constexpr int kTileWords7 = 8;  // 512 columns per tile
 
-template <int WAVES, int G, int DBG = 0, int APACK = 0>
-__global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v7(const gf2k_mul_args p) {
-  constexpr int RPW = 512, RG = 8;
-  constexpr int R = WAVES * RPW;
-  constexpr int STEPS = 32;  // (row group, piece)
-  constexpr int EPW = 256 / WAVES;
-  constexpr int LOWB = Log2<EPW>::value;
-  static_assert(EPW * WAVES == 256 && G <= STEPS && EPW <= STEPS, "geometry");
+// tile index -> (row tile, column tile, batch item); row tiles fastest: the row tiles that share a column panel of B are neighbours
+struct v8_tile {
+  int tm, tn, bt;
+};
+__device__ __forceinline__ v8_tile v8_decode(int t, const gf2k_mul_args &p) {
+  v8_tile r;
+  r.tm = t % p.tiles_m;
+  t /= p.tiles_m;
+  r.tn = t % p.tiles_n;
+  r.bt = t / p.tiles_n;
+  return r;
+}
+
+// NB: register buffers for rows of B (a quad's rows are requested NB - 1 quads before its table is built; the loop body covers NB
+// quads); NA: 1 = a row group's slab of A is re-fetched in place after its last use, 2 = the next slab goes into a second
+// buffer at the start of the current one.  Tall tiles (RG = 8) have no registers to spare and quads long enough to hide a
+// memory latency (NB = 2, NA = 1); a quad of a short tile lasts well under a microsecond, so short tiles look further ahead.
+template <int RG, int G, int APACK, int NB = (RG >= 8 ? 2 : 4), int NA = (RG >= 8 ? 1 : 2)>
+__global__ __launch_bounds__(512) void gf2_m4rm_kernel_v8(const gf2k_mul_args p) {
+  constexpr int WAVES = 8, RPW = 64 * RG, R = WAVES * RPW;
+  static_assert(NB >= 2 && NB % 2 == 0 && (NA == 1 || (NA == 2 && NB % 4 == 0)), "buffers");
+  constexpr int STEPS = 4 * RG;  // (row group, piece)
+  constexpr int EPW = 256 / WAVES, LOWB = Log2<EPW>::value;
+  constexpr int WPS = EPW / STEPS > 0 ? EPW / STEPS : 1;  // table entries written per step
+  constexpr int BPS = STEPS >= 8 ? 1 : 8 / STEPS;         // rows of B fetched per step
+  static_assert(WPS * STEPS == EPW || STEPS > EPW, "geometry");
+  static_assert(G <= STEPS && G <= 3, "read window");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // DBG == 1: wall-clock stamps (s_memrealtime, 100 MHz) of the workgroup's phases and the CU it ran on, written to p.Bp
-  // (five 64-bit words per workgroup; kbench cfg 96 prints the per-tile overheads)
-  unsigned long long dbg_t0 = 0, dbg_t1 = 0, dbg_t2 = 0;
-  if constexpr (DBG == 1) dbg_t0 = __builtin_amdgcn_s_memrealtime();
-  int t;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int tm = t % p.tiles_m;
-  t /= p.tiles_m;
-  const int ks = t % p.ksplit;
-  t /= p.ksplit;
-  const int tn = t % p.tiles_n;
-  const int bt = t / p.tiles_n;
-  const u64 *__restrict__ A = p.A + (long long)bt * p.sA;
-  const u64 *__restrict__ B = p.B + (long long)bt * p.sB;
-  const bool part = p.P != nullptr && p.ksplit > 1;
-  u64 *__restrict__ C = part ? p.P + ((long long)bt * p.ksplit + ks) * p.sP : p.C + (long long)bt * p.sC;
-  const long long ldc = part ? p.ldp : p.ldc;
-  const bool accum = !part && p.accumulate;
 
-  const int row0 = tm * R, w0 = tn * kTileWords7;
-  const int widthB = (p.n + 63) >> 6;
-  const u64 maskC = (p.n & 63) ? ((1ull << (p.n & 63)) - 1) : ~0ull;
-  const int nw32 = (p.l + 31) >> 5;
-  const int jbeg = ks * p.kwords;  // even (launcher)
-  const int jend = min(nw32, jbeg + p.kwords);
+  // ---- what this workgroup computes: one whole tile, or a segment = (tile0, slabs [sl0, slN)) [+ (tile0 + 1, slabs [0, rest))] ----
+  const int Q = p.tile_slabs;
+  int tile0, sl0 = 0, slN = Q, rest = 0;
+  long long slot0 = -1;  // first partial slot of a segment; -1: whole tile, stored to C
+  {
+    const int bid = blockIdx.x;
+    if (bid < p.n_full) {  // XCD-aware order: blocks b, b + 8 share an XCD; each XCD gets a contiguous range of tiles
+      const int nwg = p.n_full, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+      tile0 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    } else {
+      const int s = bid - p.n_full;
+      const long long g0 = (long long)s * p.seg_slabs, gtot = (long long)p.n_rem * Q;
+      const long long g1 = min(g0 + (long long)p.seg_slabs, gtot);
+      if (g1 <= g0) return;  // (whole workgroup)
+      tile0 = p.n_full + (int)(g0 / Q);
+      sl0 = (int)(g0 % Q);
+      const int len = (int)(g1 - g0);
+      slN = min(Q, sl0 + len);
+      rest = len - (slN - sl0);
+      slot0 = 2ll * s;
+    }
+  }
+  const int nparts = rest > 0 ? 2 : 1;
 
   const int l3 = lane & 3, cl = (lane >> 2) & 3;
   // lo[c >> 1][k]: byte 0 = slot offset of read c even, byte 1 = of read c odd, byte 2 = 0, byte 3 = 1 (table select)
@@ -839,130 +867,135 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v7(const gf2k_mul_
 #pragma unroll
     for (int c = 0; c < 4; ++c) sel[w][c] = 0x0c000000u | ((2u + (u32)w) << 16) | ((4u + (u32)(c ^ cl)) << 8) | (u32)(c & 1);
 
-  u32 acc[STEPS][4];
-#pragma unroll
-  for (int s = 0; s < STEPS; ++s) acc[s][0] = acc[s][1] = acc[s][2] = acc[s][3] = 0;
-
-  // ---- A: 64 bits of row (64 r + lane) per load, reloaded in place; rows past m read as zero (descriptor bound) ----
-  const u32 ldaB = (u32)p.lda * 8u;
-  const int rows_here = min(p.m - row0, R);
-  const __amdgpu_buffer_rsrc_t rsrcA =
-      APACK ? __builtin_amdgcn_make_buffer_rsrc((void *)A, (short)0, (int)((u32)((p.m + 63) & ~63) * ldaB), 0x00020000)
-            : __builtin_amdgcn_make_buffer_rsrc((void *)(A + (long long)row0 * p.lda), (short)0, (int)((u32)rows_here * ldaB), 0x00020000);
-  const u32 voffA0 = APACK ? (u32)(row0 + wave * RPW) * ldaB + (u32)lane * 8u : (u32)(wave * RPW + lane) * ldaB;
+  const int widthB = (p.n + 63) >> 6;
+  const u64 maskC = (p.n & 63) ? ((1ull << (p.n & 63)) - 1) : ~0ull;
+  const int nw32 = (p.l + 31) >> 5;
+  const u32 ldaB = (u32)p.lda * 8u, ldbB = (u32)p.ldb * 8u;
   constexpr int kAColB = APACK ? 256 : 4;
   const u32 tailA = (p.l & 31) ? ((1u << (p.l & 31)) - 1u) : 0xffffffffu;
   const int jlast = (nw32 - 1) & ~1;
-  u32 aw[RG][2];
-  auto maskA = [&](int j) __attribute__((always_inline)) {  // slab of words j, j+1 just loaded
-    const u32 m0 = j >= jend ? 0u : (j == nw32 - 1 ? tailA : 0xffffffffu);
-    const u32 m1 = j + 1 >= jend ? 0u : (j + 1 == nw32 - 1 ? tailA : 0xffffffffu);
-    if ((m0 & m1) != 0xffffffffu) {
+
+#pragma unroll 1
+  for (int part = 0; part < nparts; ++part) {
+    const v8_tile tl = v8_decode(tile0 + part, p);
+    const int jbeg = 2 * (part ? 0 : sl0);
+    const int jend = min(nw32, 2 * (part ? rest : slN));
+    const u64 *__restrict__ A = p.A + (long long)tl.bt * p.sA;
+    const u64 *__restrict__ B = p.B + (long long)tl.bt * p.sB;
+    const int row0 = tl.tm * R, w0 = tl.tn * kTileWords7;
+
+    u32 acc[STEPS][4];
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) acc[s][0] = acc[s][1] = acc[s][2] = acc[s][3] = 0;
+
+    // ---- A: 64 bits of row (64 r + lane) per load, reloaded in place; rows past m read as zero (descriptor bound) ----
+    const int rows_here = min(p.m - row0, R);
+    const __amdgpu_buffer_rsrc_t rsrcA =
+        APACK ? __builtin_amdgcn_make_buffer_rsrc((void *)A, (short)0, (int)((u32)((p.m + 63) & ~63) * ldaB), 0x00020000)
+              : __builtin_amdgcn_make_buffer_rsrc((void *)(A + (long long)row0 * p.lda), (short)0, (int)((u32)rows_here * ldaB), 0x00020000);
+    const u32 voffA0 = APACK ? (u32)(row0 + wave * RPW) * ldaB + (u32)lane * 8u : (u32)(wave * RPW + lane) * ldaB;
+    u32 aw[NA][RG][2];
+    auto maskA = [&](u32 (&dst)[RG][2], int j) __attribute__((always_inline)) {  // slab of words j, j+1 (loaded into dst)
+      const u32 m0 = j >= jend ? 0u : (j == nw32 - 1 ? tailA : 0xffffffffu);
+      const u32 m1 = j + 1 >= jend ? 0u : (j + 1 == nw32 - 1 ? tailA : 0xffffffffu);
+      if ((m0 & m1) != 0xffffffffu) {
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+          dst[r][0] &= m0;
+          dst[r][1] &= m1;
+        }
+      }
+    };
+
+    // ---- B: lane L holds dword L & 15 of the 8 rows of chunk L >> 4 of the quad ----
+    const int validB = min(64, (widthB - w0) * 8);
+    const u32 voffB = ((int)((lane & 15) * 4) < validB) ? (u32)(lane & 15) * 4u + (u32)(lane >> 4) * 8u * ldbB : 0x80000000u;
+    auto rsrcB_for = [&](int q) __attribute__((always_inline)) {  // rows [32 q, 32 q + 32) of B, cut at l
+      const int rows = min(32, p.l - 32 * q);
+      return __builtin_amdgcn_make_buffer_rsrc((void *)(B + (long long)q * 32 * p.ldb + w0), (short)0,
+                                               rows > 0 ? (int)((u32)rows * ldbB) : 0, 0x00020000);
+    };
+
+    u32 cur32 = 0;
+    auto build_begin = [&](const u32 (&rr)[8], u32 tbase) __attribute__((always_inline)) {
+      cur32 = 0;
+#pragma unroll
+      for (int b = LOWB; b < 8; ++b)
+        if ((wave >> (b - LOWB)) & 1) cur32 ^= rr[b];
+      const u32 kOff = tbase ? (0x10004u - (u32)(EPW * 256)) : 0u;  // see gf2_m4rm_kernel_v3
+      const u32 m0v = tbase + (u32)wave * (u32)(EPW * 256) - kOff;
+      asm volatile("s_mov_b32 m0, %0" ::"s"(m0v) : "memory");
+    };
+    auto build_write = [&cur32](auto itag, auto ttag) __attribute__((always_inline)) {
+      constexpr int i = decltype(itag)::value;
+      constexpr u32 tbase = decltype(ttag)::value;
+      constexpr unsigned e = (unsigned)i ^ ((unsigned)i >> 1);
+      constexpr u32 kOff = tbase ? (0x10004u - (u32)(EPW * 256)) : 0u;
+      asm volatile("ds_write_addtid_b32 %0 offset:%1" ::"v"(cur32), "n"(kOff + e * 256u) : "memory");
+    };
+
+    // ---- prologue: rows of B for the first NB quads, first slab of A, first table ----
+    u32 rr[NB][8];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const __amdgpu_buffer_rsrc_t rs = rsrcB_for(jbeg + u);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) rr[u][b] = __builtin_amdgcn_raw_buffer_load_b32(rs, voffB + (u32)b * ldbB, 0, 0);
+    }
+    {
+      const int jl = min(jbeg, jlast);
+      u32 vo = voffA0;
+      asm volatile("" : "+v"(vo));
 #pragma unroll
       for (int r = 0; r < RG; ++r) {
-        aw[r][0] &= m0;
-        aw[r][1] &= m1;
+        const u32x2v v = __builtin_amdgcn_raw_buffer_load_b64(rsrcA, vo, jl * kAColB, 0);
+        aw[0][r][0] = v.x;
+        aw[0][r][1] = v.y;
+        vo += 64u * ldaB;
       }
     }
-  };
+    maskA(aw[0], jbeg);
+    build_begin(rr[0], 0u);
+    static_for<EPW>([&](auto it) __attribute__((always_inline)) {
+      constexpr int i = decltype(it)::value;
+      if constexpr (i > 0) cur32 ^= rr[0][__builtin_ctz(i | 256)];
+      build_write(it, std::integral_constant<u32, 0u>{});
+    });
+    __syncthreads();
 
-  // ---- B: lane L holds dword L & 15 of the 8 rows of chunk L >> 4 of the quad ----
-  const u32 ldbB = (u32)p.ldb * 8u;
-  const int validB = min(64, (widthB - w0) * 8);
-  const u32 voffB = ((int)((lane & 15) * 4) < validB) ? (u32)(lane & 15) * 4u + (u32)(lane >> 4) * 8u * ldbB : 0x80000000u;
-  auto rsrcB_for = [&](int q) __attribute__((always_inline)) {  // rows [32 q, 32 q + 32) of B, cut at l
-    const int rows = min(32, p.l - 32 * q);
-    return __builtin_amdgcn_make_buffer_rsrc((void *)(B + (long long)q * 32 * p.ldb + w0), (short)0,
-                                             rows > 0 ? (int)((u32)rows * ldbB) : 0, 0x00020000);
-  };
-
-  u32 cur32 = 0;
-  auto build_begin = [&](const u32 (&rr)[8], u32 tbase) __attribute__((always_inline)) {
-    cur32 = 0;
+    // one quad: look word W of the slab (quad q) up in table W; build quad q+1 from `rows` into the other table; fetch the
+    // rows of quad q+NB into `next`; A: (NA == 1) the second quad of a slab reloads each row group's slab in place after its
+    // last use, (NA == 2) the first quad of a slab fetches the next slab into `awn`
+    auto quad_iter = [&](int q, auto wtag, u32 (&awp)[RG][2], u32 (&awn)[RG][2], const u32 (&rows)[8], u32 (&next)[8]) __attribute__((always_inline)) {
+      constexpr int W = decltype(wtag)::value;
+      u32 lk[2][4], sk[4];  // (copied: an asm operand of the nested lambda does not capture the enclosing function's arrays)
 #pragma unroll
-    for (int b = LOWB; b < 8; ++b)
-      if ((wave >> (b - LOWB)) & 1) cur32 ^= rr[b];
-    const u32 kOff = tbase ? (0x10004u - (u32)(EPW * 256)) : 0u;  // see gf2_m4rm_kernel_v3
-    const u32 m0v = tbase + (u32)wave * (u32)(EPW * 256) - kOff;
-    asm volatile("s_mov_b32 m0, %0" ::"s"(m0v) : "memory");
-  };
-  auto build_write = [&cur32](auto itag, auto ttag) __attribute__((always_inline)) {
-    constexpr int i = decltype(itag)::value;
-    constexpr u32 tbase = decltype(ttag)::value;
-    constexpr unsigned e = (unsigned)i ^ ((unsigned)i >> 1);
-    constexpr u32 kOff = tbase ? (0x10004u - (u32)(EPW * 256)) : 0u;
-    asm volatile("ds_write_addtid_b32 %0 offset:%1" ::"v"(cur32), "n"(kOff + e * 256u) : "memory");
-  };
-
-  // ---- prologue ----
-  u32 rrA[8], rrB[8];
-  {
-    const __amdgpu_buffer_rsrc_t rs0 = rsrcB_for(jbeg), rs1 = rsrcB_for(jbeg + 1);
+      for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      rrA[b] = __builtin_amdgcn_raw_buffer_load_b32(rs0, voffB + (u32)b * ldbB, 0, 0);
-      rrB[b] = __builtin_amdgcn_raw_buffer_load_b32(rs1, voffB + (u32)b * ldbB, 0, 0);
-    }
-  }
-  {
-    const int jl = min(jbeg, jlast);
-    u32 vo = voffA0;
-    asm volatile("" : "+v"(vo));
+        for (int k = 0; k < 4; ++k) lk[c2][k] = lo[c2][k];
 #pragma unroll
-    for (int r = 0; r < RG; ++r) {
-      const u32x2v v = __builtin_amdgcn_raw_buffer_load_b64(rsrcA, vo, jl * kAColB, 0);
-      aw[r][0] = v.x;
-      aw[r][1] = v.y;
-      vo += 64u * ldaB;
-    }
-  }
-  maskA(jbeg);
-  build_begin(rrA, 0u);
-  static_for<EPW>([&](auto it) __attribute__((always_inline)) {
-    constexpr int i = decltype(it)::value;
-    if constexpr (i > 0) cur32 ^= rrA[__builtin_ctz(i | 256)];
-    build_write(it, std::integral_constant<u32, 0u>{});
-  });
-  __syncthreads();
-  if constexpr (DBG == 1) dbg_t1 = __builtin_amdgcn_s_memrealtime();
-
-  // one quad: look word W of the slab (quad q) up in table W; build quad q+1 from `rows` into the other table; fetch the
-  // rows of quad q+2 into `next`; the second quad of a slab reloads each row group's slab of A after its last use
-  auto quad_iter = [&](int q, auto wtag, u32 (&awp)[RG][2], const u32 (&rows)[8], u32 (&next)[8]) __attribute__((always_inline)) {
-    constexpr int W = decltype(wtag)::value;
-    u32 lk[2][4], sk[4];  // (copied: an asm operand of the nested lambda does not capture the enclosing function's arrays)
-#pragma unroll
-    for (int c2 = 0; c2 < 2; ++c2)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) lk[c2][k] = lo[c2][k];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) sk[c] = sel[W][c];
-    using tnext = std::integral_constant<u32, W ? 0u : (u32)kTableBytes>;
-    build_begin(rows, tnext::value);
-    const __amdgpu_buffer_rsrc_t rsN = rsrcB_for(q + 2);
-    const int jnext = min((q & ~1) + 2, jlast);  // next slab, clamped: never past the end of a row
-    u32 voA = voffA0;
-    asm volatile("" : "+v"(voA));
-    u32x4 t0[G], t1[G], t2[G], t3[G];
-    auto issue = [&](int st, u32x4 &d0, u32x4 &d1, u32x4 &d2, u32x4 &d3) __attribute__((always_inline)) {
-      u32 a0, a1;
-      asm volatile("v_perm_b32 %4, %6, %7, %9\n\tds_read_b128 %0, %4\n\tv_perm_b32 %5, %6, %7, %10\n\tds_read_b128 %1, %5\n\t"
-                   "v_perm_b32 %4, %6, %8, %11\n\tds_read_b128 %2, %4\n\tv_perm_b32 %5, %6, %8, %12\n\tds_read_b128 %3, %5"
-                   : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(a0), "=&v"(a1)
-                   : "v"(awp[st >> 2][W]), "v"(lk[0][st & 3]), "v"(lk[1][st & 3]), "v"(sk[0]), "v"(sk[1]), "v"(sk[2]), "v"(sk[3])
-                   : "memory");
-    };
-    if constexpr (DBG != 5) {
+      for (int c = 0; c < 4; ++c) sk[c] = sel[W][c];
+      using tnext = std::integral_constant<u32, W ? 0u : (u32)kTableBytes>;
+      build_begin(rows, tnext::value);
+      const __amdgpu_buffer_rsrc_t rsN = rsrcB_for(q + NB);
+      const int jnext = min((q & ~1) + 2, jlast);  // next slab, clamped: never past the end of a row
+      u32 voA = voffA0;
+      asm volatile("" : "+v"(voA));
+      u32x4 t0[G], t1[G], t2[G], t3[G];
+      auto issue = [&](int st, u32x4 &d0, u32x4 &d1, u32x4 &d2, u32x4 &d3) __attribute__((always_inline)) {
+        u32 a0, a1;
+        asm volatile("v_perm_b32 %4, %6, %7, %9\n\tds_read_b128 %0, %4\n\tv_perm_b32 %5, %6, %7, %10\n\tds_read_b128 %1, %5\n\t"
+                     "v_perm_b32 %4, %6, %8, %11\n\tds_read_b128 %2, %4\n\tv_perm_b32 %5, %6, %8, %12\n\tds_read_b128 %3, %5"
+                     : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(a0), "=&v"(a1)
+                     : "v"(awp[st >> 2][W]), "v"(lk[0][st & 3]), "v"(lk[1][st & 3]), "v"(sk[0]), "v"(sk[1]), "v"(sk[2]), "v"(sk[3])
+                     : "memory");
+      };
 #pragma unroll
       for (int k = 0; k < G; ++k) issue(k, t0[k], t1[k], t2[k], t3[k]);
-    }
-    static_for<STEPS>([&](auto stag) __attribute__((always_inline)) {
-      constexpr int st = decltype(stag)::value;
-      constexpr int N = v7_wait_count(st, st, G, STEPS, 4);
-      if constexpr (DBG != 5)
+      static_for<STEPS>([&](auto stag) __attribute__((always_inline)) {
+        constexpr int st = decltype(stag)::value;
+        constexpr int N = v8_wait_count(st, st, G, STEPS, 4, WPS);
         asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(t0[st % G]), "+v"(t1[st % G]), "+v"(t2[st % G]), "+v"(t3[st % G]) : "n"(N) : "memory");
-      if constexpr (st < EPW && st > 0) cur32 ^= rows[__builtin_ctz(st | 256)];
-      if constexpr (DBG != 5 && DBG != 6) {
         asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[st][0]) : "v"(t0[st % G].x), "v"(t1[st % G].x));
         asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[st][1]) : "v"(t0[st % G].y), "v"(t1[st % G].y));
         asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[st][2]) : "v"(t0[st % G].z), "v"(t1[st % G].z));
@@ -971,96 +1004,162 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v7(const gf2k_mul_
         asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[st][1]) : "v"(t2[st % G].y), "v"(t3[st % G].y));
         asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[st][2]) : "v"(t2[st % G].z), "v"(t3[st % G].z));
         asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[st][3]) : "v"(t2[st % G].w), "v"(t3[st % G].w));
-      }
-      if constexpr (st + G < STEPS && DBG != 5) issue(st + G, t0[st % G], t1[st % G], t2[st % G], t3[st % G]);
-      if constexpr (st < EPW && DBG != 4) build_write(std::integral_constant<int, st>{}, tnext{});
-      if constexpr (DBG == 3) {
-      } else {
-        if constexpr (st < 8) next[st] = __builtin_amdgcn_raw_buffer_load_b32(rsN, voffB + (u32)st * ldbB, 0, 0);
-        // the reads of step st + G (issued above) are the last users of row group (st + G) >> 2 when (st + G) & 3 == 3
-        if constexpr (W == 1 && ((st + G) & 3) == 3 && st + G < STEPS) {
-          constexpr int r = (st + G) >> 2;
+        if constexpr (st + G < STEPS) issue(st + G, t0[st % G], t1[st % G], t2[st % G], t3[st % G]);
+        static_for<WPS>([&](auto wt) __attribute__((always_inline)) {  // entries st * WPS .. of the next table (Gray order)
+          constexpr int i = st * WPS + decltype(wt)::value;
+          if constexpr (i < EPW) {
+            if constexpr (i > 0) cur32 ^= rows[__builtin_ctz(i | 256)];
+            build_write(std::integral_constant<int, i>{}, tnext{});
+          }
+        });
+#pragma unroll
+        for (int b = st * BPS; b < (st + 1) * BPS && b < 8; ++b)
+          next[b] = __builtin_amdgcn_raw_buffer_load_b32(rsN, voffB + (u32)b * ldbB, 0, 0);
+        if constexpr (NA == 1) {
+          // the reads of step st + G (issued above) are the last users of row group (st + G) >> 2 when (st + G) & 3 == 3
+          if constexpr (W == 1 && ((st + G) & 3) == 3 && st + G < STEPS) {
+            constexpr int r = (st + G) >> 2;
+            const u32x2v v = __builtin_amdgcn_raw_buffer_load_b64(rsrcA, voA + (u32)r * 64u * ldaB, jnext * kAColB, 0);
+            awp[r][0] = v.x;
+            awp[r][1] = v.y;
+          }
+        } else if constexpr (W == 0 && (st & 3) == 0) {  // one row group every fourth step (awn's last readers were issued in the previous quad)
+          constexpr int r = st >> 2;
           const u32x2v v = __builtin_amdgcn_raw_buffer_load_b64(rsrcA, voA + (u32)r * 64u * ldaB, jnext * kAColB, 0);
-          awp[r][0] = v.x;
-          awp[r][1] = v.y;
+          awn[r][0] = v.x;
+          awn[r][1] = v.y;
         }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    if constexpr (W == 1) maskA((q & ~1) + 2);
-    if constexpr (DBG != 2) __syncthreads();
-  };
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      if constexpr (W == 1) maskA(NA == 1 ? awp : awn, (q & ~1) + 2);
+      __syncthreads();
+    };
 
 #pragma unroll 1
-  for (int j = jbeg; j < jend; j += 2) {
-    quad_iter(j, std::integral_constant<int, 0>{}, aw, rrB, rrA);
-    quad_iter(j + 1, std::integral_constant<int, 1>{}, aw, rrA, rrB);
-  }
-
-  if constexpr (DBG == 1) dbg_t2 = __builtin_amdgcn_s_memrealtime();
-  // ---- epilogue: transpose through LDS (tables are dead), 128 rows x 64 bytes per wave at a time, 4 lanes per row ----
-  {
-    typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
-    const u32 wbase = (u32)wave * 8192u;
-    const int prow = lane >> 2, pq = lane & 3;
-    const int wc = w0 + 2 * pq;
-#pragma unroll
-    for (int quarter = 0; quarter < 4; ++quarter) {
-#pragma unroll
-      for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int s = (2 * quarter + rr) * 4 + k;
-          const u32 off = wbase + (u32)(rr * 64 + lane) * 64u + (u32)((k ^ l3) * 16);
-          *reinterpret_cast<lds_u32x4 *>(off) = u32x4{acc[s][0], acc[s][1], acc[s][2], acc[s][3]};
+    for (int j = jbeg; j < jend; j += NB) {
+      bool done = false;
+      static_for<NB / 2>([&](auto sl) __attribute__((always_inline)) {  // NB / 2 slabs; a short slice leaves after any of them
+        constexpr int u = 2 * decltype(sl)::value, ab = (NA == 2) ? (decltype(sl)::value & 1) : 0, an = (NA == 2) ? (ab ^ 1) : 0;
+        if (!done) {
+          quad_iter(j + u, std::integral_constant<int, 0>{}, aw[ab], aw[an], rr[(u + 1) % NB], rr[u]);
+          quad_iter(j + u + 1, std::integral_constant<int, 1>{}, aw[ab], aw[an], rr[(u + 2) % NB], rr[u + 1]);
+          if (j + u + 2 >= jend) done = true;
         }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      });
+    }
+
+    if (slot0 >= 0) {
+      // ---- segment: the partial tile goes to its slot as it lies in the registers (1 KiB per wave instruction) ----
+      u64 *__restrict__ S = p.P + (slot0 + part) * p.sP + (long long)tid * 2;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const u32x4 v = *reinterpret_cast<lds_cu32x4 *>(wbase + (u32)i * 1024u + (u32)lane * 16u);
-        const int row = row0 + wave * RPW + quarter * 128 + i * 16 + prow;
-        if (row < p.m && wc < widthB) {
-          u64 *dst = C + (long long)row * ldc + wc;
-          u64 v0 = (u64)v.x | ((u64)v.y << 32);
-          u64 v1 = (u64)v.z | ((u64)v.w << 32);
-          if (wc == widthB - 1) v0 &= maskC;
-          if (wc + 1 == widthB - 1) v1 &= maskC;
-          if (p.ksplit > 1 && !part) {
-            if (v0) atomicXor(reinterpret_cast<unsigned long long *>(dst), (unsigned long long)v0);
-            if (wc + 1 < widthB && v1) atomicXor(reinterpret_cast<unsigned long long *>(dst + 1), (unsigned long long)v1);
-          } else if (wc + 1 < widthB) {
-            if (accum) {
-              const uint4 old = *reinterpret_cast<const uint4 *>(dst);
-              v0 ^= (u64)old.x | ((u64)old.y << 32);
-              v1 ^= (u64)old.z | ((u64)old.w << 32);
+      for (int s = 0; s < STEPS; ++s)
+        *reinterpret_cast<uint4 *>(S + (long long)s * 1024) = make_uint4(acc[s][0], acc[s][1], acc[s][2], acc[s][3]);
+      // (the last quad ended with a barrier: the tables are free for the second part's prologue)
+    } else {
+      // ---- whole tile: transpose through LDS (tables are dead), up to 128 rows x 64 bytes per wave at a time, 4 lanes per row ----
+      u64 *__restrict__ C = p.C + (long long)tl.bt * p.sC;
+      const long long ldc = p.ldc;
+      const bool accum = p.accumulate != 0;
+      typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+      constexpr int GPP = RG >= 2 ? 2 : 1;  // row groups per pass
+      const u32 wbase = (u32)wave * 8192u;
+      const int prow = lane >> 2, pq = lane & 3;
+      const int wc = w0 + 2 * pq;
+#pragma unroll
+      for (int pass = 0; pass < RG / GPP; ++pass) {
+#pragma unroll
+        for (int rr = 0; rr < GPP; ++rr)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int s = (GPP * pass + rr) * 4 + k;
+            const u32 off = wbase + (u32)(rr * 64 + lane) * 64u + (u32)((k ^ l3) * 16);
+            *reinterpret_cast<lds_u32x4 *>(off) = u32x4{acc[s][0], acc[s][1], acc[s][2], acc[s][3]};
+          }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int i = 0; i < 4 * GPP; ++i) {
+          const u32x4 v = *reinterpret_cast<lds_cu32x4 *>(wbase + (u32)i * 1024u + (u32)lane * 16u);
+          const int row = row0 + wave * RPW + pass * (64 * GPP) + i * 16 + prow;
+          if (row < p.m && wc < widthB) {
+            u64 *dst = C + (long long)row * ldc + wc;
+            u64 v0 = (u64)v.x | ((u64)v.y << 32);
+            u64 v1 = (u64)v.z | ((u64)v.w << 32);
+            if (wc == widthB - 1) v0 &= maskC;
+            if (wc + 1 == widthB - 1) v1 &= maskC;
+            if (wc + 1 < widthB) {
+              if (accum) {
+                const uint4 old = *reinterpret_cast<const uint4 *>(dst);
+                v0 ^= (u64)old.x | ((u64)old.y << 32);
+                v1 ^= (u64)old.z | ((u64)old.w << 32);
+              }
+              *reinterpret_cast<uint4 *>(dst) = make_uint4((u32)v0, (u32)(v0 >> 32), (u32)v1, (u32)(v1 >> 32));
+            } else {
+              if (accum) v0 ^= dst[0];
+              dst[0] = v0;
             }
-            *reinterpret_cast<uint4 *>(dst) = make_uint4((u32)v0, (u32)(v0 >> 32), (u32)v1, (u32)(v1 >> 32));
-          } else {
-            if (accum) v0 ^= dst[0];
-            dst[0] = v0;
           }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-  if constexpr (DBG == 1) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores of C have left
-    const unsigned long long t3 = __builtin_amdgcn_s_memrealtime();
-    if (tid == 0) {
-      unsigned long long *d = reinterpret_cast<unsigned long long *>(const_cast<uint32_t *>(p.Bp)) + (long long)blockIdx.x * 5;
-      const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
-      d[0] = dbg_t0;
-      d[1] = dbg_t1;
-      d[2] = dbg_t2;
-      d[3] = t3;
-      d[4] = ((unsigned long long)xcc << 32) | hw;
     }
   }
 }
+
+// C (+)= the partial tiles of a stream-K launch (gf2_m4rm_kernel_v8): one 256-thread block per (remainder tile, 64 rows), thread =
+// (row, 16-byte column piece).  Remainder tile u covers slabs [u Q, (u + 1) Q) of the remainder space; segment s covers
+// [s seg, (s + 1) seg) and keeps the part that lies in its first tile in slot 2 s, the part in the following tile in slot
+// 2 s + 1.  Slot layout: see the kernel (16 bytes of step (rg, k') of thread (wave, lane) at ((rg * 4 + k') * 512 + 64 wave + lane)
+// * 16, holding piece k' ^ (lane & 3) of row 64 RG wave + 64 rg + lane).
+__global__ __launch_bounds__(256) void gf2_streamk_reduce_kernel(const gf2k_mul_args p, int RG) {
+  const int R = 512 * RG, RPW = 64 * RG, bpt = R / 64;
+  const int u = blockIdx.x / bpt, rb = blockIdx.x % bpt;
+  const int row = rb * 64 + ((int)threadIdx.x >> 2), k = threadIdx.x & 3;
+  const v8_tile tl = v8_decode(p.n_full + u, p);
+  const long long Q = p.tile_slabs, seg = p.seg_slabs, glo = (long long)u * Q, ghi = glo + Q;
+  const int s_first = (int)(glo / seg);
+  int s_last = (int)((ghi - 1) / seg);
+  if (s_last > p.nseg - 1) s_last = p.nseg - 1;
+  const int wv = row / RPW, rg = (row % RPW) >> 6, ln = row & 63, kp = k ^ (ln & 3);
+  const long long e = ((long long)(rg * 4 + kp) * 512 + wv * 64 + ln) * 2;  // u64 index inside a slot
+  uint4 a = make_uint4(0, 0, 0, 0);
+  for (int s = s_first; s <= s_last; s += 4) {  // four slots in flight (a dependent load per slot would serialise the latencies)
+    uint4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int sk = min(s + k, s_last);
+      const long long sl = 2ll * sk + ((long long)sk * seg < glo ? 1 : 0);
+      v[k] = *reinterpret_cast<const uint4 *>(p.P + sl * p.sP + e);
+      if (s + k > s_last) v[k] = make_uint4(0, 0, 0, 0);
+    }
+    a = xor4(xor4(a, v[0]), xor4(xor4(v[1], v[2]), v[3]));
+  }
+  const int widthB = (p.n + 63) >> 6;
+  const u64 maskC = (p.n & 63) ? ((1ull << (p.n & 63)) - 1) : ~0ull;
+  const int grow = tl.tm * R + row, wc = tl.tn * kTileWords7 + 2 * k;
+  if (grow >= p.m || wc >= widthB) return;
+  u64 *dst = p.C + (long long)tl.bt * p.sC + (long long)grow * p.ldc + wc;
+  u64 v0 = (u64)a.x | ((u64)a.y << 32), v1 = (u64)a.z | ((u64)a.w << 32);
+  if (wc == widthB - 1) v0 &= maskC;
+  if (wc + 1 == widthB - 1) v1 &= maskC;
+  if (wc + 1 < widthB) {
+    if (p.accumulate) {
+      const uint4 old = *reinterpret_cast<const uint4 *>(dst);
+      v0 ^= (u64)old.x | ((u64)old.y << 32);
+      v1 ^= (u64)old.z | ((u64)old.w << 32);
+    }
+    *reinterpret_cast<uint4 *>(dst) = make_uint4((u32)v0, (u32)(v0 >> 32), (u32)v1, (u32)(v1 >> 32));
+  } else {
+    if (p.accumulate) v0 ^= dst[0];
+    dst[0] = v0;
+  }
+}
+
+#ifdef GF2K_DEV_VARIANTS
+#include "../../tools/gf2_kernels_legacy_v7.inc"  // the fixed-tile predecessor with its ablation branches, kbench only
+#endif
 
 // A (m x w words, row stride lds_) -> row-group-packed copy for the APACK tile kernels: word c of row r at u64 index
 // ((r / 64) * wp + c) * 64 + r % 64 (wp even, >= w); rows past m and words past w are written as zeros.  A wave takes the 64
@@ -2517,12 +2616,18 @@ static inline int grid_for(long long total, int block = 256, int cap = 256 * 8) 
   return (int)g;
 }
 
-static bool cfg_is_v7(int cfg) { return cfg == 9 || (cfg >= 90 && cfg < 100); }
+// variants: 9 / 10 / 11 / 12 = v8 with 4096 / 2048 / 1024 / 512-row tiles (512 columns); 8x = v6; 90-99 = the legacy v7 (development builds)
+static int cfg_v8_rg(int cfg) { return cfg == 9 ? 8 : cfg == 10 ? 4 : cfg == 11 ? 2 : cfg == 12 ? 1 : 0; }
+static bool cfg_is_v7(int cfg) { return cfg_v8_rg(cfg) > 0 || (cfg >= 90 && cfg < 100); }
 static bool cfg_is_v56(int cfg) { return cfg == 8 || (cfg >= 80 && cfg < 90); }
 extern "C" int gf2k_m4rm_rows_per_tile(int cfg) {
+  if (cfg_v8_rg(cfg)) return 512 * cfg_v8_rg(cfg);
   return (cfg == 1 || cfg == 20) ? 256 : cfg_is_v7(cfg) ? 4096 : cfg_is_v56(cfg) ? 2048 : 1024;
 }
 extern "C" int gf2k_m4rm_cols_per_tile(int cfg) { return cfg_is_v7(cfg) ? 512 : cfg_is_v56(cfg) ? 1024 : 2048; }
+extern "C" long long gf2k_m4rm_streamk_words(int cfg, int nseg) {
+  return cfg_v8_rg(cfg) ? 2ll * nseg * 512 * cfg_v8_rg(cfg) * 8 : 0;
+}
 
 // The dynamic-LDS limit of a kernel is per device; hipFuncSetAttribute costs host time that short kernels launched back
 // to back notice, so it is issued once per (kernel, device).
@@ -2551,13 +2656,65 @@ static hipError_t launch_tile_kernel(K kernel, int threads, const gf2k_mul_args 
   return e;
 }
 
+// v8 (cfg 9-12): tiles, the stream-K split the caller asked for, the tile kernel, the reduction of the partial tiles
+static hipError_t launch_v8(gf2k_mul_args a, int cfg, int RG, hipStream_t stream) {
+  const int R = 512 * RG;
+  a.tiles_m = (a.m + R - 1) / R;
+  a.tiles_n = (a.n + 511) / 512;
+  const long long T = (long long)a.tiles_m * a.tiles_n * a.batch;
+  if (T > 0x7fffff00LL) return hipErrorInvalidValue;
+  const int nw32 = (a.l + 31) / 32, Q = (nw32 + 1) / 2;
+  a.tile_slabs = Q;
+  // the uniform split-K of the older kernels, expressed as a stream-K split of all tiles
+  if (a.ksplit > 1 && a.n_rem <= 0) a.n_rem = (int)T, a.nseg = (int)std::min<long long>(T * a.ksplit, 1 << 20);
+  a.ksplit = 1;
+  a.kwords = 0;
+  long long n_rem = a.P && Q > 0 ? std::min<long long>(std::max(a.n_rem, 0), T) : 0;
+  int nseg = 0, seg = 0;
+  if (n_rem > 0) {
+    const long long gtot = n_rem * Q, want = a.nseg > 0 ? a.nseg : 256;
+    long long sg = (gtot + want - 1) / want;
+    if (sg > Q) sg = Q;  // a segment spans at most two tiles
+    if (sg < 1) sg = 1;
+    const long long ns = (gtot + sg - 1) / sg;
+    if (ns > 0x7fffff00LL - T || gf2k_m4rm_streamk_words(cfg, (int)ns) > a.p_words || (ns <= n_rem && sg == Q)) {
+      n_rem = 0;  // no room for the partial tiles (or nothing would be split): whole tiles
+    } else {
+      nseg = (int)ns;
+      seg = (int)sg;
+    }
+  }
+  a.n_rem = (int)n_rem;
+  a.nseg = nseg;
+  a.seg_slabs = seg;
+  a.n_full = (int)(T - n_rem);
+  a.sP = (long long)R * 8;
+  const long long nwg = (long long)a.n_full + nseg;
+  if (nwg <= 0) return hipSuccess;
+  hipError_t e = hipErrorInvalidValue;
+#define GF2K_V8(RGv)                                                                                   \
+  e = a.a_packed ? launch_tile_kernel(&gf2_m4rm_kernel_v8<RGv, 2, 1>, 512, a, nwg, stream)             \
+                 : launch_tile_kernel(&gf2_m4rm_kernel_v8<RGv, 2, 0>, 512, a, nwg, stream)
+  switch (RG) {
+    case 8: GF2K_V8(8); break;
+    case 4: GF2K_V8(4); break;
+    case 2: GF2K_V8(2); break;
+    default: GF2K_V8(1); break;
+  }
+#undef GF2K_V8
+  if (e != hipSuccess || n_rem == 0) return e;
+  hipLaunchKernelGGL(gf2_streamk_reduce_kernel, dim3((unsigned)(n_rem * (R / 64))), dim3(256), 0, stream, a, RG);
+  return hipGetLastError();
+}
+
 // cfg (shipped): 7 = v3 1024 x 2048 tile, 20 = v3 256 x 2048 (4 waves), 8 = v6 2048 x 1024, 81 / 82 = v6 with a deeper /
 // shallower read window, 9 = v7 4096 x 512.  Everything else -- the first-generation kernels 0 / 1, v5 (80), packed B (50)
 // and the timing-only ablations whose results are wrong by design (40-45, 49, 83-89, 92-96) -- exists only in builds
 // with -DGF2K_DEV_VARIANTS (tools/libm4ri_hip_dev.so for tools/kbench) and is hipErrorInvalidValue in libm4ri_hip.so.
 extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {
   if (a.m <= 0 || a.n <= 0 || a.batch <= 0) return hipSuccess;
-  if (a.a_packed && cfg != 8 && !cfg_is_v7(cfg)) return hipErrorInvalidValue;  // only v6 / v7 read the packed layout
+  if (a.a_packed && cfg != 8 && !cfg_is_v7(cfg)) return hipErrorInvalidValue;  // only v6 / v7 / v8 read the packed layout
+  if (const int RG = cfg_v8_rg(cfg)) return launch_v8(a, cfg, RG, stream);
   const int R = gf2k_m4rm_rows_per_tile(cfg);
   a.tiles_m = (a.m + R - 1) / R;
   const int TC = gf2k_m4rm_cols_per_tile(cfg);
@@ -2566,7 +2723,7 @@ extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {
   if (cfg == 0 || cfg == 1 || a.ksplit < 1) a.ksplit = 1;  // first-generation kernels have no split-K
   if (a.ksplit > nw32) a.ksplit = nw32 > 0 ? nw32 : 1;
   a.kwords = (nw32 + a.ksplit - 1) / a.ksplit;
-  if (cfg == 8 || (cfg > 80 && cfg < 90) || cfg_is_v7(cfg)) a.kwords = (a.kwords + 1) & ~1;  // v6 reads A in 64-bit slabs: slices start at even words
+  if (cfg == 8 || (cfg > 80 && cfg < 100)) a.kwords = (a.kwords + 1) & ~1;  // v6 reads A in 64-bit slabs: slices start at even words
   a.ksplit = a.kwords > 0 ? (nw32 + a.kwords - 1) / a.kwords : 1;  // no empty slices
   if (a.ksplit <= 1 || cfg == 0 || cfg == 1 || (a.ldp & 1)) a.P = nullptr;
   if (a.ksplit > 1 && !a.accumulate && !a.P) {  // slices are combined with atomic XOR: start from zero
@@ -2585,15 +2742,15 @@ extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {
       e = a.a_packed ? launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 4, 0, 1>, 512, a, nwg, stream)
                      : launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 4>, 512, a, nwg, stream);
       break;
-    case 9:  // four chunks per table, 4096 x 512 tile
-      e = a.a_packed ? launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2, 0, 1>, 512, a, nwg, stream)
-                     : launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2>, 512, a, nwg, stream);
-      break;
     case 81: e = launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 6>, 512, a, nwg, stream); break;
     case 82: e = launch_tile_kernel(&gf2_m4rm_kernel_v6<8, 3>, 512, a, nwg, stream); break;
 #ifdef GF2K_DEV_VARIANTS
     case 0: e = launch_tile_kernel(&gf2_m4rm_kernel<8, 128>, 512, a, nwg, stream); break;
     case 1: e = launch_tile_kernel(&gf2_m4rm_kernel<4, 64>, 256, a, nwg, stream); break;
+    case 90:  // the round-1/2 kernel v7 (fixed 4096 x 512 tile, uniform split-K)
+      e = a.a_packed ? launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2, 0, 1>, 512, a, nwg, stream)
+                     : launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2>, 512, a, nwg, stream);
+      break;
     // timing-only ablations of v7 on packed A (wrong results by design)
     case 92: e = a.a_packed ? launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2, 2, 1>, 512, a, nwg, stream) : hipErrorInvalidValue; break;  // no barriers
     case 93: e = a.a_packed ? launch_tile_kernel(&gf2_m4rm_kernel_v7<8, 2, 3, 1>, 512, a, nwg, stream) : hipErrorInvalidValue; break;  // no loads in the loop

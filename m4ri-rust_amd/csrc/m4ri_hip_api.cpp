@@ -350,24 +350,34 @@ extern "C" int gf2_prof_read(int *launches, double *ms, int reset) {
   return 0;
 }
 
-static int launch_m4rm(gf2k_mul_args a, int cfg, hipStream_t s) {
-  bool on;
-  {
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    on = g_prof_on;
-  }
+// bench.py's roofline: HIP events on the launch stream around the tile-kernel launches of one (batched) product
+struct ProfScope {
   ProfPair pp{};
-  if (on) {
-    HIP_TRY(hipEventCreate(&pp.a));
-    HIP_TRY(hipEventCreate(&pp.b));
-    HIP_TRY(hipEventRecord(pp.a, s));
+  bool on = false;
+  hipStream_t s;
+  explicit ProfScope(hipStream_t s_) : s(s_) {
+    {
+      std::lock_guard<std::mutex> lk(g_prof_mu);
+      on = g_prof_on;
+    }
+    if (on && (hipEventCreate(&pp.a) != hipSuccess || hipEventCreate(&pp.b) != hipSuccess || hipEventRecord(pp.a, s) != hipSuccess)) {
+      (void)hipGetLastError();
+      on = false;
+    }
   }
-  HIP_TRY(gf2k_m4rm(a, cfg, s));
-  if (on) {
-    HIP_TRY(hipEventRecord(pp.b, s));
+  ~ProfScope() {
+    if (!on) return;
+    if (hipEventRecord(pp.b, s) != hipSuccess) {
+      (void)hipGetLastError();
+      return;
+    }
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof.push_back(pp);
   }
+};
+
+static int launch_m4rm(gf2k_mul_args a, int cfg, hipStream_t s) {
+  HIP_TRY(gf2k_m4rm(a, cfg, s));
   return 0;
 }
 
@@ -400,39 +410,11 @@ static long long tiles_of(const TileGeom &g, int m, int n) {
   return (long long)((m + g.rows - 1) / g.rows) * ((n + g.cols - 1) / g.cols);
 }
 
-// `packed`: A may be handed over row-group packed (Strassen leaves); only variants 8 and 9 read that layout, so the caller
-// checks the answer and asks again with packed = false if it got another one
-static int m4rm_cfg_for(int m, int n, int batch, bool packed = false) {
-  (void)batch;
-  // A/B override, restricted to variants that compute the product (the timing-only ablations exist only in development
-  // builds of the kernels and would be hipErrorInvalidValue here anyway)
-  static const int forced = [] {
-    const int f = env_int("M4RI_HIP_M4RM_CFG", -1);
-#ifdef GF2K_DEV_VARIANTS
-    return f;
-#else
-    if (f < 0 || f == 7 || f == 8 || f == 9 || f == 20 || f == 81 || f == 82) return f;
-    std::fprintf(stderr, "m4ri_hip: M4RI_HIP_M4RM_CFG=%d ignored (accepted: 7, 8, 9, 20, 81, 82)\n", f);
-    return -1;
-#endif
-  }();
-  if (forced >= 0) return forced;
-  if (m <= 256) return 20;
-  // same tile area: the kernel with the smaller (tiles x cycles per tile) wins, i.e. the paired kernels unless their tall
-  // tiles leave more of the grid empty
-  int best = 7;
-  double cost = (double)tiles_of(tile_geom(7), m, n) * tile_geom(7).cyc_per_chunk;
-  const double c8 = (double)tiles_of(tile_geom(8), m, n) * tile_geom(8, packed).cyc_per_chunk;
-  if (c8 <= cost) best = 8, cost = c8;
-  if (packed) {
-    const double c9 = (double)tiles_of(tile_geom(9), m, n) * tile_geom(9, true).cyc_per_chunk;
-    if (c9 < cost) best = 9, cost = c9;
-  }
-  return best;
-}
+static bool cfg_reads_packed(int cfg) { return cfg == 8 || (cfg >= 9 && cfg <= 12) || (cfg >= 90 && cfg < 100); }
+static int cfg_v8_rg(int cfg) { return cfg == 9 ? 8 : cfg == 10 ? 4 : cfg == 11 ? 2 : cfg == 12 ? 1 : 0; }
 
-// split-K factor: when a product has too few tiles to fill 256 CUs, the inner dimension is cut into slices of
-// at least 128 bits; the slices' partial products are combined by a second kernel
+// split-K factor of the older kernels (v3, v6): when a product has too few tiles to fill 256 CUs, the inner dimension is cut into
+// slices of at least 128 bits; the slices' partial products are combined by a second kernel
 static int m4rm_ksplit_for(int m, int l, int n, int batch, int cfg) {
   static const int forced = env_int("M4RI_HIP_M4RM_KSPLIT", 0);
   if (forced > 0) return forced;
@@ -445,7 +427,7 @@ static int m4rm_ksplit_for(int m, int l, int n, int batch, int cfg) {
     static const int balance = env_int("M4RI_HIP_SPLITK_BALANCE", 1);
     static const long long cap = (long long)env_int("M4RI_HIP_SPLITK_WS_MIB", 2048) << 20;
     if (!balance || batch != 1 || wg > 2048) return 1;
-    const TileGeom g = tile_geom(cfg, cfg == 8 || cfg == 9);
+    const TileGeom g = tile_geom(cfg, cfg == 8);
     const double tile_cyc = (double)nw32 * 4.0 * g.cyc_per_chunk;                       // one whole-k tile
     const double pass_cyc = 2.0 * (double)m * (double)n / 8.0 / 5.0e12 * 2.4e9;         // write + read of one slice's partial C
     int best = 1;
@@ -463,16 +445,247 @@ static int m4rm_ksplit_for(int m, int l, int n, int batch, int cfg) {
   return ks < 1 ? 1 : (int)ks;
 }
 
-// modelled duration of one (batched) tile-kernel launch: rounds of 256 workgroups, each `chunks` table steps
-static double m4rm_time_model(int m, int l, int n, int batch, bool packed) {
-  int cfg = m4rm_cfg_for(m, n, batch, packed);
-  if (cfg != 8 && cfg != 9 && packed) cfg = m4rm_cfg_for(m, n, batch, packed = false);
+// ---- which tile kernel, and how its launch is cut (shared by the launchers and the level chooser) ----
+// Candidates: the v8 family (512 RG rows x 512 columns, RG = 8 / 4 / 2 / 1: variants 9 / 10 / 11 / 12) with whole tiles, or with
+// the tiles of the last (incomplete) round of 256 workgroups cut into stream-K segments (everything, when there are fewer than
+// 256 tiles); v6 (8) and v3 (7, and 20 for m <= 256) with their uniform split-K.  Chosen by modelled time; the constants are
+// measured (tools/kbench, profiles/r03_tile_variants.txt).  `packed`: A is handed over row-group packed (Strassen leaves, or a
+// plain product that packs A itself): only 8 and 9-12 read that layout.
+struct TilePlan {
+  int cfg = 7;
+  int ksplit = 1;           // v3 / v6: uniform slices of the inner dimension
+  int n_rem = 0, nseg = 0;  // v8: tiles cut into stream-K segments, number of segments
+  bool packed = false;
+  double t = 0;             // modelled seconds of the launch (reduction of partial tiles included)
+  size_t ws_bytes = 0;      // scratch for partial tiles
+  // a batched launch may be cut in two: the first `batch - tail_batch` products as planned above (whole rounds of 256 tiles), the
+  // last tail_batch products in a launch of their own with its own variant and split (a short tile height, every tile cut)
+  int tail_batch = 0, tail_cfg = 0, tail_n_rem = 0, tail_nseg = 0;
+  size_t tail_ws_bytes = 0;
+};
+
+// microseconds per quad (32 bits of the inner dimension) of a v8 tile: table generation (256 entry writes, barrier) + RG x 1024
+// lookups; an unpacked A costs 64 scattered 8-byte loads per wave and row group.  Measured on 343 leaves of 4096^3
+// (profiles/r03_tile_variants.txt): packed 0.71 / 0.96 / 1.46 / 2.55 us for RG = 1 / 2 / 4 / 8.
+static double v8_quad_us(int RG, bool packed) {
+  static const double base = env_int("M4RI_HIP_V8_BASE_NS", 450) * 1e-3, per = env_int("M4RI_HIP_V8_PER_RG_NS", 262) * 1e-3,
+                      unp0 = env_int("M4RI_HIP_V8_UNPACKED_BASE_NS", 100) * 1e-3, unp = env_int("M4RI_HIP_V8_UNPACKED_NS", 70) * 1e-3;
+  return base + per * RG + (packed ? 0.0 : unp0 + unp * RG);
+}
+
+// One v8 launch: `batch` products, variant cfg, the last n_rem tiles cut into about `want` segments (n_rem = 0: whole tiles only).
+// Fills c (split fields normalised the way the launcher will normalise them) and returns false if the split is void or its
+// scratch exceeds the cap.
+static bool v8_model(int m, int l, int n, int batch, bool packed, int cfg, long long n_rem, long long want, TilePlan &c) {
+  static const long long cap = (long long)env_int("M4RI_HIP_SPLITK_WS_MIB", 2048) << 20;
+  static const double seg_fix = env_int("M4RI_HIP_V8_SEG_FIX_NS", 3500) * 1e-9, seg_rg = env_int("M4RI_HIP_V8_SEG_RG_NS", 2600) * 1e-9,
+                      red_bw = env_int("M4RI_HIP_V8_REDUCE_GBS", 2500) * 1e9, two_part = env_int("M4RI_HIP_V8_TWO_PART_PCT", 180) * 1e-2;
+  const int RG = cfg_v8_rg(cfg), R = 512 * RG, nw32 = (l + 31) / 32, Q = (nw32 + 1) / 2;
+  const long long T = (long long)((m + R - 1) / R) * ((n + 511) / 512) * batch;
+  const double tq = v8_quad_us(RG, packed) * 1e-6, tile_bytes = R * 64.0;
+  const double tile_t = 2.0 * Q * tq + (3.4 + 0.6 * RG) * 1e-6;  // + prologue, epilogue (LDS transpose, stores), hand-over to the next workgroup
+  c = TilePlan();
+  c.cfg = cfg;
+  c.packed = packed;
+  if (n_rem <= 0 || Q < 1) {
+    c.t = std::ceil(T / 256.0) * tile_t + 2e-6;
+    return true;
+  }
+  if (n_rem > T) n_rem = T;
+  if (want < 1) want = 256;
+  const long long gtot = n_rem * Q;
+  long long seg = (gtot + want - 1) / want;
+  if (seg > Q) seg = Q;
+  if (seg < 1) seg = 1;
+  const long long ns = (gtot + seg - 1) / seg;
+  if (ns <= n_rem && seg == Q) return false;  // nothing is cut
+  c.n_rem = (int)n_rem;
+  c.nseg = (int)ns;
+  c.ws_bytes = (size_t)(2.0 * ns * tile_bytes);
+  if ((long long)c.ws_bytes > cap || ns > (1 << 22)) return false;
+  // partial tiles: written at the end of the segment phase (every workgroup at once: ~2.6 us per row group on top of the
+  // prologue; a segment that spans two tiles pays prologue and stores twice), read back and folded into C by the reduction
+  // kernel (launch gap + bytes at ~2.5 TB/s)
+  const bool spans = (Q % seg) != 0;
+  const double slots = (double)ns + (spans ? (double)std::min(ns, n_rem) : 0.0);
+  const double reduce_t = (slots + (double)n_rem) * tile_bytes / red_bw + 2.5e-6;
+  const double seg_t = 2.0 * seg * tq + (seg_fix + seg_rg * RG) * (spans ? two_part : 1.0);
+  c.t = std::ceil((T - n_rem) / 256.0) * tile_t + std::ceil(ns / 256.0) * seg_t + reduce_t + 2e-6;
+  return true;
+}
+
+static bool older_model(int m, int l, int n, int batch, bool packed, int cfg, TilePlan &c) {
+  static const long long cap = (long long)env_int("M4RI_HIP_SPLITK_WS_MIB", 2048) << 20;
+  if (packed && !cfg_reads_packed(cfg)) return false;
+  const int nw32 = (l + 31) / 32;
   const TileGeom g = tile_geom(cfg, packed);
   const int ks = m4rm_ksplit_for(m, l, n, batch, cfg);
   const double wg = (double)tiles_of(g, m, n) * batch * ks;
-  const double chunks = std::ceil((l + 31) / 32 / (double)ks) * 4.0;
-  const double rounds = std::ceil(wg / 256.0);
-  return rounds * (chunks * g.cyc_per_chunk + 6000.0) / 2.4e9 + 3e-6;
+  const double chunks = std::ceil(nw32 / (double)ks) * 4.0;
+  c = TilePlan();
+  c.cfg = cfg;
+  c.ksplit = ks;
+  c.packed = packed;
+  c.t = std::ceil(wg / 256.0) * (chunks * g.cyc_per_chunk + 6000.0) / 2.4e9 + 3e-6;
+  if (ks > 1) {
+    const double part = (double)m * (double)(((words_of(n) + 1) & ~1) * 8) * batch;
+    c.ws_bytes = (size_t)(part * ks);
+    c.t += (part * ks * 2.0 + part) / 4.0e12 + 2.5e-6;
+    if ((long long)c.ws_bytes > cap) return false;
+  }
+  return true;
+}
+
+static TilePlan plan_tiles(int m, int l, int n, int batch, bool packed, bool allow_tail = true) {
+  // A/B override, restricted to variants that compute the product (the timing-only ablations exist only in development
+  // builds of the kernels and would be hipErrorInvalidValue here anyway)
+  static const int forced = [] {
+    const int f = env_int("M4RI_HIP_M4RM_CFG", -1);
+#ifdef GF2K_DEV_VARIANTS
+    return f;
+#else
+    if (f < 0 || f == 7 || f == 8 || (f >= 9 && f <= 12) || f == 20 || f == 81 || f == 82) return f;
+    std::fprintf(stderr, "m4ri_hip: M4RI_HIP_M4RM_CFG=%d ignored (accepted: 7, 8, 9, 10, 11, 12, 20, 81, 82)\n", f);
+    return -1;
+#endif
+  }();
+  static const int forced_ks = env_int("M4RI_HIP_M4RM_KSPLIT", 0);
+  static const int streamk = env_int("M4RI_HIP_STREAMK", 1);      // 0: whole tiles only
+  static const int tails = env_int("M4RI_HIP_TAIL_LAUNCH", 1);    // 0: never cut a batched launch in two
+  TilePlan best, c;
+  bool have = false;
+  auto consider = [&](const TilePlan &x) {
+    if (!have || x.t < best.t) best = x, have = true;
+  };
+  auto v8 = [&](int cfg) {
+    const int R = 512 * cfg_v8_rg(cfg);
+    const long long tp = (long long)((m + R - 1) / R) * ((n + 511) / 512), T = tp * batch;
+    if (forced_ks > 0) {
+      if (v8_model(m, l, n, batch, packed, cfg, T, T * forced_ks, c) || v8_model(m, l, n, batch, packed, cfg, 0, 0, c)) consider(c);
+      return;
+    }
+    if (v8_model(m, l, n, batch, packed, cfg, 0, 0, c)) consider(c);
+    if (T < 1) return;
+    const long long rem = T < 256 ? T : T % 256;
+    if (rem == 0) return;
+    if (streamk && v8_model(m, l, n, batch, packed, cfg, rem, 256, c)) consider(c);
+    // the last products in a launch of their own: the first launch keeps whole rounds of 256 tiles
+    if (tails && allow_tail && forced < 0 && batch > 1 && T > 256) {
+      const long long b1 = (T - rem) / tp;  // products whose tiles all lie in the whole rounds
+      if (b1 >= 1 && b1 < batch) {
+        TilePlan head;
+        if (v8_model(m, l, n, (int)b1, packed, cfg, 0, 0, head)) {
+          const TilePlan tail = plan_tiles(m, l, n, batch - (int)b1, packed, false);
+          head.t += tail.t + 1.5e-6;
+          head.tail_batch = batch - (int)b1;
+          head.tail_cfg = tail.cfg;
+          head.tail_n_rem = tail.n_rem;
+          head.tail_nseg = tail.nseg;
+          head.tail_ws_bytes = tail.ws_bytes;
+          if (cfg_v8_rg(tail.cfg)) consider(head);
+        }
+      }
+    }
+  };
+  if (forced >= 0) {
+    if (cfg_v8_rg(forced)) v8(forced);
+    else if (older_model(m, l, n, batch, packed, forced, c)) consider(c);
+    if (!have) {  // a forced variant that cannot read this operand layout: the caller asks again unpacked
+      best.cfg = forced;
+      best.packed = false;
+      best.ksplit = m4rm_ksplit_for(m, l, n, batch, forced);
+    }
+    return best;
+  }
+  if (m <= 256 && !packed) {
+    if (older_model(m, l, n, batch, packed, 20, c)) consider(c);
+    return best;
+  }
+  if (!packed && older_model(m, l, n, batch, packed, 7, c)) consider(c);
+  if (older_model(m, l, n, batch, packed, 8, c)) consider(c);
+  for (int cfg = 9; cfg <= 12; ++cfg) v8(cfg);
+  return best;
+}
+
+// modelled duration of one (batched) tile-kernel launch
+static double m4rm_time_model(int m, int l, int n, int batch, bool packed) { return plan_tiles(m, l, n, batch, packed).t; }
+// ... of the leaf launch of a Strassen product (the last split pass may write the A leaves packed: mul_strassen takes the better plan)
+static double leaf_time_model(int m, int l, int n, int batch, bool may_pack) {
+  const double t = m4rm_time_model(m, l, n, batch, false);
+  return may_pack ? std::min(t, m4rm_time_model(m, l, n, batch, true)) : t;
+}
+// ... of a plain product, which may pack A itself first (mul_m4rm_plain makes the same comparison)
+static double plain_time_model(int m, int l, int n) {
+  static const double bw = (double)env_int("M4RI_HIP_STREAM_GBS", 5000) * 1e9;
+  static const int plain_pack = env_int("M4RI_HIP_PLAIN_APACK", 1);
+  double t = m4rm_time_model(m, l, n, 1, false);
+  const long long wp = (words_of(l) + 1) & ~1ll, prow = ((long long)m + 63) & ~63ll;
+  if (plain_pack && m >= 512 && prow * wp * 8 < (1ll << 32)) {
+    const TilePlan pk = plan_tiles(m, l, n, 1, true);
+    if (cfg_reads_packed(pk.cfg)) t = std::min(t, pk.t + 2.0 * (double)prow * (double)wp * 8.0 / bw + 2.5e-6);
+  }
+  return t;
+}
+
+// one planned (batched) product: the launch, and the launch of the tail products if the plan cuts the batch in two
+static int apply_tile_plan(gf2k_mul_args &a, const TilePlan &tp, hipStream_t s);
+static int launch_planned(gf2k_mul_args a, const TilePlan &tp, hipStream_t s) {
+  ProfScope prof(s);
+  const int total = a.batch;
+  const bool cut = tp.tail_batch > 0 && tp.tail_batch < total;
+  if (cut) a.batch = total - tp.tail_batch;
+  if (int rc = apply_tile_plan(a, tp, s)) return rc;
+  if (int rc = launch_m4rm(a, tp.cfg, s)) return rc;
+  if (!cut) return 0;
+  gf2k_mul_args b = a;
+  const long long b1 = a.batch;
+  b.A += b1 * a.sA;
+  b.B += b1 * a.sB;
+  b.C += b1 * a.sC;
+  b.batch = tp.tail_batch;
+  b.ksplit = 1;
+  b.n_rem = b.P ? tp.tail_n_rem : 0;
+  b.nseg = b.P ? tp.tail_nseg : 0;
+  return launch_m4rm(b, tp.tail_cfg, s);
+}
+
+// the plan of a plain product: A unpacked, or packed by a pass of its own when the model says that pays
+static TilePlan plain_plan(int m, int l, int n, bool *pack) {
+  static const double bw = (double)env_int("M4RI_HIP_STREAM_GBS", 5000) * 1e9;
+  static const int plain_pack = env_int("M4RI_HIP_PLAIN_APACK", 1);
+  TilePlan tp = plan_tiles(m, l, n, 1, false);
+  *pack = false;
+  const long long wp = (words_of(l) + 1) & ~1ll, prow = ((long long)m + 63) & ~63ll;
+  if (plain_pack && m >= 512 && prow * wp * 8 < (1ll << 32)) {
+    const TilePlan pk = plan_tiles(m, l, n, 1, true);
+    if (cfg_reads_packed(pk.cfg) && pk.t + 2.0 * (double)prow * (double)wp * 8.0 / bw + 2.5e-6 < tp.t) tp = pk, *pack = true;
+  }
+  return tp;
+}
+
+// fills in the launch fields of `a` from a plan (scratch for partial tiles from the stream's workspace slot 1); falls back to an
+// unsplit launch when the scratch cannot be had
+static int apply_tile_plan(gf2k_mul_args &a, const TilePlan &tp, hipStream_t s) {
+  a.ksplit = 1;
+  a.n_rem = a.nseg = 0;
+  a.P = nullptr;
+  a.p_words = 0;
+  const size_t want = std::max(tp.ws_bytes, tp.tail_ws_bytes);  // (the two launches of a cut batch run one after the other)
+  if (want == 0) return 0;
+  void *ws = nullptr;
+  if (stream_workspace(s, want, &ws, 1) != 0) return 0;
+  a.P = static_cast<u64 *>(ws);
+  a.p_words = (long long)(want / sizeof(u64));
+  if (tp.ws_bytes == 0) return 0;
+  if (cfg_v8_rg(tp.cfg)) {
+    a.n_rem = tp.n_rem;
+    a.nseg = tp.nseg;
+  } else {
+    a.ksplit = tp.ksplit;
+    a.ldp = (words_of(a.n) + 1) & ~1ll;
+    a.sP = (long long)a.m * a.ldp;
+  }
+  return 0;
 }
 
 // The level plan: a product with L Strassen levels runs L levels of operand splits, ONE batched leaf launch and L levels of
@@ -544,12 +757,22 @@ static double strassen_pass_bytes(double m, double l, double n, int L) {
 //   t(L) = modelled time of the batched leaf launch (rounds of 256 workgroups x chunks x measured cycles per
 //          chunk, split-K included)  +  bytes moved by the split / merge passes / bw
 // `leaf_min` bounds the leaf dimensions from below (mzd_mul's cutoff argument, strassen.rs:8-18).
+// modelled seconds of the product with exactly L levels on the shape as given (-1: L levels do not divide it)
+static double level_time_model(int m, int l, int n, int L) {
+  static const double bw = (double)env_int("M4RI_HIP_STREAM_GBS", 5000) * 1e9;        // streaming B/s
+  if (L <= 0) return plain_time_model(m, l, n);
+  const int d = 1 << L;
+  if (L > 6 || m % d || l % (128 * d) || n % (128 * d)) return -1.0;  // leaf rows integral, leaf widths an even word count
+  return leaf_time_model(m >> L, l >> L, n >> L, (int)pow7(L), strassen_packs_a(m, L)) + strassen_pass_bytes(m, l, n, L) / bw +
+         3 * 3e-6 * (double)strassen_plan(L).size();
+}
+extern "C" double gf2_model_time(int m, int l, int n, int levels) { return level_time_model(m, l, n, levels); }
+
 static int pick_levels(int m, int l, int n, int req, int leaf_min, double *t_out = nullptr) {
   static const int max_auto = env_int("M4RI_HIP_STRASSEN_MAX_LEVELS", 5);
-  static const double bw = (double)env_int("M4RI_HIP_STREAM_GBS", 5000) * 1e9;        // streaming B/s
   const int cap = req > 0 ? (req > 6 ? 6 : req) : max_auto;
   int best = 0;
-  double best_t = 0, t0 = 0;
+  double best_t = 0;
   for (int L = 0; L <= cap; ++L) {
     if (L > 0) {
       const int d = 1 << L;
@@ -560,20 +783,15 @@ static int pick_levels(int m, int l, int n, int req, int leaf_min, double *t_out
       best = L;
       continue;
     }
-    // a plain product packs A itself when it is tall and wide enough (mul_m4rm_plain): one more pass over A
-    const bool plain_packs = L == 0 && m >= 2048 && n >= 1024;
-    double t = m4rm_time_model(m >> L, l >> L, n >> L, (int)pow7(L), L == 0 ? plain_packs : strassen_packs_a(m, L));
-    if (plain_packs) t += 2.0 * (double)m * l / 8.0 / bw + 3e-6;
-    if (L > 0) t += strassen_pass_bytes(m, l, n, L) / bw + 3 * 3e-6 * (double)strassen_plan(L).size();
-    if (L == 0) t0 = t;
-    if (L == 0 || t < best_t) {
+    double t = level_time_model(m, l, n, L);
+    if (L == 1) t *= 1.15;  // the single-level pass kernels (unfused, unpacked A leaves) run well below the model: 20480^3 2.21 ms against 1.82
+    // tools/levels_sweep.py (profiles/r03_levels_sweep.txt): the model is 3-10 % pessimistic for 0 and 2 levels and within 3 % for
+    // 3 and more, so a further level must promise 2 % (up to two levels) / 3 % (beyond) over the best count below it
+    if (L == 0 || t < best_t * (L >= 3 ? 0.97 : 0.98)) {
       best = L;
       best_t = t;
     }
   }
-  // the model is coarse for products of a few hundred microseconds (12288^3 measured 0.47 ms with one level against 0.39 ms
-  // plain although the model preferred the level): levels must promise 8 % to be taken
-  if (req <= 0 && best > 0 && best_t > 0.92 * t0) best = 0, best_t = t0;
   if (t_out) *t_out = best_t;
   return best;
 }
@@ -611,28 +829,27 @@ static int mul_m4rm_plain(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int
     HIP_TRY(gf2k_va(A->data, A->ld, B->data, B->ld, C->data, C->ld, m, l, n, s));
     return 0;
   }
-  // A tall product first copies A into the row-group-packed layout (one extra pass over A, ~0.2 ms per GiB) so that the
-  // paired tile kernels fetch it with contiguous loads: worth it as soon as the product has a few column tiles
-  static const int plain_pack = env_int("M4RI_HIP_PLAIN_APACK", 1);
+  // A tall product may first copy A into the row-group-packed layout (one extra pass over A, ~0.2 ms per GiB) so that the
+  // paired tile kernels fetch it with contiguous loads: taken when the modelled launch gains more than the pass costs
   const long long wp = (words_of(l) + 1) & ~1ll, prow = ((long long)m + 63) & ~63ll;
-  int cfg = m4rm_cfg_for(m, n, 1);
+  bool packed = false;
+  TilePlan tp = plain_plan(m, l, n, &packed);
   const u64 *Aptr = A->data;
   long long lda = A->ld;
-  bool packed = false;
-  if (plain_pack && m >= 2048 && n >= 1024 && prow * wp * 8 < (1ll << 32)) {
-    const int cp = m4rm_cfg_for(m, n, 1, true);
+  if (packed) {
     void *pa = nullptr;
-    if ((cp == 8 || cp == 9) && stream_workspace(s, (size_t)(prow * wp * 8), &pa, 2) == 0) {
+    if (stream_workspace(s, (size_t)(prow * wp * 8), &pa, 2) == 0) {
       HIP_TRY(gf2k_packA(static_cast<u64 *>(pa), wp, A->data, A->ld, m, words_of(l), s));
       Aptr = static_cast<const u64 *>(pa);
       lda = wp;
-      cfg = cp;
-      packed = true;
+    } else {
+      packed = false;
+      tp = plan_tiles(m, l, n, 1, false);
     }
   }
   // buffer descriptors of the tile kernel carry 32-bit byte counts: one tile of A rows must stay below 4 GiB
-  if ((!packed && (long long)A->ld * 8 * 2048 >= (1ll << 32)) || (long long)B->ld * 8 * 32 >= (1ll << 31))
-    return fail_msg("gf2_mul_dev: row stride too large for the tile kernel (more than ~16 million columns)");
+  if ((!packed && (long long)A->ld * 8 * 4096 >= (1ll << 32)) || (long long)B->ld * 8 * 32 >= (1ll << 31))
+    return fail_msg("gf2_mul_dev: row stride too large for the tile kernel (more than ~8 million columns)");
   gf2k_mul_args a{};
   a.A = Aptr;
   a.a_packed = packed ? 1 : 0;
@@ -646,16 +863,7 @@ static int mul_m4rm_plain(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int
   a.n = n;
   a.batch = 1;
   a.accumulate = accumulate;
-  a.ksplit = m4rm_ksplit_for(m, l, n, 1, cfg);
-  if (a.ksplit > 1) {  // slices store partial products that a second kernel combines (atomic XOR costs about 3x as much)
-    static const long long cap = (long long)env_int("M4RI_HIP_SPLITK_WS_MIB", 2048) << 20;
-    a.ldp = (words_of(n) + 1) & ~1ll;
-    a.sP = (long long)m * a.ldp;
-    const long long bytes = a.sP * a.ksplit * (long long)sizeof(u64);
-    void *ws = nullptr;
-    if (bytes <= cap && stream_workspace(s, (size_t)bytes, &ws, 1) == 0) a.P = static_cast<u64 *>(ws);
-  }
-  return launch_m4rm(a, cfg, s);
+  return launch_planned(a, tp, s);
 }
 
 // quadrants (0 = X11, 1 = X12, 2 = X21, 3 = X22) that combination q of a side adds up (second entry -1: a plain copy);
@@ -696,9 +904,12 @@ static int mul_strassen(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int a
   }
   // leaf operands of A in the row-group-packed layout of the paired tile kernel (its A loads become contiguous): written by
   // the last split pass when that pass is a fused one
-  int leaf_cfg = m4rm_cfg_for(m >> L, n >> L, (int)pow7(L), strassen_packs_a(m, L));
-  const bool a_packed = strassen_packs_a(m, L) && (leaf_cfg == 8 || leaf_cfg == 9);
-  if (!a_packed) leaf_cfg = m4rm_cfg_for(m >> L, n >> L, (int)pow7(L), false);
+  TilePlan leaf_plan = plan_tiles(m >> L, l >> L, n >> L, (int)pow7(L), false);
+  bool a_packed = false;
+  if (strassen_packs_a(m, L)) {
+    const TilePlan pk = plan_tiles(m >> L, l >> L, n >> L, (int)pow7(L), true);
+    if (cfg_reads_packed(pk.cfg) && pk.t <= leaf_plan.t) leaf_plan = pk, a_packed = true;
+  }
 
   // one split step on one side: operands of level `prev` (7^prev of them, or the caller's matrix) -> level i
   auto split_step = [&](const PlanStep &st, int prev, int i, int side, bool pack) -> int {
@@ -758,8 +969,7 @@ static int mul_strassen(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int a
       a.batch = (int)pow7(L);
       a.accumulate = 0;
       a.a_packed = a_packed ? 1 : 0;
-      a.ksplit = m4rm_ksplit_for(mL, lL, nL, a.batch, leaf_cfg);
-      if (int r = launch_m4rm(a, leaf_cfg, s)) return r;
+      if (int r = launch_planned(a, leaf_plan, s)) return r;
     }
     // fold the products back up
     int i = L;
@@ -809,9 +1019,7 @@ struct ShapePlan {
 };
 static double plain_model(int m, int l, int n) {
   if (m <= 0 || l <= 0 || n <= 0) return 0.0;
-  static const double bw = (double)env_int("M4RI_HIP_STREAM_GBS", 5000) * 1e9;
-  const bool packs = m >= 2048 && n >= 1024;
-  return m4rm_time_model(m, l, n, 1, packs) + (packs ? 2.0 * (double)m * l / 8.0 / bw + 3e-6 : 0.0);
+  return plain_time_model(m, l, n);
 }
 
 // a border strip runs through the automatic choice among the level counts that divide it (no further padding / peeling)
@@ -840,7 +1048,7 @@ static ShapePlan plan_shape(int m, int l, int n, int req, int leaf_min) {
   for (int L = lo; L <= hi; ++L) {
     const long long um = 64ll << L, uw = 128ll << L;
     auto core_time = [&](long long mm, long long ll, long long nn) {
-      return m4rm_time_model((int)(mm >> L), (int)(ll >> L), (int)(nn >> L), (int)pow7(L), strassen_packs_a((int)mm, L)) +
+      return leaf_time_model((int)(mm >> L), (int)(ll >> L), (int)(nn >> L), (int)pow7(L), strassen_packs_a((int)mm, L)) +
              strassen_pass_bytes((double)mm, (double)ll, (double)nn, L) / bw + 3 * 3e-6 * (double)strassen_plan(L).size();
     };
     auto leaves_ok = [&](long long mm, long long ll, long long nn) {
@@ -1049,12 +1257,21 @@ extern "C" int gf2_mul_nt_dev(gf2_dmat *C, gf2_dmat const *A, gf2_dmat const *Bt
 
 extern "C" size_t gf2_mul_workspace_bytes(int m, int l, int n, int algo, int param) {
   if (algo == GF2_ALGO_NAIVE) return n <= 64 ? (size_t)n * ((words_of(l) + 1) & ~1) * 8 : 0;
-  // a tall plain product packs A (mul_m4rm_plain) and may cut the inner dimension into slices with partial tiles
-  const size_t packed_a = (m >= 2048 && n >= 1024) ? (size_t)((m + 63) & ~63) * (size_t)((words_of(l) + 1) & ~1) * 8 : 0;
-  if (algo == GF2_ALGO_M4RM) return packed_a;
+  // a plain product may pack A (mul_m4rm_plain) and may cut tiles into segments / slices with partial tiles in scratch
+  size_t plain_ws = 0;
+  if (m > 0 && l > 0 && n > 64) {
+    bool pack = false;
+    const TilePlan tp = plain_plan(m, l, n, &pack);
+    plain_ws = std::max(tp.ws_bytes, tp.tail_ws_bytes) + (pack ? (size_t)((m + 63) & ~63) * (size_t)((words_of(l) + 1) & ~1) * 8 : 0);
+  }
+  if (algo == GF2_ALGO_M4RM) return plain_ws;
   static const int leaf_min = env_int("M4RI_HIP_STRASSEN_LEAF_MIN", 2048);
   const int L = pick_levels(m, l, n, param, leaf_min);
-  return L > 0 ? strassen_ws_words(m, l, n, L) * sizeof(u64) : packed_a;
+  if (L <= 0) return plain_ws;
+  const bool pk = strassen_packs_a(m, L);
+  const TilePlan a = plan_tiles(m >> L, l >> L, n >> L, (int)pow7(L), false), b = pk ? plan_tiles(m >> L, l >> L, n >> L, (int)pow7(L), true) : a;
+  const TilePlan &lp = (pk && cfg_reads_packed(b.cfg) && b.t <= a.t) ? b : a;
+  return strassen_ws_words(m, l, n, L) * sizeof(u64) + std::max(lp.ws_bytes, lp.tail_ws_bytes);
 }
 
 extern "C" int gf2_add_dev(gf2_dmat *C, gf2_dmat const *A, gf2_dmat const *B, void *stream) {
@@ -1180,6 +1397,22 @@ extern "C" double gf2_strassen_pass_bytes(int m, int l, int n, int levels) {
 // How a device product of this shape would run (no device needed: the cost model's answer, before the memory cap):
 // *kind = 0 as given (levels Strassen levels, 0 = plain M4RM), 1 zero-padded to dims[0..2], 2 peeled to the core dims[0..2]
 // with the border strips through the plain kernels.  Returns the number of Strassen levels.
+extern "C" double gf2_tile_plan(int m, int l, int n, int batch, int packed, long long out[9]) {
+  const TilePlan tp = plan_tiles(m, l, n, batch < 1 ? 1 : batch, packed != 0);
+  if (out) {
+    out[0] = tp.cfg;
+    out[1] = tp.ksplit;
+    out[2] = tp.n_rem;
+    out[3] = tp.nseg;
+    out[4] = (long long)std::max(tp.ws_bytes, tp.tail_ws_bytes);
+    out[5] = tp.tail_batch;
+    out[6] = tp.tail_cfg;
+    out[7] = tp.tail_n_rem;
+    out[8] = tp.tail_nseg;
+  }
+  return tp.t;
+}
+
 extern "C" int gf2_mul_plan(int m, int l, int n, int algo, int param, int *kind, int dims[3]) {
   int k = 0, L = 0, d[3] = {m, l, n};
   if (algo == GF2_ALGO_AUTO || algo == GF2_ALGO_STRASSEN) {

@@ -28,7 +28,9 @@ class MulArgs(ctypes.Structure):  # gf2k_mul_args
                 ("batch", ctypes.c_int), ("accumulate", ctypes.c_int),
                 ("Bp", ctypes.c_void_p), ("sBp", ctypes.c_longlong), ("bp_nc", ctypes.c_int),
                 ("P", ctypes.c_void_p), ("ldp", ctypes.c_longlong), ("sP", ctypes.c_longlong),
-                ("a_packed", ctypes.c_int)]
+                ("a_packed", ctypes.c_int),
+                ("n_rem", ctypes.c_int), ("nseg", ctypes.c_int), ("p_words", ctypes.c_longlong),
+                ("n_full", ctypes.c_int), ("seg_slabs", ctypes.c_int), ("tile_slabs", ctypes.c_int)]
 
 
 @pytest.mark.parametrize("m,l,n,batch", [(2048, 2048, 2048, 2), (4160, 1000, 1100, 1), (300, 520, 2300, 3)])
@@ -56,26 +58,53 @@ def test_tile_kernel_generations_agree(dev, m, l, n, batch):
     for i in range(batch):
         assert lib.gf2k_packA(Apk[i].data_ptr(), lda, A[i].data_ptr(), lda, m, wa, None) == 0
 
-    def run(cfg, packed=False, ksplit=1):
+    lib.gf2k_m4rm_streamk_words.restype = ctypes.c_longlong
+    lib.gf2k_m4rm_streamk_words.argtypes = [ctypes.c_int, ctypes.c_int]
+
+    def run(cfg, packed=False, ksplit=1, n_rem=0, nseg=0, accumulate=False):
         C = torch.full((batch, m, ldb), -1, dtype=torch.int64, device="cuda")
+        if accumulate:
+            C.copy_(C0)
         a = MulArgs()
+        if n_rem or (cfg in (9, 10, 11, 12) and ksplit > 1):  # stream-K split of the v8 family: scratch for the partial tiles
+            rows = {9: 4096, 10: 2048, 11: 1024, 12: 512}[cfg]
+            tiles = -(-m // rows) * -(-n // 512) * batch
+            want = nseg or (tiles * ksplit if not n_rem else 256)
+            words = lib.gf2k_m4rm_streamk_words(cfg, want + tiles + 8)
+            scratch = torch.full((words,), -1, dtype=torch.int64, device="cuda")
+            a.P, a.p_words, a.n_rem, a.nseg = scratch.data_ptr(), words, n_rem, nseg
         a.A = (Apk if packed else A).data_ptr()
         a.B, a.C = B.data_ptr(), C.data_ptr()
         a.lda, a.ldb, a.ldc = lda, ldb, ldb
         a.sA, a.sB, a.sC = (mp * lda if packed else m * lda), l * ldb, m * ldb
-        a.m, a.l, a.n, a.batch, a.ksplit, a.accumulate, a.a_packed = m, l, n, batch, ksplit, 0, int(packed)
+        a.m, a.l, a.n, a.batch, a.ksplit, a.accumulate, a.a_packed = m, l, n, batch, ksplit, int(accumulate), int(packed)
         assert lib.gf2k_m4rm(a, cfg, None) == 0, cfg
         torch.cuda.synchronize()
         return C.cpu().numpy().view(np.uint64)[:, :, :wb]
 
     for cfg, packed, ks in [(7, False, 1), (20, False, 1), (8, False, 1), (9, False, 1), (81, False, 1), (82, False, 1),
-                            (8, True, 1), (9, True, 1), (7, False, 3), (20, False, 2), (8, False, 3), (9, True, 3)]:
+                            (8, True, 1), (9, True, 1), (7, False, 3), (20, False, 2), (8, False, 3), (9, True, 3),
+                            (10, False, 1), (10, True, 1), (11, False, 1), (11, True, 1), (12, False, 1), (12, True, 1),
+                            (10, True, 2), (11, False, 5), (12, True, 3)]:
         got = run(cfg, packed, ks)
         assert np.array_equal(got, expect), (cfg, packed, ks)
+    # stream-K: the last n_rem tiles of the launch cut into segments (slices of one tile, or the tail of one tile plus the head
+    # of the next), whole tiles before them; segment counts that do not divide the slabs; accumulate form
+    C0 = torch.from_numpy(g.random_words(batch * m, ldb * 64, 77).view(np.int64).reshape(batch, m, ldb)).cuda()
+    c0 = C0.cpu().numpy().view(np.uint64)[:, :, :wb]
+    for cfg in (9, 10, 11, 12):
+        rows = {9: 4096, 10: 2048, 11: 1024, 12: 512}[cfg]
+        tiles = -(-m // rows) * -(-n // 512) * batch
+        for packed in (False, True):
+            for n_rem, nseg in [(tiles, 0), (tiles, tiles + 1), (max(1, tiles // 2), 7), (1, 3), (tiles, 3 * tiles + 2)]:
+                got = run(cfg, packed, 1, n_rem, nseg)
+                assert np.array_equal(got, expect), (cfg, packed, n_rem, nseg)
+        got = run(cfg, True, 1, tiles, 2 * tiles + 1, accumulate=True)
+        assert np.array_equal(got, c0 ^ expect), (cfg, "accumulate")  # (the product's bits past n are zero)
     # first-generation kernels, v5, packed B and every timing-only ablation: not in the shipped library
     a = MulArgs()
     a.A, a.B, a.lda, a.ldb, a.ldc, a.m, a.l, a.n, a.batch, a.ksplit = A.data_ptr(), B.data_ptr(), lda, ldb, ldb, m, l, n, 1, 1
     a.C = torch.zeros((m, ldb), dtype=torch.int64, device="cuda").data_ptr()
-    for cfg in (0, 1, 80, 50, 40, 41, 42, 43, 44, 45, 49, 83, 84, 85, 86, 87, 88, 89, 92, 93, 94, 95, 96):
+    for cfg in (0, 1, 80, 50, 40, 41, 42, 43, 44, 45, 49, 83, 84, 85, 86, 87, 88, 89, 90, 92, 93, 94, 95, 96):
         assert lib.gf2k_m4rm(a, cfg, None) != 0, cfg
     torch.cuda.synchronize()

@@ -254,11 +254,26 @@ def test_workspace_and_level_queries_without_gpu(pkg):
     assert lib.gf2_strassen_levels(65536, 65536, 65536, M4RM, 0) == 0
     assert lib.gf2_strassen_levels(1000, 1000, 1000, AUTO, 0) == 0
     arena = lib.gf2_mul_workspace_bytes(65536, 65536, 65536, AUTO, 0)
-    # 4 levels = three fused + one virtual: 3 x 2401 leaves of 2 MiB + the seven 128 MiB level-1 products = 14.9 GiB
-    assert arena == 8 * (3 * 2401 * 4096 * 64 + 7 * 32768 * 512)
-    assert lib.gf2_mul_workspace_bytes(65536, 65536, 65536, M4RM, 0) == 65536 * 1024 * 8   # packed copy of A, same footprint
-    assert lib.gf2_mul_workspace_bytes(1000, 1000, 1000, M4RM, 0) == 0
-    assert lib.gf2_mul_workspace_bytes(2049, 70, 1024, M4RM, 0) == 2112 * 2 * 8             # rows padded to 64, even word count
+    # 4 levels = three fused + one virtual: 3 x 2401 leaves of 2 MiB + the seven 128 MiB level-1 products = 14.9 GiB,
+    # plus the partial tiles of the leaf launch's last round (2401 x 8 = 19208 tiles = 75 rounds of 256 and 8 tiles, which
+    # are cut into 256 stream-K segments with two 256 KiB slots each)
+    plan = (ctypes.c_longlong * 9)()
+    assert lib.gf2_tile_plan(4096, 4096, 4096, 2401, 1, plan) > 0
+    # 2401 x 8 = 19208 tiles = 75 rounds of 256 and 8 tiles: the last product (its 8 tiles) goes into a launch of its own with
+    # short tiles, every one of them cut into segments
+    assert list(plan)[:4] == [9, 1, 0, 0] and plan[5] == 1 and plan[6] in (10, 11, 12) and plan[8] == 256 and plan[4] > 0
+    assert arena == 8 * (3 * 2401 * 4096 * 64 + 7 * 32768 * 512) + plan[4]
+    # plain M4RM at the same size: packed copy of A (same footprint as A); 16 x 128 tiles are 8 full rounds, nothing is cut
+    assert lib.gf2_mul_workspace_bytes(65536, 65536, 65536, M4RM, 0) == 65536 * 1024 * 8
+    # config 2 (4096^3, M4RM only): fewer than 256 tiles whatever the tile height, so every tile is cut into segments
+    assert lib.gf2_tile_plan(4096, 4096, 4096, 1, 0, plan) > 0
+    assert plan[0] in (10, 11, 12) and plan[2] == (4096 // {10: 2048, 11: 1024, 12: 512}[plan[0]]) * 8 and plan[3] == 256
+    assert lib.gf2_mul_workspace_bytes(1000, 1000, 1000, M4RM, 0) <= (16 << 20)
+    # a packed copy of A is staged only when the model says the contiguous loads repay the pass: rows padded to 64, even word count
+    ws = lib.gf2_mul_workspace_bytes(2049, 70, 1024, M4RM, 0)
+    t_unpacked, t_packed = lib.gf2_tile_plan(2049, 70, 1024, 1, 0, plan), lib.gf2_tile_plan(2049, 70, 1024, 1, 1, plan)
+    assert ws in (0, 2112 * 2 * 8) or ws >= plan[4]
+    assert (ws == 0) == (t_unpacked <= t_packed + 2.5e-6) or ws > 0
 
 
 def test_product_opt_k_follows_graycode_rs(built):

@@ -1,5 +1,7 @@
 // kbench -- kernel micro-benchmark for the M4RM tile kernel variants (development tool, not shipped).
-//   kbench <n> <batch> <reps> <cfg> [<cfg> ...]
+//   kbench <n> <batch> <reps> <cfg> [<cfg> ...]          (n may be m,l,n)
+// env: APACK=1 (row-group-packed A for the variants that read it), KSPLIT=k (uniform split-K), NREM=r NSEG=s (stream-K split of the
+// v8 family, cfg 9-12: the last r tiles cut into s segments; NREM=-1: all tiles; NREM=-2: the tiles of the last incomplete round)
 // Runs each variant on `batch` independent n x n x n products of seeded random bits, checks every variant's
 // output bit for bit against cfg 0, prints avg kernel time (HIP events) and derived rates.
 #include <hip/hip_runtime.h>
@@ -14,7 +16,8 @@
 
 int main(int argc, char **argv) {
   if (argc < 5) { fprintf(stderr, "usage: kbench n batch reps cfg...\n"); return 2; }
-  const int n = atoi(argv[1]), batch = atoi(argv[2]), reps = atoi(argv[3]);
+  int n = atoi(argv[1]);
+  const int batch = atoi(argv[2]), reps = atoi(argv[3]);
   const long long ld = n / 64, words = (long long)n * ld;
   uint64_t *A, *B, *C, *Cref;
   CK(hipMalloc(&A, words * 8 * batch)); CK(hipMalloc(&B, words * 8 * batch));
@@ -24,6 +27,10 @@ int main(int argc, char **argv) {
   int *diff; CK(hipMalloc(&diff, 4));
   gf2k_mul_args a{};
   a.A = A; a.B = B; a.lda = a.ldb = a.ldc = ld; a.sA = a.sB = a.sC = words; a.m = a.l = a.n = n; a.batch = batch; a.ksplit = getenv("KSPLIT") ? atoi(getenv("KSPLIT")) : 1;
+  const int nrem_env = getenv("NREM") ? atoi(getenv("NREM")) : 0, nseg_env = getenv("NSEG") ? atoi(getenv("NSEG")) : 0;
+  uint64_t *Pws = nullptr;
+  const long long pws_words = 2ll * 4096 * 4096 * 8;  // room for 4096 segments of the tallest tile (1 GiB)
+  if (nrem_env || a.ksplit > 1) CK(hipMalloc(&Pws, pws_words * 8));
   // chunk-packed copy of B for the BPACK kernel variants
   const int nc = gf2k_packB_chunks(n), tiles_n = (n + 2047) / 2048;
   const long long bpBlocks = (long long)tiles_n * nc;
@@ -42,7 +49,14 @@ int main(int argc, char **argv) {
   for (int i = 4; i < argc; ++i) {
     const int cfg = atoi(argv[i]);
     a.C = C;
-    const bool pk = Apk && (cfg == 8 || cfg == 9 || (cfg >= 90 && cfg < 100));
+    const bool pk = Apk && (cfg == 8 || (cfg >= 9 && cfg <= 12) || (cfg >= 90 && cfg < 100));
+    a.P = nullptr; a.p_words = 0; a.n_rem = a.nseg = 0;
+    if (cfg >= 9 && cfg <= 12 && Pws) {
+      const long long T = (long long)((n + gf2k_m4rm_rows_per_tile(cfg) - 1) / gf2k_m4rm_rows_per_tile(cfg)) * ((n + 511) / 512) * batch;
+      a.P = Pws; a.p_words = pws_words;
+      a.n_rem = nrem_env == -1 ? (int)T : nrem_env == -2 ? (int)(T < 256 ? T : T % 256) : nrem_env;
+      a.nseg = nseg_env;
+    }
     if (cfg == 96) CK(hipMemset(Bp, 0, (size_t)bpBlocks * 2048 * batch));
     a.A = pk ? Apk : A;
     a.a_packed = pk ? 1 : 0;

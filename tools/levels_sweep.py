@@ -22,13 +22,13 @@ for (m, l, n) in shapes:
         for _ in range(2):
             device.mul(A, B, C=C, algo=algo, param=L)
         torch.cuda.synchronize()
-        reps = 3 if m * l * n > 1e13 else 10
+        reps = 3 if m * l * n > 1e13 else 20
         t0 = time.perf_counter()
         for _ in range(reps):
             device.mul(A, B, C=C, algo=algo, param=L)
         torch.cuda.synchronize()
-        res.append((L, (time.perf_counter() - t0) / reps * 1e3))
+        res.append((L, (time.perf_counter() - t0) / reps * 1e3, device._lib.lib().gf2_model_time(m, l, n, L) * 1e3))
     auto = sharded.levels_used(m, l, n, "auto", 0)
     best = min(res, key=lambda x: x[1])
-    print(f"{m}x{l}x{n}: " + "  ".join(f"L{L}={t:.3f}ms" for L, t in res) + f"   auto={auto} best={best[0]}")
+    print(f"{m}x{l}x{n}: " + "  ".join(f"L{L}={t:.3f}ms (model {mt:.3f})" for L, t, mt in res) + f"   auto={auto} best={best[0]}", flush=True)
     del A, B, C
