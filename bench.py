@@ -431,8 +431,9 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            # v7 on row-group-packed A (>= 2 Strassen levels, or a packed plain product), v6 / v3 otherwise
-            "kernel": "M4RM tile kernel gf2_m4rm_kernel_v7/_v6 (batch of %d leaf products %dx%dx%d)" % (batch, mi, li, ni),
+            # v8 (4096 x 512 tiles) on row-group-packed A for tall leaves; the launcher picks tile height / variant by shape
+            "kernel": "M4RM tile kernel gf2_m4rm_kernel_v8 (batch of %d leaf products %dx%dx%d; the products of the last, incomplete "
+                      "round of 256 tiles run in a second launch with shorter tiles cut into stream-K segments)" % (batch, mi, li, ni),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "frac_of_measured_copy": achieved / HBM_COPY_GBS,

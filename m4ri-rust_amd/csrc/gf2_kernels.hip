@@ -2100,18 +2100,36 @@ __global__ __launch_bounds__(256) void gf2_xor2d_kernel(u64 *__restrict__ C, lon
 
 // dst (drows x dwords words, dense) = src (srows x swords) in its top left corner, zeros elsewhere: operands padded up to
 // dimensions that divide by the Strassen level plan (m4ri_hip_api.cpp, mul_strassen_padded)
+// dst (drows x dwords, zero padded) <- src (srows x swords); 16-byte accesses where both rows allow them (ldd, lds_ even and
+// 16-byte aligned bases: `vec`), one block row per blockIdx.y step (no division in the loop)
 __global__ __launch_bounds__(256) void gf2_padcopy_kernel(u64 *__restrict__ dst, long long ldd, int drows, int dwords,
-                                                          const u64 *__restrict__ src, long long lds_, int srows, int swords) {
-  const long long total = (long long)drows * dwords;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int r = (int)(idx / dwords), w = (int)(idx % dwords);
-    dst[(long long)r * ldd + w] = (r < srows && w < swords) ? src[(long long)r * lds_ + w] : 0;
+                                                          const u64 *__restrict__ src, long long lds_, int srows, int swords, int vec) {
+  const int pairs = (dwords + 1) >> 1;
+  for (int r = blockIdx.y; r < drows; r += gridDim.y) {
+    u64 *d = dst + (long long)r * ldd;
+    const u64 *sr = src + (long long)r * lds_;
+    const bool live = r < srows;
+    for (int pr = blockIdx.x * blockDim.x + threadIdx.x; pr < pairs; pr += gridDim.x * blockDim.x) {
+      const int w = 2 * pr;
+      u64 v0 = 0, v1 = 0;
+      if (live && w + 1 < swords && vec) {
+        const uint4 t = *reinterpret_cast<const uint4 *>(sr + w);
+        v0 = (u64)t.x | ((u64)t.y << 32);
+        v1 = (u64)t.z | ((u64)t.w << 32);
+      } else if (live) {
+        if (w < swords) v0 = sr[w];
+        if (w + 1 < swords) v1 = sr[w + 1];
+      }
+      if (w + 1 < dwords && vec) {
+        *reinterpret_cast<uint4 *>(d + w) = make_uint4((u32)v0, (u32)(v0 >> 32), (u32)v1, (u32)(v1 >> 32));
+      } else {
+        d[w] = v0;
+        if (w + 1 < dwords) d[w + 1] = v1;
+      }
+    }
   }
 }
 
-// splitmix64 counter stream, identical to oracle_fill_random (test/bench input generator;
-// stands in for mzd_randomize, mzd.rs:183-184)
-// M holds rows [row0, row0+rows) x words [colw0, colw0 + ceil(cols/64)) of a seeded matrix that is `fullw` words wide
 __global__ __launch_bounds__(256) void gf2_fill_random_kernel(u64 *M, long long ld, int rows, int cols, u64 seed,
                                                               long long row0, long long fullw, long long colw0) {
   const int w = (cols + 63) >> 6;
@@ -3022,9 +3040,10 @@ extern "C" hipError_t gf2k_xor2d(u64 *C, long long ldc, const u64 *A, long long 
 extern "C" hipError_t gf2k_padcopy(u64 *dst, long long ldd, int drows, int dwords, const u64 *src, long long lds_, int srows,
                                    int swords, hipStream_t stream) {
   if (drows <= 0 || dwords <= 0) return hipSuccess;
-  const long long total = (long long)drows * dwords;
-  hipLaunchKernelGGL(gf2_padcopy_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, stream, dst, ldd, drows, dwords, src, lds_,
-                     srows, swords);
+  const int vec = !((ldd | lds_) & 1) && !(((uintptr_t)dst | (uintptr_t)src) & 15);
+  const int pairs = (dwords + 1) >> 1;
+  const unsigned gx = (unsigned)std::min(8, (pairs + 255) / 256), gy = (unsigned)std::min(drows, 65535);
+  hipLaunchKernelGGL(gf2_padcopy_kernel, dim3(gx, gy), dim3(256), 0, stream, dst, ldd, drows, dwords, src, lds_, srows, swords, vec);
   return hipGetLastError();
 }
 

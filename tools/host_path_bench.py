@@ -8,7 +8,8 @@ import m4ri_rust_amd as pkg
 from m4ri_rust_amd import device
 device.require_gpu()
 L = pkg._lib.lib()
-for n in (4096, 16384, 32768, 65536):
+sizes = [int(x) for x in sys.argv[1:]] or [4096, 16384, 32768, 65536]
+for n in sizes:
     A, B = pkg.BinMatrix.random(n, n), pkg.BinMatrix.random(n, n)
     c = L.mzd_mul(None, A.mzd, B.mzd, 0); L.mzd_free(c)
     reps = 3
@@ -25,7 +26,7 @@ for n in (4096, 16384, 32768, 65536):
     print(f"n={n}: mzd_mul(NULL,..) {dt*1e3:.1f} ms  preallocated C {dt2*1e3:.1f} ms  -> {2*n**3/dt2/1e12:.1f} Tbit-ops/s end to end; bytes moved {3*n*n/8/1e6:.0f} MB")
 
 import time as _t
-for n in (16384, 65536):
+for n in ([] if len(sys.argv) > 1 else [16384, 65536]):
     A = pkg.BinMatrix.random(n, n)
     T = A.transposed()
     t0 = _t.perf_counter(); T = A.transposed(); dt = _t.perf_counter() - t0
