@@ -350,7 +350,7 @@ def main():
     rank_info = None
     if world > 1:
         mine = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(),
-                "name": torch.cuda.get_device_name(torch.cuda.current_device()), "ms": dt_local * 1e3}
+                "name": torch.cuda.get_device_name(torch.cuda.current_device()), "timed_region_ms": dt_local * 1e3}
         rank_info = [None] * world
         dist.all_gather_object(rank_info, mine)
     if rank != 0:

@@ -2894,7 +2894,8 @@ extern "C" hipError_t gf2k_tallskinny(const u64 *A, long long lda, const u64 *B,
   if (l <= 256 && !old_only && (ts6 & (nw == 3 ? 4 : nw))) {
     const int vec_ok = l > 192 && (lda & 1) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
     long long blocks = ((long long)m + 255) / 256;
-    const long long cap = nw <= 2 ? 2048 : 1024;  // 8 (4) workgroups per CU
+    static const int cap_env = getenv("M4RI_HIP_TS6_BLOCKS") ? atoi(getenv("M4RI_HIP_TS6_BLOCKS")) : 0;  // (A/B measurements)
+    const long long cap = cap_env > 0 ? cap_env : (nw <= 2 ? 2048 : 1024);  // 8 (4) workgroups per CU
     if (blocks > cap) blocks = cap;
 #define GF2_TS6_LAUNCH(NWV)                                                                                                       \
   do {                                                                                                                            \

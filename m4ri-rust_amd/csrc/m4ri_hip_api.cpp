@@ -22,6 +22,7 @@
 #include <thread>
 #include <string>
 #include <tuple>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/m4ri_hip.h"
@@ -536,7 +537,34 @@ static bool older_model(int m, int l, int n, int batch, bool packed, int cfg, Ti
   return true;
 }
 
+static TilePlan plan_tiles_uncached(int m, int l, int n, int batch, bool packed, bool allow_tail);
+// Planning is pure arithmetic on the shape (and the environment, read once), but a level choice evaluates dozens of candidate
+// launches: 15-55 us of host time per product, which a 0.2 ms product notices.  Every thread keeps what it has planned.
+struct PlanKey {
+  int m, l, n, batch, flags;
+  bool operator==(const PlanKey &o) const { return m == o.m && l == o.l && n == o.n && batch == o.batch && flags == o.flags; }
+};
+struct PlanKeyHash {
+  size_t operator()(const PlanKey &k) const {
+    size_t h = (size_t)k.m * 0x9E3779B97F4A7C15ull;
+    h ^= ((size_t)k.l + 0x7F4A7C15u) * 0xC2B2AE3D27D4EB4Full + (h << 6) + (h >> 2);
+    h ^= ((size_t)k.n + 0x165667B1u) * 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+    h ^= ((size_t)k.batch * 31 + (size_t)k.flags) * 0xC2B2AE3D27D4EB4Full + (h << 6) + (h >> 2);
+    return h;
+  }
+};
 static TilePlan plan_tiles(int m, int l, int n, int batch, bool packed, bool allow_tail = true) {
+  thread_local std::unordered_map<PlanKey, TilePlan, PlanKeyHash> memo;
+  const PlanKey key{m, l, n, batch, (packed ? 1 : 0) | (allow_tail ? 2 : 0)};
+  auto it = memo.find(key);
+  if (it != memo.end()) return it->second;
+  if (memo.size() > 8192) memo.clear();
+  const TilePlan tp = plan_tiles_uncached(m, l, n, batch, packed, allow_tail);
+  memo.emplace(key, tp);
+  return tp;
+}
+
+static TilePlan plan_tiles_uncached(int m, int l, int n, int batch, bool packed, bool allow_tail) {
   // A/B override, restricted to variants that compute the product (the timing-only ablations exist only in development
   // builds of the kernels and would be hipErrorInvalidValue here anyway)
   static const int forced = [] {
@@ -614,6 +642,9 @@ static double leaf_time_model(int m, int l, int n, int batch, bool may_pack) {
   const double t = m4rm_time_model(m, l, n, batch, false);
   return may_pack ? std::min(t, m4rm_time_model(m, l, n, batch, true)) : t;
 }
+// fixed cost of the packing pass of a plain product: its launch and the dependent-kernel boundary behind it (4.8 us measured for
+// the 2 MiB of a 4096^2 operand, profiles/r03_config2_kernel_stats.csv, of which 0.8 us are the bytes)
+static const double kPackLaunch = 5.0e-6;
 // ... of a plain product, which may pack A itself first (mul_m4rm_plain makes the same comparison)
 static double plain_time_model(int m, int l, int n) {
   static const double bw = (double)env_int("M4RI_HIP_STREAM_GBS", 5000) * 1e9;
@@ -622,7 +653,7 @@ static double plain_time_model(int m, int l, int n) {
   const long long wp = (words_of(l) + 1) & ~1ll, prow = ((long long)m + 63) & ~63ll;
   if (plain_pack && m >= 512 && prow * wp * 8 < (1ll << 32)) {
     const TilePlan pk = plan_tiles(m, l, n, 1, true);
-    if (cfg_reads_packed(pk.cfg)) t = std::min(t, pk.t + 2.0 * (double)prow * (double)wp * 8.0 / bw + 2.5e-6);
+    if (cfg_reads_packed(pk.cfg)) t = std::min(t, pk.t + 2.0 * (double)prow * (double)wp * 8.0 / bw + kPackLaunch);
   }
   return t;
 }
@@ -658,7 +689,7 @@ static TilePlan plain_plan(int m, int l, int n, bool *pack) {
   const long long wp = (words_of(l) + 1) & ~1ll, prow = ((long long)m + 63) & ~63ll;
   if (plain_pack && m >= 512 && prow * wp * 8 < (1ll << 32)) {
     const TilePlan pk = plan_tiles(m, l, n, 1, true);
-    if (cfg_reads_packed(pk.cfg) && pk.t + 2.0 * (double)prow * (double)wp * 8.0 / bw + 2.5e-6 < tp.t) tp = pk, *pack = true;
+    if (cfg_reads_packed(pk.cfg) && pk.t + 2.0 * (double)prow * (double)wp * 8.0 / bw + kPackLaunch < tp.t) tp = pk, *pack = true;
   }
   return tp;
 }
@@ -768,7 +799,25 @@ static double level_time_model(int m, int l, int n, int L) {
 }
 extern "C" double gf2_model_time(int m, int l, int n, int levels) { return level_time_model(m, l, n, levels); }
 
+static int pick_levels_uncached(int m, int l, int n, int req, int leaf_min, double *t_out);
 static int pick_levels(int m, int l, int n, int req, int leaf_min, double *t_out = nullptr) {
+  struct Res {
+    int L;
+    double t;
+  };
+  thread_local std::unordered_map<PlanKey, Res, PlanKeyHash> memo;
+  const PlanKey key{m, l, n, req, leaf_min * 2 + (env_int("M4RI_HIP_STRASSEN_FUSE3", 1) ? 1 : 0)};  // (the tests switch level plans)
+  auto it = memo.find(key);
+  if (it == memo.end()) {
+    if (memo.size() > 8192) memo.clear();
+    Res r{0, 0.0};
+    r.L = pick_levels_uncached(m, l, n, req, leaf_min, &r.t);
+    it = memo.emplace(key, r).first;
+  }
+  if (t_out) *t_out = it->second.t;
+  return it->second.L;
+}
+static int pick_levels_uncached(int m, int l, int n, int req, int leaf_min, double *t_out) {
   static const int max_auto = env_int("M4RI_HIP_STRASSEN_MAX_LEVELS", 5);
   const int cap = req > 0 ? (req > 6 ? 6 : req) : max_auto;
   int best = 0;
@@ -1030,7 +1079,18 @@ static double strip_model(int m, int l, int n, int leaf_min) {
   return t + 3e-6;
 }
 
+static ShapePlan plan_shape_uncached(int m, int l, int n, int req, int leaf_min);
 static ShapePlan plan_shape(int m, int l, int n, int req, int leaf_min) {
+  thread_local std::unordered_map<PlanKey, ShapePlan, PlanKeyHash> memo;
+  const PlanKey key{m, l, n, req, leaf_min * 2 + (env_int("M4RI_HIP_STRASSEN_FUSE3", 1) ? 1 : 0)};
+  auto it = memo.find(key);
+  if (it != memo.end()) return it->second;
+  if (memo.size() > 8192) memo.clear();
+  const ShapePlan sp = plan_shape_uncached(m, l, n, req, leaf_min);
+  memo.emplace(key, sp);
+  return sp;
+}
+static ShapePlan plan_shape_uncached(int m, int l, int n, int req, int leaf_min) {
   static const double bw = (double)env_int("M4RI_HIP_STREAM_GBS", 5000) * 1e9;
   static const int max_auto = env_int("M4RI_HIP_STRASSEN_MAX_LEVELS", 5);
   static const int debug = env_int("M4RI_HIP_DEBUG_PLAN", 0);
