@@ -218,9 +218,10 @@ size_t gf2_mul_workspace_bytes(int m, int l, int n, int algo, int param);
  * link, multiplies and downloads its rows of C; the inner dimension is never split, so there is no reduction.  C NULL:
  * allocated.  Returns C, or NULL on failure.  algo / param as gf2_mul_dev.
  * The drop-in entry points (mzd_mul, mzd_mul_m4rm, mzd_mul_naive, strassen.rs:18 / brilliantrussian.rs:216 / mzd.rs:152) do
- * the same by themselves when more than one device is visible and the product is large (>= 7e13 bit operations, >= 4096
- * rows per share); M4RI_HIP_DEVICES = "auto" (default) | "all" | "0,1,..." overrides (a single ordinal pins the product to
- * that device). */
+ * the same by themselves when asked to: M4RI_HIP_DEVICES = "auto" (more than one device visible and the product large: >= 7e13
+ * bit operations, >= 4096 rows per share; ignored when WORLD_SIZE > 1, i.e. inside a torch.distributed job) | "all" | "0,1,...".
+ * Unset: the current device only.  A single ordinal pins every host entry point (products, elimination, transpose, operand
+ * cache) to that device. */
 mzd_t *gf2_mul_multi(mzd_t *C, mzd_t const *A, mzd_t const *B, int algo, int param, const int *devices, int ndev);
 
 /* Operand cache for the drop-in entry points: keep a device copy of the host matrix M until gf2_mzd_uncache(M) or
