@@ -849,6 +849,10 @@ __global__ __launch_bounds__(512) void gf2_m4rm_kernel_v8(const gf2k_mul_args p)
     }
   }
   const int nparts = rest > 0 ? 2 : 1;
+#ifdef GF2K_DEV_VARIANTS
+  if ((p.kwords & 1) && wave >= 4) __builtin_amdgcn_s_setprio(1);  // static priority for the later-dispatched half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+  if ((p.kwords & 2) && wave < 4) __builtin_amdgcn_s_setprio(1);
+#endif
 
   const int l3 = lane & 3, cl = (lane >> 2) & 3;
   // lo[c >> 1][k]: byte 0 = slot offset of read c even, byte 1 = of read c odd, byte 2 = 0, byte 3 = 1 (table select)
@@ -860,12 +864,11 @@ __global__ __launch_bounds__(512) void gf2_m4rm_kernel_v8(const gf2k_mul_args p)
       const u32 s0 = (u32)((((2 * c2) ^ cl) * 4 + (k ^ l3)) * 16), s1 = (u32)((((2 * c2 + 1) ^ cl) * 4 + (k ^ l3)) * 16);
       lo[c2][k] = s0 | (s1 << 8) | 0x01000000u;
     }
-  // sel[W][c] = {0, table byte of lo (2 + W), byte c ^ cl of the A word, slot byte c & 1 of lo}
-  u32 sel[2][4];
+  // sel[c] = {0, table byte of lo (2: table 0; the second table's selector is sel[c] + 0x10000, formed where it is used so that it
+  // does not occupy four more registers), byte c ^ cl of the A word, slot byte c & 1 of lo}
+  u32 sel[4];
 #pragma unroll
-  for (int w = 0; w < 2; ++w)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) sel[w][c] = 0x0c000000u | ((2u + (u32)w) << 16) | ((4u + (u32)(c ^ cl)) << 8) | (u32)(c & 1);
+  for (int c = 0; c < 4; ++c) sel[c] = 0x0c000000u | (2u << 16) | ((4u + (u32)(c ^ cl)) << 8) | (u32)(c & 1);
 
   const int widthB = (p.n + 63) >> 6;
   const u64 maskC = (p.n & 63) ? ((1ull << (p.n & 63)) - 1) : ~0ull;
@@ -974,7 +977,10 @@ __global__ __launch_bounds__(512) void gf2_m4rm_kernel_v8(const gf2k_mul_args p)
 #pragma unroll
         for (int k = 0; k < 4; ++k) lk[c2][k] = lo[c2][k];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) sk[c] = sel[W][c];
+      for (int c = 0; c < 4; ++c) {
+        if constexpr (W == 0) sk[c] = sel[c];
+        else asm volatile("v_add_u32 %0, %1, %2" : "=v"(sk[c]) : "v"(sel[c]), "s"(0x10000u));
+      }
       using tnext = std::integral_constant<u32, W ? 0u : (u32)kTableBytes>;
       build_begin(rows, tnext::value);
       const __amdgpu_buffer_rsrc_t rsN = rsrcB_for(q + NB);
@@ -2635,7 +2641,13 @@ static inline int grid_for(long long total, int block = 256, int cap = 256 * 8) 
 }
 
 // variants: 9 / 10 / 11 / 12 = v8 with 4096 / 2048 / 1024 / 512-row tiles (512 columns); 8x = v6; 90-99 = the legacy v7 (development builds)
-static int cfg_v8_rg(int cfg) { return cfg == 9 ? 8 : cfg == 10 ? 4 : cfg == 11 ? 2 : cfg == 12 ? 1 : 0; }
+static int cfg_v8_rg(int cfg) {
+#ifdef GF2K_DEV_VARIANTS
+  if (cfg >= 13 && cfg <= 16) return 8 >> (cfg - 13);  // read window of three steps (kbench A/B)
+  if (cfg >= 17 && cfg <= 19) return 8 >> (cfg - 17);  // read window of one step
+#endif
+  return cfg == 9 ? 8 : cfg == 10 ? 4 : cfg == 11 ? 2 : cfg == 12 ? 1 : 0;
+}
 static bool cfg_is_v7(int cfg) { return cfg_v8_rg(cfg) > 0 || (cfg >= 90 && cfg < 100); }
 static bool cfg_is_v56(int cfg) { return cfg == 8 || (cfg >= 80 && cfg < 90); }
 extern "C" int gf2k_m4rm_rows_per_tile(int cfg) {
@@ -2687,6 +2699,10 @@ static hipError_t launch_v8(gf2k_mul_args a, int cfg, int RG, hipStream_t stream
   if (a.ksplit > 1 && a.n_rem <= 0) a.n_rem = (int)T, a.nseg = (int)std::min<long long>(T * a.ksplit, 1 << 20);
   a.ksplit = 1;
   a.kwords = 0;
+#ifdef GF2K_DEV_VARIANTS
+  static const int v8_flags = getenv("GF2K_V8_FLAGS") ? atoi(getenv("GF2K_V8_FLAGS")) : 0;  // kbench A/B: 1 = s_setprio 1 for waves 4-7
+  a.kwords = v8_flags;
+#endif
   long long n_rem = a.P && Q > 0 ? std::min<long long>(std::max(a.n_rem, 0), T) : 0;
   int nseg = 0, seg = 0;
   if (n_rem > 0) {
@@ -2710,9 +2726,26 @@ static hipError_t launch_v8(gf2k_mul_args a, int cfg, int RG, hipStream_t stream
   const long long nwg = (long long)a.n_full + nseg;
   if (nwg <= 0) return hipSuccess;
   hipError_t e = hipErrorInvalidValue;
-#define GF2K_V8(RGv)                                                                                   \
-  e = a.a_packed ? launch_tile_kernel(&gf2_m4rm_kernel_v8<RGv, 2, 1>, 512, a, nwg, stream)             \
-                 : launch_tile_kernel(&gf2_m4rm_kernel_v8<RGv, 2, 0>, 512, a, nwg, stream)
+#define GF2K_V8G(RGv, Gv)                                                                              \
+  e = a.a_packed ? launch_tile_kernel(&gf2_m4rm_kernel_v8<RGv, Gv, 1>, 512, a, nwg, stream)            \
+                 : launch_tile_kernel(&gf2_m4rm_kernel_v8<RGv, Gv, 0>, 512, a, nwg, stream)
+#define GF2K_V8(RGv) GF2K_V8G(RGv, 2)
+#ifdef GF2K_DEV_VARIANTS
+  if (cfg >= 13 && cfg <= 16) {
+    switch (RG) {
+      case 8: GF2K_V8G(8, 3); break;
+      case 4: GF2K_V8G(4, 3); break;
+      case 2: GF2K_V8G(2, 3); break;
+      default: GF2K_V8G(1, 3); break;
+    }
+  } else if (cfg >= 17 && cfg <= 19) {
+    switch (RG) {
+      case 8: GF2K_V8G(8, 1); break;
+      case 4: GF2K_V8G(4, 1); break;
+      default: GF2K_V8G(2, 1); break;
+    }
+  } else
+#endif
   switch (RG) {
     case 8: GF2K_V8(8); break;
     case 4: GF2K_V8(4); break;
@@ -2720,6 +2753,7 @@ static hipError_t launch_v8(gf2k_mul_args a, int cfg, int RG, hipStream_t stream
     default: GF2K_V8(1); break;
   }
 #undef GF2K_V8
+#undef GF2K_V8G
   if (e != hipSuccess || n_rem == 0) return e;
   hipLaunchKernelGGL(gf2_streamk_reduce_kernel, dim3((unsigned)(n_rem * (R / 64))), dim3(256), 0, stream, a, RG);
   return hipGetLastError();
