@@ -1164,6 +1164,9 @@ __global__ __launch_bounds__(256) void gf2_streamk_reduce_kernel(const gf2k_mul_
 }
 
 #ifdef GF2K_DEV_VARIANTS
+#include "../../tools/gf2_kernels_v9_experiment.inc"  // tall, narrow tiles (4096 x 128): measured, not adopted
+#endif
+#ifdef GF2K_DEV_VARIANTS
 #include "../../tools/gf2_kernels_legacy_v7.inc"  // the fixed-tile predecessor with its ablation branches, kbench only
 #endif
 
@@ -2640,7 +2643,8 @@ static inline int grid_for(long long total, int block = 256, int cap = 256 * 8) 
   return (int)g;
 }
 
-// variants: 9 / 10 / 11 / 12 = v8 with 4096 / 2048 / 1024 / 512-row tiles (512 columns); 8x = v6; 90-99 = the legacy v7 (development builds)
+// variants: 9 / 10 / 11 / 12 = v8 with 4096 / 2048 / 1024 / 512-row tiles (512 columns); 21 / 22 / 23 = v9 with 4096 / 2048 / 1024-row
+// tiles of 128 columns; 8x = v6; 90-99 = the legacy v7 (development builds)
 static int cfg_v8_rg(int cfg) {
 #ifdef GF2K_DEV_VARIANTS
   if (cfg >= 13 && cfg <= 16) return 8 >> (cfg - 13);  // read window of three steps (kbench A/B)
@@ -2648,14 +2652,24 @@ static int cfg_v8_rg(int cfg) {
 #endif
   return cfg == 9 ? 8 : cfg == 10 ? 4 : cfg == 11 ? 2 : cfg == 12 ? 1 : 0;
 }
+static int cfg_v9_rg(int cfg) {  // the tall-narrow experiment (tools/gf2_kernels_v9_experiment.inc): development builds only
+#ifdef GF2K_DEV_VARIANTS
+  return cfg == 21 ? 8 : cfg == 22 ? 4 : cfg == 23 ? 2 : 0;
+#else
+  (void)cfg;
+  return 0;
+#endif
+}
 static bool cfg_is_v7(int cfg) { return cfg_v8_rg(cfg) > 0 || (cfg >= 90 && cfg < 100); }
 static bool cfg_is_v56(int cfg) { return cfg == 8 || (cfg >= 80 && cfg < 90); }
 extern "C" int gf2k_m4rm_rows_per_tile(int cfg) {
   if (cfg_v8_rg(cfg)) return 512 * cfg_v8_rg(cfg);
+  if (cfg_v9_rg(cfg)) return 512 * cfg_v9_rg(cfg);
   return (cfg == 1 || cfg == 20) ? 256 : cfg_is_v7(cfg) ? 4096 : cfg_is_v56(cfg) ? 2048 : 1024;
 }
-extern "C" int gf2k_m4rm_cols_per_tile(int cfg) { return cfg_is_v7(cfg) ? 512 : cfg_is_v56(cfg) ? 1024 : 2048; }
+extern "C" int gf2k_m4rm_cols_per_tile(int cfg) { return cfg_v9_rg(cfg) ? 128 : cfg_is_v7(cfg) ? 512 : cfg_is_v56(cfg) ? 1024 : 2048; }
 extern "C" long long gf2k_m4rm_streamk_words(int cfg, int nseg) {
+  if (cfg_v9_rg(cfg)) return 2ll * nseg * 512 * cfg_v9_rg(cfg) * 2;
   return cfg_v8_rg(cfg) ? 2ll * nseg * 512 * cfg_v8_rg(cfg) * 8 : 0;
 }
 
@@ -2686,14 +2700,15 @@ static hipError_t launch_tile_kernel(K kernel, int threads, const gf2k_mul_args 
   return e;
 }
 
-// v8 (cfg 9-12): tiles, the stream-K split the caller asked for, the tile kernel, the reduction of the partial tiles
+// v8 (cfg 9-12) and v9 (cfg 21-23): tiles, the stream-K split the caller asked for, the tile kernel, the reduction of the partial tiles
 static hipError_t launch_v8(gf2k_mul_args a, int cfg, int RG, hipStream_t stream) {
-  const int R = 512 * RG;
+  const bool v9 = cfg_v9_rg(cfg) != 0;
+  const int R = 512 * RG, TC = v9 ? 128 : 512;
   a.tiles_m = (a.m + R - 1) / R;
-  a.tiles_n = (a.n + 511) / 512;
+  a.tiles_n = (a.n + TC - 1) / TC;
   const long long T = (long long)a.tiles_m * a.tiles_n * a.batch;
   if (T > 0x7fffff00LL) return hipErrorInvalidValue;
-  const int nw32 = (a.l + 31) / 32, Q = (nw32 + 1) / 2;
+  const int nw32 = (a.l + 31) / 32, Q = v9 ? (nw32 + 3) / 4 : (nw32 + 1) / 2;  // units of the inner dimension: 128 / 64 bits
   a.tile_slabs = Q;
   // the uniform split-K of the older kernels, expressed as a stream-K split of all tiles
   if (a.ksplit > 1 && a.n_rem <= 0) a.n_rem = (int)T, a.nseg = (int)std::min<long long>(T * a.ksplit, 1 << 20);
@@ -2722,7 +2737,7 @@ static hipError_t launch_v8(gf2k_mul_args a, int cfg, int RG, hipStream_t stream
   a.nseg = nseg;
   a.seg_slabs = seg;
   a.n_full = (int)(T - n_rem);
-  a.sP = (long long)R * 8;
+  a.sP = (long long)R * (v9 ? 2 : 8);
   const long long nwg = (long long)a.n_full + nseg;
   if (nwg <= 0) return hipSuccess;
   hipError_t e = hipErrorInvalidValue;
@@ -2730,8 +2745,17 @@ static hipError_t launch_v8(gf2k_mul_args a, int cfg, int RG, hipStream_t stream
   e = a.a_packed ? launch_tile_kernel(&gf2_m4rm_kernel_v8<RGv, Gv, 1>, 512, a, nwg, stream)            \
                  : launch_tile_kernel(&gf2_m4rm_kernel_v8<RGv, Gv, 0>, 512, a, nwg, stream)
 #define GF2K_V8(RGv) GF2K_V8G(RGv, 2)
+#define GF2K_V9(RGv)                                                                                   \
+  e = a.a_packed ? launch_tile_kernel(&gf2_m4rm_kernel_v9<RGv, 2, 1>, 512, a, nwg, stream)             \
+                 : launch_tile_kernel(&gf2_m4rm_kernel_v9<RGv, 2, 0>, 512, a, nwg, stream)
 #ifdef GF2K_DEV_VARIANTS
-  if (cfg >= 13 && cfg <= 16) {
+  if (v9) {
+    switch (RG) {
+      case 8: GF2K_V9(8); break;
+      case 4: GF2K_V9(4); break;
+      default: GF2K_V9(2); break;
+    }
+  } else if (cfg >= 13 && cfg <= 16) {
     switch (RG) {
       case 8: GF2K_V8G(8, 3); break;
       case 4: GF2K_V8G(4, 3); break;
@@ -2752,9 +2776,16 @@ static hipError_t launch_v8(gf2k_mul_args a, int cfg, int RG, hipStream_t stream
     case 2: GF2K_V8(2); break;
     default: GF2K_V8(1); break;
   }
+#undef GF2K_V9
 #undef GF2K_V8
 #undef GF2K_V8G
   if (e != hipSuccess || n_rem == 0) return e;
+#ifdef GF2K_DEV_VARIANTS
+  if (v9) {
+    hipLaunchKernelGGL(gf2_streamk_reduce9_kernel, dim3((unsigned)(n_rem * (R / 256))), dim3(256), 0, stream, a, RG);
+    return hipGetLastError();
+  }
+#endif
   hipLaunchKernelGGL(gf2_streamk_reduce_kernel, dim3((unsigned)(n_rem * (R / 64))), dim3(256), 0, stream, a, RG);
   return hipGetLastError();
 }
@@ -2765,8 +2796,9 @@ static hipError_t launch_v8(gf2k_mul_args a, int cfg, int RG, hipStream_t stream
 // with -DGF2K_DEV_VARIANTS (tools/libm4ri_hip_dev.so for tools/kbench) and is hipErrorInvalidValue in libm4ri_hip.so.
 extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {
   if (a.m <= 0 || a.n <= 0 || a.batch <= 0) return hipSuccess;
-  if (a.a_packed && cfg != 8 && !cfg_is_v7(cfg)) return hipErrorInvalidValue;  // only v6 / v7 / v8 read the packed layout
+  if (a.a_packed && cfg != 8 && !cfg_is_v7(cfg) && !cfg_v9_rg(cfg)) return hipErrorInvalidValue;  // only v6 / v7 / v8 / v9 read the packed layout
   if (const int RG = cfg_v8_rg(cfg)) return launch_v8(a, cfg, RG, stream);
+  if (const int RG = cfg_v9_rg(cfg)) return launch_v8(a, cfg, RG, stream);
   const int R = gf2k_m4rm_rows_per_tile(cfg);
   a.tiles_m = (a.m + R - 1) / R;
   const int TC = gf2k_m4rm_cols_per_tile(cfg);

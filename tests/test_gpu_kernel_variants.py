@@ -61,14 +61,16 @@ def test_tile_kernel_generations_agree(dev, m, l, n, batch):
     lib.gf2k_m4rm_streamk_words.restype = ctypes.c_longlong
     lib.gf2k_m4rm_streamk_words.argtypes = [ctypes.c_int, ctypes.c_int]
 
+    V89 = {9: (4096, 512), 10: (2048, 512), 11: (1024, 512), 12: (512, 512)}  # the v8 family: tile rows x columns
+
     def run(cfg, packed=False, ksplit=1, n_rem=0, nseg=0, accumulate=False):
         C = torch.full((batch, m, ldb), -1, dtype=torch.int64, device="cuda")
         if accumulate:
             C.copy_(C0)
         a = MulArgs()
-        if n_rem or (cfg in (9, 10, 11, 12) and ksplit > 1):  # stream-K split of the v8 family: scratch for the partial tiles
-            rows = {9: 4096, 10: 2048, 11: 1024, 12: 512}[cfg]
-            tiles = -(-m // rows) * -(-n // 512) * batch
+        if n_rem or (cfg in V89 and ksplit > 1):  # stream-K split of the v8 / v9 family: scratch for the partial tiles
+            rows, cols = V89[cfg]
+            tiles = -(-m // rows) * -(-n // cols) * batch
             want = nseg or (tiles * ksplit if not n_rem else 256)
             words = lib.gf2k_m4rm_streamk_words(cfg, want + tiles + 8)
             scratch = torch.full((words,), -1, dtype=torch.int64, device="cuda")
@@ -92,9 +94,9 @@ def test_tile_kernel_generations_agree(dev, m, l, n, batch):
     # of the next), whole tiles before them; segment counts that do not divide the slabs; accumulate form
     C0 = torch.from_numpy(g.random_words(batch * m, ldb * 64, 77).view(np.int64).reshape(batch, m, ldb)).cuda()
     c0 = C0.cpu().numpy().view(np.uint64)[:, :, :wb]
-    for cfg in (9, 10, 11, 12):
-        rows = {9: 4096, 10: 2048, 11: 1024, 12: 512}[cfg]
-        tiles = -(-m // rows) * -(-n // 512) * batch
+    for cfg in sorted(V89):
+        rows, cols = V89[cfg]
+        tiles = -(-m // rows) * -(-n // cols) * batch
         for packed in (False, True):
             for n_rem, nseg in [(tiles, 0), (tiles, tiles + 1), (max(1, tiles // 2), 7), (1, 3), (tiles, 3 * tiles + 2)]:
                 got = run(cfg, packed, 1, n_rem, nseg)
@@ -105,6 +107,6 @@ def test_tile_kernel_generations_agree(dev, m, l, n, batch):
     a = MulArgs()
     a.A, a.B, a.lda, a.ldb, a.ldc, a.m, a.l, a.n, a.batch, a.ksplit = A.data_ptr(), B.data_ptr(), lda, ldb, ldb, m, l, n, 1, 1
     a.C = torch.zeros((m, ldb), dtype=torch.int64, device="cuda").data_ptr()
-    for cfg in (0, 1, 80, 50, 40, 41, 42, 43, 44, 45, 49, 83, 84, 85, 86, 87, 88, 89, 90, 92, 93, 94, 95, 96):
+    for cfg in (0, 1, 13, 17, 21, 22, 23, 80, 50, 40, 41, 42, 43, 44, 45, 49, 83, 84, 85, 86, 87, 88, 89, 90, 92, 93, 94, 95, 96):
         assert lib.gf2k_m4rm(a, cfg, None) != 0, cfg
     torch.cuda.synchronize()

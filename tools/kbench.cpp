@@ -49,10 +49,11 @@ int main(int argc, char **argv) {
   for (int i = 4; i < argc; ++i) {
     const int cfg = atoi(argv[i]);
     a.C = C;
-    const bool pk = Apk && (cfg == 8 || (cfg >= 9 && cfg <= 12) || (cfg >= 90 && cfg < 100));
+    const bool pk = Apk && (cfg == 8 || (cfg >= 9 && cfg <= 24) || (cfg >= 90 && cfg < 100));
     a.P = nullptr; a.p_words = 0; a.n_rem = a.nseg = 0;
-    if (cfg >= 9 && cfg <= 12 && Pws) {
-      const long long T = (long long)((n + gf2k_m4rm_rows_per_tile(cfg) - 1) / gf2k_m4rm_rows_per_tile(cfg)) * ((n + 511) / 512) * batch;
+    if (cfg >= 9 && cfg <= 24 && Pws) {
+      const int tcols = gf2k_m4rm_cols_per_tile(cfg);
+      const long long T = (long long)((n + gf2k_m4rm_rows_per_tile(cfg) - 1) / gf2k_m4rm_rows_per_tile(cfg)) * ((n + tcols - 1) / tcols) * batch;
       a.P = Pws; a.p_words = pws_words;
       a.n_rem = nrem_env == -1 ? (int)T : nrem_env == -2 ? (int)(T < 256 ? T : T % 256) : nrem_env;
       a.nseg = nseg_env;
