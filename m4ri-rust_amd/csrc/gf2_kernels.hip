@@ -2925,7 +2925,8 @@ extern "C" hipError_t gf2k_narrow(const u64 *A, long long lda, const u64 *B, lon
   const size_t lds = (size_t)n * wl * 8;
   if (n > 64 || lds > 65536 || l <= 0) return hipErrorInvalidValue;
   long long blocks = ((long long)m + 255) / 256;
-  if (blocks > 2048) blocks = 2048;  // grid-stride: every block pays the B transpose once
+  static const int cap_env = getenv("M4RI_HIP_NARROW_BLOCKS") ? atoi(getenv("M4RI_HIP_NARROW_BLOCKS")) : 0;  // (A/B measurements)
+  if (blocks > (cap_env > 0 ? cap_env : 2048)) blocks = cap_env > 0 ? cap_env : 2048;  // grid-stride: every block pays the B transpose once
   dim3 grid((unsigned)blocks), block(256);
   const bool vec_ok = (lda % 2 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
   if (wl <= 1)
