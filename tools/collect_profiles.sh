@@ -19,16 +19,17 @@ python3 tools/levels_sweep.py 4096x4096x4096 8192x8192x8192 12288x12288x12288 16
 python3 tools/stream_bench.py > $O/stream_reference.txt 2>/dev/null
 python3 tools/hbm_rates.py > $O/hbm_rates.txt 2>/dev/null
 echo "timings done"
-( cd tools && { echo "== 343 leaves of 4096^3, packed A: legacy v7 (90), v8 with 4096 / 2048 / 1024 / 512-row tiles (9-12)"; APACK=1 ./kbench 4096 343 3 90 9 10 11 12;
-  echo "== the same, unpacked A (and v6 = 8)"; ./kbench 4096 343 3 9 10 11 12 8;
-  echo "== 2401 leaves, packed"; APACK=1 ./kbench 4096 2401 2 90 9;
+( cd tools && { echo "== (the first kernel a process times runs 4-5 % slow: every list below starts with a throw-away entry)";
+  echo "== 343 leaves of 4096^3, packed A: legacy v7 (90), v8 with 4096 / 2048 / 1024 / 512-row tiles (9-12)"; APACK=1 ./kbench 4096 343 3 9 90 9 10 11 12;
+  echo "== the same, unpacked A (and v6 = 8)"; ./kbench 4096 343 3 9 9 10 11 12 8;
+  echo "== 2401 leaves, packed"; APACK=1 ./kbench 4096 2401 2 9 90 9;
   echo "== 4096^3 alone, every tile cut into stream-K segments, unpacked"; NREM=-1 ./kbench 4096 1 200 9 10 11 12;
   echo "== 4096^3 alone, uniform split-K of the older kernels"; KSPLIT=32 ./kbench 4096 1 200 8; KSPLIT=8 ./kbench 4096 1 200 7;
   echo "== 49 leaves of 4096^3 packed: whole tiles, then stream-K on the last round"; APACK=1 ./kbench 4096 49 5 9 10; APACK=1 NREM=-2 ./kbench 4096 49 5 9 10;
-  echo "== read window of the lookup loop on 343 packed leaves: two steps (9, 10, 11), three (13, 14, 15), one (17, 18, 19)"; APACK=1 ./kbench 4096 343 3 9 13 17 10 14 18 11 15 19;
+  echo "== read window of the lookup loop on 343 packed leaves: two steps (9, 10, 11), three (13, 14, 15), one (17, 18, 19)"; APACK=1 ./kbench 4096 343 3 9 9 13 17 10 14 18 11 15 19;
   echo "== static wave priority (GF2K_V8_FLAGS=1: waves 4-7, 2: waves 0-3)"; for f in 0 1 2; do GF2K_V8_FLAGS=$f APACK=1 ./kbench 4096 343 3 9; done;
   echo "== tall narrow tiles (v9 experiment: 21 / 22 / 23 = 4096 / 2048 / 1024 x 128) against v8 (9): 343 leaves packed, unpacked; 4096^3 and 8192^3 alone";
-  APACK=1 ./kbench 4096 343 3 9 21 22 23; ./kbench 4096 343 3 9 21 22; NREM=-1 ./kbench 4096 1 200 11 21 22 23; APACK=1 NREM=-1 ./kbench 4096 1 200 11 21; NREM=-1 ./kbench 8192 1 50 10 21 22; } ) > $O/tile_variants.txt 2>&1
+  APACK=1 ./kbench 4096 343 3 9 9 21 22 23; ./kbench 4096 343 3 9 9 21 22; NREM=-1 ./kbench 4096 1 200 11 21 22 23; APACK=1 NREM=-1 ./kbench 4096 1 200 11 21; NREM=-1 ./kbench 8192 1 50 10 21 22; } ) > $O/tile_variants.txt 2>&1
 echo "kbench done"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu --no-configs > $O/prof_bench.log 2>&1
