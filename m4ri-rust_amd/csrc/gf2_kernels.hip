@@ -18,11 +18,12 @@
 //    by a byte of A with one conflict-free ds_read_b128 and XORs it into its accumulators.  The table
 //    row is exactly one LDS bank row (64 banks x 4 B), so any mix of entries is conflict free.
 //    The LDS byte address is formed by ONE v_perm_b32: {0, table-select, A byte, lane offset}.
-//    Shipped generations: _v3 (instruction-count minimal; used for m <= 1024), _v6 (two chunks per lookup step folded with
-//    v_bitop3_b32, 2048 x 1024 tile, one row of A per lane), _v7 (four chunks per table generation, 4096 x 512 tile; default on
-//    row-group-packed A, i.e. Strassen leaves and packed plain products).  The first generation and v5 live in
-//    tools/gf2_kernels_legacy.inc (development builds only).
-//  * few-tile products cut the inner dimension into slices (split-K); gf2_splitk_reduce_kernel XORs the partial tiles.
+//    Shipped generations: _v3 (instruction-count minimal; short operands), _v6 (two chunks per lookup step folded with
+//    v_bitop3_b32, 2048 x 1024 tile, one row of A per lane), _v8 (four chunks per table generation, 512 columns, tile height 4096 /
+//    2048 / 1024 / 512 chosen at launch, stream-K segments for the last round of a launch; the default nearly everywhere).  The first
+//    generation, v5, v7 (v8's fixed-height predecessor with its ablation branches) and the tall-narrow experiment v9 live under
+//    tools/ (development builds only).
+//  * few-tile products cut the inner dimension: stream-K segments + gf2_streamk_reduce_kernel (v8), uniform slices + gf2_splitk_reduce_kernel (v3, v6).
 //  * products with n <= 256, many rows and a short inner dimension (batches of matrix x vector products) have their own
 //    Four-Russians kernels with tables over B in LDS: gf2_tallskinny6_kernel (n <= 64: 4-bit tables, small streaming workgroups),
 //    gf2_tallskinny5_kernel (64 < n <= 256: 8-bit tables, every row read once), gf2_tallskinny4 / 3_kernel for 256 < l <= 1024;
@@ -2791,7 +2792,7 @@ static hipError_t launch_v8(gf2k_mul_args a, int cfg, int RG, hipStream_t stream
 }
 
 // cfg (shipped): 7 = v3 1024 x 2048 tile, 20 = v3 256 x 2048 (4 waves), 8 = v6 2048 x 1024, 81 / 82 = v6 with a deeper /
-// shallower read window, 9 = v7 4096 x 512.  Everything else -- the first-generation kernels 0 / 1, v5 (80), packed B (50)
+// shallower read window, 9 / 10 / 11 / 12 = v8 with 4096 / 2048 / 1024 / 512-row tiles (launch_v8).  Everything else -- the first-generation kernels 0 / 1, v5 (80), packed B (50)
 // and the timing-only ablations whose results are wrong by design (40-45, 49, 83-89, 92-96) -- exists only in builds
 // with -DGF2K_DEV_VARIANTS (tools/libm4ri_hip_dev.so for tools/kbench) and is hipErrorInvalidValue in libm4ri_hip.so.
 extern "C" hipError_t gf2k_m4rm(gf2k_mul_args a, int cfg, hipStream_t stream) {

@@ -394,9 +394,9 @@ static int env_int(const char *name, int dflt) {
 }
 
 // ---- launch geometry of the tile kernel (shared by the launcher and the level chooser) ----
-// kernel variants (gf2_kernels.hip): 8 = v6 2048 x 1024 tile, two chunks per lookup step, one row per lane; 9 = v7 4096 x 512
-// tile, four chunks per table (only ahead of v6 when A comes row-group packed from the Strassen split); 7 = v3 1024 x 2048
-// tile; 20 = v3 256 x 2048 tile (4 waves).  M4RI_HIP_M4RM_CFG overrides (shipped variants only)
+// tile geometry and measured cost of the OLDER kernel variants (gf2_kernels.hip): 8 = v6 2048 x 1024 tile, two chunks per lookup step, one
+// row per lane; 7 = v3 1024 x 2048 tile; 20 = v3 256 x 2048 tile (4 waves).  (The v8 family, 9-12, is priced by v8_model below;
+// 90-99 are the legacy v7 of development builds.)  M4RI_HIP_M4RM_CFG overrides (shipped variants only)
 struct TileGeom {
   int rows, cols;
   double cyc_per_chunk;  // measured cycles per 8 bits of the inner dimension and tile, 2.4 GHz
