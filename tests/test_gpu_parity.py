@@ -666,6 +666,58 @@ def test_split_k_and_small_tile_paths(dev):
         assert np.array_equal(C0.to_words(), c0 ^ ref), (m, l, n, "accumulate")
 
 
+def _tile_plan(dev, m, l, n, batch, packed):
+    import ctypes
+    plan = (ctypes.c_longlong * 9)()
+    dev._lib.lib().gf2_tile_plan(m, l, n, batch, int(packed), plan)
+    return list(plan)
+
+
+def test_streamk_cut_of_the_last_round(dev):
+    """Launches whose tiles are a few more than a multiple of 256 (brilliantrussian.rs:210-216 on shapes with 258-276 tiles): the
+    whole rounds run whole tiles, the tiles of the last round are cut into stream-K segments whose partial tiles a second kernel
+    folds into C -- both kinds of workgroup in ONE launch.  The planner's choice is read back (at least one case must really be
+    such a launch), the product is compared with the oracle: whole matrix for the small case, sampled rows otherwise; accumulate
+    form too (the reduction kernel then XORs into C)."""
+    mixed = 0
+    for (m, l, n) in [(4096, 2048, 16896), (8192, 512, 66048), (4096, 2048, 70000), (8192, 2048, 35000)]:
+        for packed in (0, 1):
+            cfg, _, n_rem, nseg = _tile_plan(dev, m, l, n, 1, packed)[:4]
+            if cfg in (9, 10, 11, 12):
+                tiles = -(-m // {9: 4096, 10: 2048, 11: 1024, 12: 512}[cfg]) * -(-n // 512)
+                mixed += 0 < n_rem < tiles
+        a, b = g.random_words(m, l, 21), g.random_words(l, n, 22)
+        A, B = dev.DMat.from_words(a, l), dev.DMat.from_words(b, n)
+        rows = np.arange(m) if m * n <= 4096 * 16896 else np.unique(np.concatenate([np.arange(0, m, 509), [m - 1, m // 2, 4095, 4096 % m]]))
+        ref = g.o_mul_m4rm(np.ascontiguousarray(a[rows]), b, len(rows), l, n, k=8)
+        got = dev.mul(A, B, algo="m4rm").to_words()
+        assert np.array_equal(got[rows], ref), (m, l, n)
+        C0 = dev.DMat.random(m, n, 23)
+        c0 = C0.to_words()
+        dev.mul(A, B, C=C0, accumulate=True, algo="m4rm")
+        assert np.array_equal(C0.to_words(), c0 ^ got), (m, l, n, "accumulate")
+    assert mixed >= 2, "no launch with whole tiles AND segments among the cases: the planner has changed, pick new shapes"
+
+
+def test_batched_leaves_with_a_tail_launch(dev):
+    """A Strassen product whose leaf batch is cut in two launches (strassen.rs:8-18 at 16384^3 with two levels: 49 leaves of 4096^3
+    = 392 tiles; the products of the incomplete second round run in a launch of their own with shorter tiles cut into segments):
+    same bits as plain M4RM on the device and as the oracle on sampled rows."""
+    n = 16384
+    plan = _tile_plan(dev, 4096, 4096, 4096, 49, 1)
+    assert plan[5] > 0 and plan[6] in (9, 10, 11, 12), ("the planner no longer cuts this batch: pick another shape", plan)
+    A, B = dev.DMat.random(n, n, 31), dev.DMat.random(n, n, 32)
+    P2 = dev.mul(A, B, algo="strassen", param=2)
+    assert dev.equal(P2, dev.mul(A, B, algo="m4rm"))
+    rows = [0, 4095, 4096, 9999, n - 1]
+    a = np.ascontiguousarray(g.random_words(n, n, 31)[rows])
+    assert np.array_equal(P2.to_words()[rows], g.o_mul_m4rm(a, g.random_words(n, n, 32), len(rows), n, n, k=8))
+    C0 = dev.DMat.random(n, n, 33)
+    expect = dev.add(C0, P2)
+    dev.mul(A, B, C=C0, accumulate=True, algo="strassen", param=2)
+    assert dev.equal(C0, expect)
+
+
 def test_dev_full_size_65536(dev):
     """BASELINE's metric size on one GPU: Strassen (4 fused levels) over M4RM == plain M4RM == oracle on sampled rows."""
     n = 65536
