@@ -18,6 +18,7 @@ python3 tools/levels_sweep.py 4096x4096x4096 8192x8192x8192 12288x12288x12288 16
    32768x32768x32768 40960x40960x40960 49152x49152x49152 65536x65536x65536 8192x65536x65536 16384x65536x65536 16384x65536x16384 8192x65536x16384 > $O/levels_sweep.txt 2>/dev/null
 python3 tools/stream_bench.py > $O/stream_reference.txt 2>/dev/null
 python3 tools/hbm_rates.py > $O/hbm_rates.txt 2>/dev/null
+python3 tools/elim_bench.py 2>/dev/null | grep "^n=" > $O/elim.txt
 echo "timings done"
 ( cd tools && { echo "== (the first kernel a process times runs 4-5 % slow: every list below starts with a throw-away entry)";
   echo "== 343 leaves of 4096^3, packed A: legacy v7 (90), v8 with 4096 / 2048 / 1024 / 512-row tiles (9-12)"; APACK=1 ./kbench 4096 343 3 9 90 9 10 11 12;
