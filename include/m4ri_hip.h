@@ -202,6 +202,10 @@ int gf2_mul_plan(int m, int l, int n, int algo, int param, int *kind, int dims[3
  * out[8] = its variant, tiles cut and segments; returns the modelled time in seconds.  Diagnostic: tools and tests read the
  * launcher's choice from here. */
 double gf2_tile_plan(int m, int l, int n, int batch, int packed, long long out[9]);
+/* ... and the plan's row band, if it has one: the rows below the last whole tile row of the launch(es) above run in a launch of
+ * their own with a shorter tile.  out[0] = rows of the band (0: none; gf2_tile_plan then describes all rows), out[1] = its variant,
+ * out[2] / out[3] = its tiles cut and segments, out[4] = its scratch bytes (gf2_tile_plan's out[4] already covers them). */
+void gf2_tile_plan_band(int m, int l, int n, int batch, int packed, long long out[5]);
 /* modelled seconds of a device product of this shape with exactly `levels` Strassen levels (0: plain M4RM); -1 if that many
  * levels do not divide the shape.  Diagnostic (tools/levels_sweep.py prints it beside the measured time). */
 double gf2_model_time(int m, int l, int n, int levels);

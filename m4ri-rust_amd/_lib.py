@@ -101,6 +101,7 @@ _PROTOS = {
     "gf2_mul_plan": (_I, [_I, _I, _I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "gf2_model_time": (ctypes.c_double, [_I, _I, _I, _I]),
     "gf2_tile_plan": (ctypes.c_double, [_I, _I, _I, _I, _I, ctypes.POINTER(ctypes.c_longlong)]),
+    "gf2_tile_plan_band": (None, [_I, _I, _I, _I, _I, ctypes.POINTER(ctypes.c_longlong)]),
     "gf2_mul_dev": (_I, [DMatP, DMatP, DMatP, _I, _I, _I, ctypes.c_void_p]),
     "gf2_mul_nt_dev": (_I, [DMatP, DMatP, DMatP, _I, ctypes.c_void_p]),
     "gf2_add_dev": (_I, [DMatP, DMatP, DMatP, ctypes.c_void_p]),

@@ -463,6 +463,11 @@ struct TilePlan {
   // last tail_batch products in a launch of their own with its own variant and split (a short tile height, every tile cut)
   int tail_batch = 0, tail_cfg = 0, tail_n_rem = 0, tail_nseg = 0;
   size_t tail_ws_bytes = 0;
+  // the rows below the last whole tile row of the main launch may run as a launch of their own with a shorter tile (a "row
+  // band": 17000 rows = four tile rows of 4096 + 616 rows in 1024-row tiles instead of a fifth tile row that is 15 % full)
+  int band_rows = 0, band_cfg = 0, band_n_rem = 0, band_nseg = 0;
+  size_t band_ws_bytes = 0;
+  size_t scratch() const { return std::max(ws_bytes, std::max(tail_ws_bytes, band_ws_bytes)); }  // the launches run one after the other
 };
 
 // microseconds per quad (32 bits of the inner dimension) of a v8 tile: table generation (256 entry writes, barrier) + RG x 1024
@@ -537,7 +542,8 @@ static bool older_model(int m, int l, int n, int batch, bool packed, int cfg, Ti
   return true;
 }
 
-static TilePlan plan_tiles_uncached(int m, int l, int n, int batch, bool packed, bool allow_tail);
+enum { PLAN_TAIL = 2, PLAN_BAND = 4, PLAN_V8_ONLY = 8 };  // what a plan may contain (PlanKey::flags; bit 0 = packed A)
+static TilePlan plan_tiles_uncached(int m, int l, int n, int batch, bool packed, int mode);
 // Planning is pure arithmetic on the shape (and the environment, read once), but a level choice evaluates dozens of candidate
 // launches: 15-55 us of host time per product, which a 0.2 ms product notices.  Every thread keeps what it has planned.
 struct PlanKey {
@@ -553,18 +559,19 @@ struct PlanKeyHash {
     return h;
   }
 };
-static TilePlan plan_tiles(int m, int l, int n, int batch, bool packed, bool allow_tail = true) {
+static TilePlan plan_tiles(int m, int l, int n, int batch, bool packed, int mode = PLAN_TAIL | PLAN_BAND) {
   thread_local std::unordered_map<PlanKey, TilePlan, PlanKeyHash> memo;
-  const PlanKey key{m, l, n, batch, (packed ? 1 : 0) | (allow_tail ? 2 : 0)};
+  const PlanKey key{m, l, n, batch, (packed ? 1 : 0) | mode};
   auto it = memo.find(key);
   if (it != memo.end()) return it->second;
   if (memo.size() > 8192) memo.clear();
-  const TilePlan tp = plan_tiles_uncached(m, l, n, batch, packed, allow_tail);
+  const TilePlan tp = plan_tiles_uncached(m, l, n, batch, packed, mode);
   memo.emplace(key, tp);
   return tp;
 }
 
-static TilePlan plan_tiles_uncached(int m, int l, int n, int batch, bool packed, bool allow_tail) {
+static TilePlan plan_tiles_uncached(int m, int l, int n, int batch, bool packed, int mode) {
+  const bool allow_tail = (mode & PLAN_TAIL) != 0;
   // A/B override, restricted to variants that compute the product (the timing-only ablations exist only in development
   // builds of the kernels and would be hipErrorInvalidValue here anyway)
   static const int forced = [] {
@@ -603,7 +610,7 @@ static TilePlan plan_tiles_uncached(int m, int l, int n, int batch, bool packed,
       if (b1 >= 1 && b1 < batch) {
         TilePlan head;
         if (v8_model(m, l, n, (int)b1, packed, cfg, 0, 0, head)) {
-          const TilePlan tail = plan_tiles(m, l, n, batch - (int)b1, packed, false);
+          const TilePlan tail = plan_tiles(m, l, n, batch - (int)b1, packed, 0);
           head.t += tail.t + 1.5e-6;
           head.tail_batch = batch - (int)b1;
           head.tail_cfg = tail.cfg;
@@ -625,13 +632,41 @@ static TilePlan plan_tiles_uncached(int m, int l, int n, int batch, bool packed,
     }
     return best;
   }
-  if (m <= 256 && !packed) {
+  const bool v8_only = (mode & PLAN_V8_ONLY) != 0;
+  if (m <= 256 && !packed && !v8_only) {
     if (older_model(m, l, n, batch, packed, 20, c)) consider(c);
     return best;
   }
-  if (!packed && older_model(m, l, n, batch, packed, 7, c)) consider(c);
-  if (older_model(m, l, n, batch, packed, 8, c)) consider(c);
+  if (!v8_only) {
+    if (!packed && older_model(m, l, n, batch, packed, 7, c)) consider(c);
+    if (older_model(m, l, n, batch, packed, 8, c)) consider(c);
+  }
   for (int cfg = 9; cfg <= 12; ++cfg) v8(cfg);
+  // a row band: whole tile rows of 4096 (2048) in the main launch, the rows below them in a launch of their own with the
+  // tile height that suits them (the same B, disjoint rows of A and C; the band's partial tiles reuse the scratch)
+  static const int bands = env_int("M4RI_HIP_ROW_BANDS", 1);
+  static const double band_gain = env_int("M4RI_HIP_ROW_BAND_MIN_GAIN_PCT", 3) * 1e-2;
+  if (bands && (mode & PLAN_BAND) && have) {
+    const TilePlan uniform = best;
+    for (int R = 4096; R >= 2048; R >>= 1) {
+      const int m1 = m / R * R, m2 = m - m1;
+      if (m1 < R || m2 <= 0) continue;
+      TilePlan head = plan_tiles(m1, l, n, batch, packed, (mode & PLAN_TAIL) | PLAN_V8_ONLY);
+      const TilePlan band = plan_tiles(m2, l, n, batch, packed, PLAN_V8_ONLY);
+      if (!cfg_v8_rg(head.cfg) || !cfg_v8_rg(band.cfg)) continue;
+      // + the launch boundary between the two; batched leaves: priced 3 % up (measured at 40000^3 and 52000^3, where padded plans
+      // with banded leaves were modelled 0.5 % ahead of the peeled plans and ran 3 % behind them; plain products match the model:
+      // 17000^3 -9 %, 12700 x 1024 x 40000 -26 %, 70000^3's bottom strip 40.4 -> 39.1 ms)
+      head.t = (head.t + band.t) * (batch > 1 ? 1.03 : 1.0) + 3e-6;
+      if (head.t >= uniform.t * (1.0 - band_gain)) continue;
+      head.band_rows = m2;
+      head.band_cfg = band.cfg;
+      head.band_n_rem = band.n_rem;
+      head.band_nseg = band.nseg;
+      head.band_ws_bytes = band.ws_bytes;
+      consider(head);
+    }
+  }
   return best;
 }
 
@@ -663,21 +698,38 @@ static int apply_tile_plan(gf2k_mul_args &a, const TilePlan &tp, hipStream_t s);
 static int launch_planned(gf2k_mul_args a, const TilePlan &tp, hipStream_t s) {
   ProfScope prof(s);
   const int total = a.batch;
+  const int band = tp.band_rows > 0 && tp.band_rows < a.m ? tp.band_rows : 0;
+  const gf2k_mul_args whole = a;
+  a.m -= band;
   const bool cut = tp.tail_batch > 0 && tp.tail_batch < total;
   if (cut) a.batch = total - tp.tail_batch;
   if (int rc = apply_tile_plan(a, tp, s)) return rc;
   if (int rc = launch_m4rm(a, tp.cfg, s)) return rc;
-  if (!cut) return 0;
-  gf2k_mul_args b = a;
-  const long long b1 = a.batch;
-  b.A += b1 * a.sA;
-  b.B += b1 * a.sB;
-  b.C += b1 * a.sC;
-  b.batch = tp.tail_batch;
-  b.ksplit = 1;
-  b.n_rem = b.P ? tp.tail_n_rem : 0;
-  b.nseg = b.P ? tp.tail_nseg : 0;
-  return launch_m4rm(b, tp.tail_cfg, s);
+  if (cut) {
+    gf2k_mul_args b = a;
+    const long long b1 = a.batch;
+    b.A += b1 * a.sA;
+    b.B += b1 * a.sB;
+    b.C += b1 * a.sC;
+    b.batch = tp.tail_batch;
+    b.ksplit = 1;
+    b.n_rem = b.P ? tp.tail_n_rem : 0;
+    b.nseg = b.P ? tp.tail_nseg : 0;
+    if (int rc = launch_m4rm(b, tp.tail_cfg, s)) return rc;
+  }
+  if (!band) return 0;
+  // the row band: rows [m - band, m) of every product (m - band is a multiple of 2048, so the offset is the same
+  // expression for row-major and row-group-packed A)
+  gf2k_mul_args r = whole;
+  r.A += (long long)a.m * whole.lda;
+  r.C += (long long)a.m * whole.ldc;
+  r.m = band;
+  r.ksplit = 1;
+  r.P = a.P;
+  r.p_words = a.p_words;
+  r.n_rem = r.P ? tp.band_n_rem : 0;
+  r.nseg = r.P ? tp.band_nseg : 0;
+  return launch_m4rm(r, tp.band_cfg, s);
 }
 
 // the plan of a plain product: A unpacked, or packed by a pass of its own when the model says that pays
@@ -701,7 +753,7 @@ static int apply_tile_plan(gf2k_mul_args &a, const TilePlan &tp, hipStream_t s) 
   a.n_rem = a.nseg = 0;
   a.P = nullptr;
   a.p_words = 0;
-  const size_t want = std::max(tp.ws_bytes, tp.tail_ws_bytes);  // (the two launches of a cut batch run one after the other)
+  const size_t want = tp.scratch();  // (the launches of a plan run one after the other)
   if (want == 0) return 0;
   void *ws = nullptr;
   if (stream_workspace(s, want, &ws, 1) != 0) return 0;
@@ -1326,7 +1378,7 @@ extern "C" size_t gf2_mul_workspace_bytes(int m, int l, int n, int algo, int par
   if (m > 0 && l > 0 && n > 64) {
     bool pack = false;
     const TilePlan tp = plain_plan(m, l, n, &pack);
-    plain_ws = std::max(tp.ws_bytes, tp.tail_ws_bytes) + (pack ? (size_t)((m + 63) & ~63) * (size_t)((words_of(l) + 1) & ~1) * 8 : 0);
+    plain_ws = tp.scratch() + (pack ? (size_t)((m + 63) & ~63) * (size_t)((words_of(l) + 1) & ~1) * 8 : 0);
   }
   if (algo == GF2_ALGO_M4RM) return plain_ws;
   static const int leaf_min = env_int("M4RI_HIP_STRASSEN_LEAF_MIN", 2048);
@@ -1335,7 +1387,7 @@ extern "C" size_t gf2_mul_workspace_bytes(int m, int l, int n, int algo, int par
   const bool pk = strassen_packs_a(m, L);
   const TilePlan a = plan_tiles(m >> L, l >> L, n >> L, (int)pow7(L), false), b = pk ? plan_tiles(m >> L, l >> L, n >> L, (int)pow7(L), true) : a;
   const TilePlan &lp = (pk && cfg_reads_packed(b.cfg) && b.t <= a.t) ? b : a;
-  return strassen_ws_words(m, l, n, L) * sizeof(u64) + std::max(lp.ws_bytes, lp.tail_ws_bytes);
+  return strassen_ws_words(m, l, n, L) * sizeof(u64) + lp.scratch();
 }
 
 extern "C" int gf2_add_dev(gf2_dmat *C, gf2_dmat const *A, gf2_dmat const *B, void *stream) {
@@ -1468,13 +1520,23 @@ extern "C" double gf2_tile_plan(int m, int l, int n, int batch, int packed, long
     out[1] = tp.ksplit;
     out[2] = tp.n_rem;
     out[3] = tp.nseg;
-    out[4] = (long long)std::max(tp.ws_bytes, tp.tail_ws_bytes);
+    out[4] = (long long)tp.scratch();
     out[5] = tp.tail_batch;
     out[6] = tp.tail_cfg;
     out[7] = tp.tail_n_rem;
     out[8] = tp.tail_nseg;
   }
   return tp.t;
+}
+
+// the row band of the same plan: out = {rows of the band (0: none), its variant, its stream-K cut (tiles, segments), its scratch}
+extern "C" void gf2_tile_plan_band(int m, int l, int n, int batch, int packed, long long out[5]) {
+  const TilePlan tp = plan_tiles(m, l, n, batch < 1 ? 1 : batch, packed != 0);
+  out[0] = tp.band_rows;
+  out[1] = tp.band_cfg;
+  out[2] = tp.band_n_rem;
+  out[3] = tp.band_nseg;
+  out[4] = (long long)tp.band_ws_bytes;
 }
 
 extern "C" int gf2_mul_plan(int m, int l, int n, int algo, int param, int *kind, int dims[3]) {

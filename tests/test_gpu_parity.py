@@ -718,6 +718,53 @@ def test_batched_leaves_with_a_tail_launch(dev):
     assert dev.equal(C0, expect)
 
 
+def _tile_plan_band(dev, m, l, n, batch, packed):
+    import ctypes
+    band = (ctypes.c_longlong * 5)()
+    dev._lib.lib().gf2_tile_plan_band(m, l, n, batch, int(packed), band)
+    return list(band)
+
+
+def test_row_band_launches(dev):
+    """Row counts a little above a multiple of the tile height (brilliantrussian.rs:210-216 on 8512, 8600 and 12700 rows): the
+    whole tile rows run as one launch, the rows below them as a second launch with shorter tiles -- disjoint rows of A and C, the
+    same B.  The planner's choice is read back (the cases must really have a band); every row of the band and sampled rows above it
+    are compared with the oracle, and the accumulate form with the plain sum."""
+    banded = 0
+    for (m, l, n) in [(8512, 1024, 32768), (8600, 2048, 66000), (12700, 1024, 40000)]:
+        rows_band = max(_tile_plan_band(dev, m, l, n, 1, p)[0] for p in (0, 1))
+        banded += rows_band > 0
+        a, b = g.random_words(m, l, 41), g.random_words(l, n, 42)
+        A, B = dev.DMat.from_words(a, l), dev.DMat.from_words(b, n)
+        rows = np.unique(np.concatenate([np.arange(0, m, 997), np.arange(m - max(rows_band, 64) - 2, m), [4095, 4096, 8191, 8192]]))
+        ref = g.o_mul_m4rm(np.ascontiguousarray(a[rows]), b, len(rows), l, n, k=8)
+        got = dev.mul(A, B, algo="m4rm").to_words()
+        assert np.array_equal(got[rows], ref), (m, l, n)
+        C0 = dev.DMat.random(m, n, 43)
+        c0 = C0.to_words()
+        dev.mul(A, B, C=C0, accumulate=True, algo="m4rm")
+        assert np.array_equal(C0.to_words(), c0 ^ got), (m, l, n, "accumulate")
+    assert banded == 3, "a case lost its row band: the planner has changed, pick new shapes"
+
+
+def test_batched_leaves_with_a_row_band(dev):
+    """Strassen leaves with 4288 rows (strassen.rs:8-18 at 17152 x 4096 x 8192, two levels: 49 packed leaves of 4288 x 1024 x 2048):
+    one tile row of 4096 per leaf in the main launch, the 192 rows below it in a band launch over the same batch."""
+    m, l, n = 17152, 4096, 8192
+    band = _tile_plan_band(dev, m >> 2, l >> 2, n >> 2, 49, 1)
+    assert band[0] > 0 and band[1] in (9, 10, 11, 12), ("the planner no longer cuts a band off these leaves: pick another shape", band)
+    A, B = dev.DMat.random(m, l, 51), dev.DMat.random(l, n, 52)
+    P2 = dev.mul(A, B, algo="strassen", param=2)
+    assert dev.equal(P2, dev.mul(A, B, algo="m4rm"))
+    rows = np.unique(np.concatenate([np.arange(0, m, 1531), np.arange(4096, 4288), np.arange(m - 192, m)]))
+    a = np.ascontiguousarray(g.random_words(m, l, 51)[rows])
+    assert np.array_equal(P2.to_words()[rows], g.o_mul_m4rm(a, g.random_words(l, n, 52), len(rows), l, n, k=8))
+    C0 = dev.DMat.random(m, n, 53)
+    expect = dev.add(C0, P2)
+    dev.mul(A, B, C=C0, accumulate=True, algo="strassen", param=2)
+    assert dev.equal(C0, expect)
+
+
 def test_dev_full_size_65536(dev):
     """BASELINE's metric size on one GPU: Strassen (4 fused levels) over M4RM == plain M4RM == oracle on sampled rows."""
     n = 65536
