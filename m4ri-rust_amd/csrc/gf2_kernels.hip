@@ -1835,10 +1835,15 @@ __global__ __launch_bounds__(256) void gf2_tallskinny6_kernel(const u64 *__restr
     for (int w = 0; w < 2 * NW; ++w) acc[w] = 0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
+      // the eight entry offsets of a dword, pre-scaled, as the bytes of two registers (even nibbles in xe, odd ones in xo): one
+      // byte extraction per lookup instead of a shift and a mask
+      u32 xe = (d[q] & 0x0f0f0f0fu) * (u32)EB, xo = ((d[q] >> 4) & 0x0f0f0f0fu) * (u32)EB;
+      asm("" : "+v"(xe), "+v"(xo));  // (opaque: the optimiser would fold the bytes back into eight shift-and-mask pairs)
 #pragma unroll
       for (int k = 0; k < 8; k += 2) {  // nibbles k and k + 1 of dword q: tables 8 q + k, 8 q + k + 1 (offsets fold to immediates)
         const u32 t0 = (u32)(8 * q + k) * TB, t1 = t0 + TB;
-        const u32 o0 = ((d[q] >> (4 * k)) & 15u) * EB, o1 = ((d[q] >> (4 * k + 4)) & 15u) * EB;
+        const u32 o0 = EB <= 16 ? __builtin_amdgcn_ubfe(xe, 4 * k, 8) : ((d[q] >> (4 * k)) & 15u) * EB,
+                  o1 = EB <= 16 ? __builtin_amdgcn_ubfe(xo, 4 * k, 8) : ((d[q] >> (4 * k + 4)) & 15u) * EB;
         if constexpr (NW == 1) {
           const u32x2v x = *reinterpret_cast<lds_cu32x2 *>(o0 + t0), y = *reinterpret_cast<lds_cu32x2 *>(o1 + t1);
           asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[0]) : "v"(x.x), "v"(y.x));

@@ -18,7 +18,9 @@ sys.path.insert(0, ROOT)
 def main():
     import torch
     import m4ri_rust_amd  # noqa
-    from m4ri_rust_amd import device
+    from m4ri_rust_amd import _lib, device
+    if os.environ.get("AB_LIB"):  # A/B of two builds on one box: load this shared object instead
+        _lib.LIB_PATH = os.environ["AB_LIB"]
     device.require_gpu()
     as_json = "--json" in sys.argv
     nbuf = 10
