@@ -124,7 +124,7 @@ def _timed(fn, reps, torch):
     return (time.perf_counter() - t0) / reps
 
 
-def _extra_configs(device, torch, stream):
+def _extra_configs(device, torch, stream, squares=True, lpn_v=(1, 64, 256)):
     """The other single-GPU BASELINE.json configurations, timed in the same run as the headline (device resident, wall clock
     around `reps` back-to-back products on the bench stream) and hashed against the committed digests:
       config 2  4096^3, M4RM kernel only;  config 3  32768^3, Strassen over M4RM;
@@ -152,24 +152,33 @@ def _extra_configs(device, torch, stream):
                                     "frac": lds / dt / 1e12 / LDS_PEAK_TBS,
                                     "note": "plain M4RM read count; Strassen levels lower the reads actually made"}}
 
-    for name, nn, algo, reps, key in (("config 2: 4096^3, M4RM kernel only", 4096, "m4rm", 200, "sq_4096"),
-                                      ("config 3: 32768^3, Strassen over M4RM", 32768, "auto", 10, "sq_32768")):
+    for name, nn, algo, reps, key in ((("config 2: 4096^3, M4RM kernel only", 4096, "m4rm", 200, "sq_4096"),
+                                       ("config 3: 32768^3, Strassen over M4RM", 32768, "auto", 10, "sq_32768")) if squares else ()):
         A, B, C = device.DMat.random(nn, nn, 1, stream), device.DMat.random(nn, nn, 2, stream), device.DMat(nn, nn)
-        for _ in range(3):
+        # untimed: ~30 ms of the same product first.  The clocks drop during the host-side hashing between two configurations and
+        # take more than 2 ms of work to come back (measured on the LPN shapes below: 23.9 us after 100 untimed products, 20.3 us
+        # after 1000, for the same 200 timed ones)
+        for _ in range(1000 if nn <= 4096 else 8):
             device.mul(A, B, C=C, algo=algo, stream=stream)
         dt = _timed(lambda i: device.mul(A, B, C=C, algo=algo, stream=stream), reps, torch)
         entry(name, nn, nn, nn, algo, dt, _sha256_of(C, stream), key, onchip(nn, nn, nn, dt))
         del A, B, C
     m, l, nbuf = 1 << 20, 256, 10
     As = [device.DMat.random(m, l, 1 if i == 0 else 100 + i, stream) for i in range(nbuf)]
-    for V in (1, 64, 256):
+    for V in lpn_v:
         X = device.DMat.random(l, V, 2, stream)
         Cs = [device.DMat(m, V) for _ in range(nbuf)]
-        for i in range(2 * nbuf):
-            device.mul(As[i % nbuf], X, C=Cs[i % nbuf], algo="naive", stream=stream)
-        dt = _timed(lambda i: device.mul(As[i % nbuf], X, C=Cs[i % nbuf], algo="naive", stream=stream), 20 * nbuf, torch)
+        # A_i is paired with C_(3i+1 mod nbuf): the allocator hands out both sets with the same stride, so pairing equal indices
+        # would give every product the SAME distance between its read and its write stream, and that distance decides whether
+        # the two collide in the HBM channels (tools/lpn_placement.py: V = 256 takes 18.9-23.0 us depending on it alone); ten
+        # different distances make the figure typical instead of lucky or unlucky
+        def one(i):
+            device.mul(As[i % nbuf], X, C=Cs[(3 * i + 1) % nbuf], algo="naive", stream=stream)
+        for i in range(100 * nbuf):  # untimed round-robin passes, 10-25 ms (see above)
+            one(i)
+        dt = _timed(one, 20 * nbuf, torch)
         entry("config 5: LPN 2^20 x 256 times 256 x %d (mzd_mul_naive entry), cold: %d rotating A buffers" % (V, nbuf),
-              m, l, V, "naive", dt, _sha256_of(Cs[0], stream), "lpn_1048576x256x%d" % V)
+              m, l, V, "naive", dt, _sha256_of(Cs[1], stream), "lpn_1048576x256x%d" % V)  # Cs[1] = A_0 * X
         del Cs, X
     del As
     return out

@@ -28,6 +28,20 @@ def main():
     cases = ((1, "naive"), (64, "naive"), (128, "naive"), (256, "naive"))
     if "--all" in sys.argv:
         cases += ((64, "m4rm"), (256, "m4rm"))
+    stream = None
+    if os.environ.get("LPN_STREAM"):  # time on a torch side stream (what bench.py does) instead of the NULL stream
+        comp = torch.cuda.Stream()
+        torch.cuda.set_stream(comp)
+        stream = comp.cuda_stream
+    if os.environ.get("LPN_PREALLOC_GIB"):  # an arena first, as in a process that has run the square products (placement of the buffers)
+        hold = torch.empty(int(os.environ["LPN_PREALLOC_GIB"]) << 27, dtype=torch.int64, device="cuda")  # noqa: F841
+    if os.environ.get("LPN_PREHEAT"):  # ten 65536^3 products first: the power / clock state a process is in after the square products
+        P, Q = device.DMat.random(65536, 65536, 1), device.DMat.random(65536, 65536, 2)
+        R = device.DMat(65536, 65536)
+        for _ in range(int(os.environ["LPN_PREHEAT"])):
+            device.mul(P, Q, C=R, stream=stream)
+        torch.cuda.synchronize()
+        del P, Q, R
     As = [device.DMat.random(m, l, 3 + i) for i in range(nbuf)]
     for V, algo in cases:
         X = device.DMat.random(l, V, 4)
@@ -36,12 +50,12 @@ def main():
         for mode in ("warm", "cold"):
             k = 1 if mode == "warm" else nbuf
             for i in range(2 * k):
-                device.mul(As[i % k], X, C=Cs[i % k], algo=algo)
+                device.mul(As[i % k], X, C=Cs[i % k], algo=algo, stream=stream)
             torch.cuda.synchronize()
             reps = 20 * nbuf
             t0 = time.perf_counter()
             for i in range(reps):
-                device.mul(As[i % k], X, C=Cs[i % k], algo=algo)
+                device.mul(As[i % k], X, C=Cs[i % k], algo=algo, stream=stream)
             torch.cuda.synchronize()
             res[mode] = (time.perf_counter() - t0) / reps
         wv = (V + 63) // 64

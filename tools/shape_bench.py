@@ -27,6 +27,14 @@ def main():
         for _ in range(2):
             dev.mul(A, B, C, algo=algo, param=levels)
         torch.cuda.synchronize()
+        # ~30 ms of untimed products: the clocks of an idle GPU need more than a couple of milliseconds of work to come up
+        # (a 35-us product measures 8 % slow after two warm-up products)
+        t0 = time.perf_counter()
+        dev.mul(A, B, C, algo=algo, param=levels)
+        torch.cuda.synchronize()
+        for _ in range(min(2000, int(0.03 / max(time.perf_counter() - t0, 1e-6)))):
+            dev.mul(A, B, C, algo=algo, param=levels)
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(reps):
             dev.mul(A, B, C, algo=algo, param=levels)
