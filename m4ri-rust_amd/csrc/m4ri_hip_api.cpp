@@ -841,13 +841,16 @@ static double strassen_pass_bytes(double m, double l, double n, int L) {
 //          chunk, split-K included)  +  bytes moved by the split / merge passes / bw
 // `leaf_min` bounds the leaf dimensions from below (mzd_mul's cutoff argument, strassen.rs:8-18).
 // modelled seconds of the product with exactly L levels on the shape as given (-1: L levels do not divide it)
+// fixed cost of one split / merge pass besides its bytes: the dependent-kernel boundary and the ramp of a launch (three passes
+// per plan step).  5 us: with 3 us the model preferred two levels at 8192^3 (133 against 138 us), which measures 0.123 against 0.115 ms
+static const double kPassLaunch = 5.0e-6;
 static double level_time_model(int m, int l, int n, int L) {
   static const double bw = (double)env_int("M4RI_HIP_STREAM_GBS", 5000) * 1e9;        // streaming B/s
   if (L <= 0) return plain_time_model(m, l, n);
   const int d = 1 << L;
   if (L > 6 || m % d || l % (128 * d) || n % (128 * d)) return -1.0;  // leaf rows integral, leaf widths an even word count
   return leaf_time_model(m >> L, l >> L, n >> L, (int)pow7(L), strassen_packs_a(m, L)) + strassen_pass_bytes(m, l, n, L) / bw +
-         3 * 3e-6 * (double)strassen_plan(L).size();
+         3 * kPassLaunch * (double)strassen_plan(L).size();
 }
 extern "C" double gf2_model_time(int m, int l, int n, int levels) { return level_time_model(m, l, n, levels); }
 
@@ -887,8 +890,8 @@ static int pick_levels_uncached(int m, int l, int n, int req, int leaf_min, doub
     double t = level_time_model(m, l, n, L);
     if (L == 1) t *= 1.15;  // the single-level pass kernels (unfused, unpacked A leaves) run well below the model: 20480^3 2.21 ms against 1.82
     // tools/levels_sweep.py (profiles/r03_levels_sweep.txt): the model is 3-10 % pessimistic for 0 and 2 levels and within 3 % for
-    // 3 and more, so a further level must promise 2 % (up to two levels) / 3 % (beyond) over the best count below it
-    if (L == 0 || t < best_t * (L >= 3 ? 0.97 : 0.98)) {
+    // 3 and more, so a further level must promise 1.5 % (up to two levels) / 3 % (beyond) over the best count below it
+    if (L == 0 || t < best_t * (L >= 3 ? 0.97 : 0.985)) {
       best = L;
       best_t = t;
     }
@@ -1163,7 +1166,7 @@ static ShapePlan plan_shape_uncached(int m, int l, int n, int req, int leaf_min)
     const long long um = 64ll << L, uw = 128ll << L;
     auto core_time = [&](long long mm, long long ll, long long nn) {
       return leaf_time_model((int)(mm >> L), (int)(ll >> L), (int)(nn >> L), (int)pow7(L), strassen_packs_a((int)mm, L)) +
-             strassen_pass_bytes((double)mm, (double)ll, (double)nn, L) / bw + 3 * 3e-6 * (double)strassen_plan(L).size();
+             strassen_pass_bytes((double)mm, (double)ll, (double)nn, L) / bw + 3 * kPassLaunch * (double)strassen_plan(L).size();
     };
     auto leaves_ok = [&](long long mm, long long ll, long long nn) {
       return req > 0 || ((mm >> L) >= 1024 && (ll >> L) >= leaf_min && (nn >> L) >= leaf_min);
