@@ -23,6 +23,7 @@
 #include <string>
 #include <tuple>
 #include <unordered_map>
+#include <array>
 #include <vector>
 
 #include "../../include/m4ri_hip.h"
@@ -472,11 +473,23 @@ struct TilePlan {
 
 // microseconds per quad (32 bits of the inner dimension) of a v8 tile: table generation (256 entry writes, barrier) + RG x 1024
 // lookups; an unpacked A costs 64 scattered 8-byte loads per wave and row group.  Measured on 343 leaves of 4096^3
-// (profiles/r03_tile_variants.txt): packed 0.71 / 0.96 / 1.46 / 2.55 us for RG = 1 / 2 / 4 / 8.
+// (profiles/r03_tile_variants.txt): packed 0.71 / 0.96 / 1.46 / 2.55 us per quad and tile for RG = 1 / 2 / 4 / 8 INCLUDING the
+// tile's prologue / epilogue / hand-over, which v8_model adds separately ((3.4 + 0.6 RG) us per 128 quads there): the loop
+// itself takes 0.679 / 0.924 / 1.415 / 2.486 us (M4RI_HIP_V8_QUAD_NS overrides the four; checked against 49 leaves of
+// 5632^3 in 2048-row tiles: 1617 tiles x 176 quads in 1.63 ms = 1.47 us per quad and tile all in)
 static double v8_quad_us(int RG, bool packed) {
-  static const double base = env_int("M4RI_HIP_V8_BASE_NS", 450) * 1e-3, per = env_int("M4RI_HIP_V8_PER_RG_NS", 262) * 1e-3,
-                      unp0 = env_int("M4RI_HIP_V8_UNPACKED_BASE_NS", 100) * 1e-3, unp = env_int("M4RI_HIP_V8_UNPACKED_NS", 70) * 1e-3;
-  return base + per * RG + (packed ? 0.0 : unp0 + unp * RG);
+  static const double unp0 = env_int("M4RI_HIP_V8_UNPACKED_BASE_NS", 100) * 1e-3, unp = env_int("M4RI_HIP_V8_UNPACKED_NS", 70) * 1e-3;
+  static const std::array<double, 4> loop_us = [] {
+    std::array<double, 4> t{0.679, 0.924, 1.415, 2.486};
+    if (const char *e = getenv("M4RI_HIP_V8_QUAD_NS")) {
+      int v[4];
+      if (std::sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4)
+        for (int i = 0; i < 4; ++i) t[i] = v[i] * 1e-3;
+    }
+    return t;
+  }();
+  const int i = RG >= 8 ? 3 : RG >= 4 ? 2 : RG >= 2 ? 1 : 0;
+  return loop_us[i] + (packed ? 0.0 : unp0 + unp * RG);
 }
 
 // One v8 launch: `batch` products, variant cfg, the last n_rem tiles cut into about `want` segments (n_rem = 0: whole tiles only).
@@ -1159,8 +1172,10 @@ static ShapePlan plan_shape_uncached(int m, int l, int n, int req, int leaf_min)
   auto consider = [&](int kind, int L, long long mm, long long ll, long long nn, double t) {
     if (only_kind && kind != only_kind) return;
     if (debug) std::fprintf(stderr, "  L=%d %s %lld x %lld x %lld: %.3f ms\n", L, kind == 1 ? "pad " : "peel", mm, ll, nn, t * 1e3);
-    // (not forced:) the model is coarse: a plan must promise 8 % over plain M4RM to be taken
-    if ((req > 0 && !forced_done) || (t < best.t && (req > 0 || t < 0.92 * plain))) best = {kind, L, (int)mm, (int)ll, (int)nn, t}, forced_done = true;
+    // (not forced:) the model is coarse: a plan must promise 5 % over plain M4RM to be taken (8 % until the tile model stopped counting
+    // the per-tile overhead twice; 30000^3 then sat exactly on the threshold: padded 3.71 ms, plain 4.06 ms measured)
+    static const double min_gain = env_int("M4RI_HIP_SHAPE_MIN_GAIN_PCT", 5) * 1e-2;
+    if ((req > 0 && !forced_done) || (t < best.t && (req > 0 || t < (1.0 - min_gain) * plain))) best = {kind, L, (int)mm, (int)ll, (int)nn, t}, forced_done = true;
   };
   for (int L = lo; L <= hi; ++L) {
     const long long um = 64ll << L, uw = 128ll << L;

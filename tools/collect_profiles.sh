@@ -14,8 +14,9 @@ python3 tools/host_path_bench.py > $O/host_path.txt 2>/dev/null
 python3 tools/pcie_duplex.py >> $O/host_path.txt 2>/dev/null
 tools/sweep_sizes.sh > $O/size_sweep.txt 2>/dev/null
 python3 tools/shape_bench.py 131072,131072,131072,auto,0,2 >> $O/size_sweep.txt 2>/dev/null
-python3 tools/levels_sweep.py 4096x4096x4096 8192x8192x8192 12288x12288x12288 16384x16384x16384 20480x20480x20480 24576x24576x24576 \
-   32768x32768x32768 40960x40960x40960 49152x49152x49152 65536x65536x65536 8192x65536x65536 16384x65536x65536 16384x65536x16384 8192x65536x16384 > $O/levels_sweep.txt 2>/dev/null
+python3 tools/levels_sweep.py 4096x4096x4096 6144x6144x6144 8192x8192x8192 10240x10240x10240 12288x12288x12288 14336x14336x14336 16384x16384x16384 18432x18432x18432 20480x20480x20480 \
+   22528x22528x22528 24576x24576x24576 28672x28672x28672 32768x32768x32768 36864x36864x36864 40960x40960x40960 45056x45056x45056 49152x49152x49152 57344x57344x57344 65536x65536x65536 \
+   8192x65536x65536 16384x65536x65536 16384x65536x16384 8192x65536x16384 > $O/levels_sweep.txt 2>/dev/null
 python3 tools/stream_bench.py > $O/stream_reference.txt 2>/dev/null
 python3 tools/hbm_rates.py > $O/hbm_rates.txt 2>/dev/null
 python3 tools/elim_bench.py 2>/dev/null | grep "^n=" > $O/elim.txt
