@@ -87,6 +87,9 @@ hipError_t gf2k_rowparity(const uint64_t *A, long long lda, const uint64_t *Bt, 
                           int m, int l, int n, int accumulate, hipStream_t stream);
 hipError_t gf2k_narrow(const uint64_t *A, long long lda, const uint64_t *B, long long ldb, uint64_t *C, long long ldc,
                        int m, int l, int n, int accumulate, hipStream_t stream);
+// n <= 32 vectors against a long inner dimension: a wave per row (Bt: n rows of l bits)
+hipError_t gf2k_widevec(const uint64_t *A, long long lda, const uint64_t *Bt, long long ldbt, uint64_t *C, long long ldc,
+                        int m, int l, int n, int accumulate, int jshift, hipStream_t stream);
 hipError_t gf2k_tallskinny(const uint64_t *A, long long lda, const uint64_t *B, long long ldb, uint64_t *C, long long ldc,
                            int m, int l, int n, int accumulate, hipStream_t stream);
 hipError_t gf2k_va(const uint64_t *A, long long lda, const uint64_t *B, long long ldb, uint64_t *C, long long ldc, int m,

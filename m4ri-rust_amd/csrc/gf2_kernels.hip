@@ -27,7 +27,8 @@
 //  * products with n <= 256, many rows and a short inner dimension (batches of matrix x vector products) have their own
 //    Four-Russians kernels with tables over B in LDS: gf2_tallskinny6_kernel (n <= 64: 4-bit tables, small streaming workgroups),
 //    gf2_tallskinny5_kernel (64 < n <= 256: 8-bit tables, every row read once), gf2_tallskinny4 / 3_kernel for 256 < l <= 1024;
-//    n <= 8 uses an AND/popcount kernel (gf2_narrow_kernel) that streams A at HBM speed.
+//    n <= 8 uses an AND/popcount kernel (gf2_narrow_kernel) that streams A at HBM speed; up to 64 vectors against LONG rows
+//    (l > 512: `&A * &v` on a big square A) take gf2_widevec_kernel, a wave per row with lanes along the row.
 //  * the Strassen passes fuse three levels (and a virtual fourth) per kernel in registers (gf2_strassen_split3 / merge3_kernel);
 //    transpose, XOR, compare, fill, padding are HBM-streaming kernels with 16- or 8-byte accesses.  The elimination kernels live in gf2_elim.hip.
 #include <hip/hip_runtime.h>
@@ -1359,6 +1360,74 @@ __global__ __launch_bounds__(256) void gf2_narrow_kernel(const u64 *__restrict__
     u64 *dst = C + i * ldc;
     if (accumulate) out ^= *dst;
     *dst = out;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// wide matrix x vector(s): C (m x n) (+)= A (m x l) * Bt^T with n <= 32 and a LONG inner dimension (mul_slice / `&A * &v` on a
+// large square A, binary_matrix.rs:416-431,528-542; a block of Wiedemann / Lanczos vectors).  The row-parity and narrow kernels
+// keep a row in the registers of ONE lane, which is right for l <= 512; a lane walking an 8-KiB row on its own makes every load
+// of its wave touch 64 cache lines (65536^2 times a vector: 0.30 ms = 1.8 TB/s).  Here a WAVE owns a row: lane t takes the
+// words t, t + 64, ... -- 512 contiguous bytes per load, eight loads in flight per lane --, ANDs them with the same words of
+// the vectors (Bt: n rows of l bits, staged in LDS slab by slab: lane-consecutive 8-byte reads, conflict-free) and keeps one
+// 64-bit XOR accumulator per vector; the parity of a vector's accumulators over the wave is one popcount, one ballot and one
+// scalar popcount.  A is read once; n = 1 ... 8 stream at the rate of a copy, 32 vectors cost about three times that (VALU).
+// The inner dimension is walked in slabs of `slab` words (n * slab * 8 bytes of LDS); rows are revisited per slab and C is
+// accumulated, by the one wave that owns the row.
+// ---------------------------------------------------------------------------------------------
+template <int NJ>
+__global__ __launch_bounds__(1024) void gf2_widevec_kernel(const u64 *__restrict__ A, long long lda, const u64 *__restrict__ Bt,
+                                                            long long ldbt, u64 *__restrict__ C, long long ldc, int m, int l,
+                                                            int n, int accumulate, int slab, int jshift) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  u64 *bt = reinterpret_cast<u64 *>(lds);  // NJ rows x slab words (rows n .. NJ-1 are zero)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int wl = (l + 63) >> 6;
+  const u64 maskL = (l & 63) ? ((1ull << (l & 63)) - 1) : ~0ull;
+  const long long gw = (long long)blockIdx.x * nwaves + wave, nw = (long long)gridDim.x * nwaves;
+  constexpr int U = 8;  // loads in flight per lane
+  for (int s0 = 0; s0 < wl; s0 += slab) {
+    const int sw = min(slab, wl - s0);
+    if (s0) __syncthreads();  // the previous slab's readers are done
+    for (int idx = tid; idx < NJ * sw; idx += blockDim.x) {
+      const int j = idx / sw, t = idx - j * sw;
+      u64 v = j < n ? Bt[(long long)j * ldbt + s0 + t] : 0;
+      if (s0 + t == wl - 1) v &= maskL;  // bits past the inner dimension never count, whatever A holds there
+      bt[j * slab + t] = v;
+    }
+    __syncthreads();
+    for (long long i = gw; i < m; i += nw) {
+      u64 acc[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[j] = 0;
+      const u64 *ar = A + i * lda + s0;
+      for (int t0 = 0; t0 < sw; t0 += 64 * U) {
+        u64 a[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int t = t0 + 64 * u + lane;
+          a[u] = t < sw ? ar[t] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int t = min(t0 + 64 * u + lane, sw - 1);  // (a[u] is zero past the slab)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[j] ^= a[u] & bt[j * slab + t];
+        }
+      }
+      u64 out = 0;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const u64 bal = __ballot(__popcll(acc[j]) & 1);
+        out |= (u64)(__popcll(bal) & 1) << j;
+      }
+      if (lane == 0) {
+        u64 *dst = C + i * ldc;
+        out <<= jshift;  // (vectors jshift .. jshift + n - 1 of a wider C: the caller accumulates)
+        if (accumulate || s0) out ^= *dst;
+        *dst = out;
+      }
+    }
   }
 }
 
@@ -2946,6 +3015,38 @@ extern "C" hipError_t gf2k_narrow(const u64 *A, long long lda, const u64 *B, lon
   else
     hipLaunchKernelGGL((gf2_narrow_kernel<0>), grid, block, lds, stream, A, lda, B, ldb, C, ldc, m, l, n, accumulate);
   return hipGetLastError();
+}
+
+// n <= 32 (Bt: n rows of l bits, row stride ldbt words); any l, meant for l > 512.  The n result bits of a row go to bits
+// jshift .. jshift + n - 1 of its word of C (jshift > 0 only with accumulate: the second half of a 64-vector block).
+extern "C" hipError_t gf2k_widevec(const u64 *A, long long lda, const u64 *Bt, long long ldbt, u64 *C, long long ldc, int m,
+                                   int l, int n, int accumulate, int jshift, hipStream_t stream) {
+  if (m <= 0 || n <= 0) return hipSuccess;
+  if (n > 32 || l <= 0 || jshift < 0 || jshift + n > 64 || (jshift && !accumulate)) return hipErrorInvalidValue;
+  const int wl = (l + 63) >> 6;
+  const int NJ = n <= 1 ? 1 : n <= 2 ? 2 : n <= 4 ? 4 : n <= 8 ? 8 : n <= 16 ? 16 : 32;
+  int slab = (128 * 1024) / (NJ * 8);  // words of the inner dimension per slab: 128 KiB of LDS
+  if (slab > wl) slab = (wl + 63) & ~63;
+  const size_t lds = (size_t)NJ * slab * 8;
+  const int threads = 1024, nwaves = threads / 64;
+  long long blocks = ((long long)m + nwaves - 1) / nwaves;
+  if (blocks > 512) blocks = 512;
+  hipError_t e = hipSuccess;
+#define GF2K_WV(NJv)                                                                                          \
+  e = lds_limit_once(reinterpret_cast<const void *>(&gf2_widevec_kernel<NJv>), 128 * 1024);                   \
+  if (e == hipSuccess)                                                                                        \
+    hipLaunchKernelGGL((gf2_widevec_kernel<NJv>), dim3((unsigned)blocks), dim3(threads), lds, stream, A, lda, Bt, ldbt, C, ldc, m, l, \
+                       n, accumulate, slab, jshift)
+  switch (NJ) {
+    case 1: GF2K_WV(1); break;
+    case 2: GF2K_WV(2); break;
+    case 4: GF2K_WV(4); break;
+    case 8: GF2K_WV(8); break;
+    case 16: GF2K_WV(16); break;
+    default: GF2K_WV(32); break;
+  }
+#undef GF2K_WV
+  return e != hipSuccess ? e : hipGetLastError();
 }
 
 // n <= 256; returns hipErrorInvalidValue otherwise

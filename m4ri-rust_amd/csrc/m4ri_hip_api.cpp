@@ -927,6 +927,27 @@ static size_t strassen_ws_words(int m, int l, int n, int L) {
   return total;
 }
 
+// Few columns against a long inner dimension (`&A * &v` with a large square A; a block of up to 64 vectors): B is transposed
+// (n rows of l bits, a few KiB) and a wave per row streams A once (gf2_widevec_kernel), 32 vectors per pass.  The tile kernel
+// would compute 512 columns to deliver n (65536^2 times 64 vectors: 1.18 ms against 0.3), the lane-per-row kernels read an
+// 8-KiB row 8 bytes at a time per lane (65536^2 times one vector: 0.30 ms against 0.1).
+static bool widevec_shape(int m, int l, int n) {
+  static const int on = env_int("M4RI_HIP_WIDEVEC", 1);
+  return on && n <= 64 && l > 512 && m >= 16 && !(n > 8 && m >= 2048 && l <= 1024);  // (the last: the tall-skinny table kernels)
+}
+static int mul_widevec(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int accumulate, hipStream_t s) {
+  const int m = A->nrows, l = A->ncols, n = B->ncols;
+  const long long ldbt = (words_of(l) + 1) & ~1ll;
+  void *bt = nullptr;
+  if (int rc = stream_workspace(s, (size_t)n * ldbt * sizeof(u64), &bt)) return rc;
+  HIP_TRY(gf2k_transpose(static_cast<u64 *>(bt), ldbt, B->data, B->ld, l, n, s));
+  const u64 *Bt = static_cast<const u64 *>(bt);
+  const int n0 = n < 32 ? n : 32;
+  HIP_TRY(gf2k_widevec(A->data, A->ld, Bt, ldbt, C->data, C->ld, m, l, n0, accumulate, 0, s));
+  if (n > 32) HIP_TRY(gf2k_widevec(A->data, A->ld, Bt + 32 * ldbt, ldbt, C->data, C->ld, m, l, n - 32, 1, 32, s));
+  return 0;
+}
+
 static int mul_m4rm_plain(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int accumulate, hipStream_t s) {
   const int m = A->nrows, l = A->ncols, n = B->ncols;
   if (m == 0 || n == 0) return 0;
@@ -941,6 +962,7 @@ static int mul_m4rm_plain(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int
     HIP_TRY(gf2k_tallskinny(A->data, A->ld, B->data, B->ld, C->data, C->ld, m, l, n, accumulate, s));
     return 0;
   }
+  if (widevec_shape(m, l, n) && l > 1024) return mul_widevec(C, A, B, accumulate, s);
   if (m <= 8) {  // a handful of rows: stream B once (v*A path, binary_matrix.rs:552-563)
     if (!accumulate) HIP_TRY(gf2k_xor2d(C->data, C->ld, nullptr, 0, nullptr, 0, m, words_of(n), s));
     HIP_TRY(gf2k_va(A->data, A->ld, B->data, B->ld, C->data, C->ld, m, l, n, s));
@@ -1269,6 +1291,11 @@ static int mul_naive_dev(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int 
   const int m = A->nrows, l = A->ncols, n = B->ncols;
   if (n > 64 || l == 0) return mul_m4rm_plain(C, A, B, accumulate, s);
   if (m == 0 || n == 0) return 0;
+  if (widevec_shape(m, l, n)) {  // long rows: a wave per row
+    if (int rc = mul_widevec(C, A, B, accumulate, s)) return rc;
+    if (sync_free && hipStreamSynchronize(s) != hipSuccess) return fail(hipGetLastError(), "hipStreamSynchronize");
+    return 0;
+  }
   if (n > 8 && m >= 2048) return mul_m4rm_plain(C, A, B, accumulate, s);  // batch of vectors: table kernel (see there)
   if ((size_t)n * words_of(l) * 8 <= 65536) {  // one launch: B is transposed into LDS by every block
     hipError_t e1 = gf2k_narrow(A->data, A->ld, B->data, B->ld, C->data, C->ld, m, l, n, accumulate, s);
@@ -1385,7 +1412,13 @@ extern "C" int gf2_mul_nt_dev(gf2_dmat *C, gf2_dmat const *A, gf2_dmat const *Bt
     return fail_msg("gf2_mul_nt_dev: dimension mismatch");
   hipStream_t s;
   if (int rc = get_stream(stream, &s)) return rc;
-  HIP_TRY(gf2k_rowparity(A->data, A->ld, Bt->data, Bt->ld, C->data, C->ld, A->nrows, A->ncols, Bt->nrows, accumulate, s));
+  const int m = A->nrows, l = A->ncols, n = Bt->nrows;
+  if (widevec_shape(m, l, n)) {  // long rows, at most 64 vectors: a wave per row (Bt is already what that kernel reads)
+    HIP_TRY(gf2k_widevec(A->data, A->ld, Bt->data, Bt->ld, C->data, C->ld, m, l, n < 32 ? n : 32, accumulate, 0, s));
+    if (n > 32) HIP_TRY(gf2k_widevec(A->data, A->ld, Bt->data + 32 * Bt->ld, Bt->ld, C->data, C->ld, m, l, n - 32, 1, 32, s));
+    return 0;
+  }
+  HIP_TRY(gf2k_rowparity(A->data, A->ld, Bt->data, Bt->ld, C->data, C->ld, m, l, n, accumulate, s));
   return 0;
 }
 
@@ -1393,6 +1426,7 @@ extern "C" size_t gf2_mul_workspace_bytes(int m, int l, int n, int algo, int par
   if (algo == GF2_ALGO_NAIVE) return n <= 64 ? (size_t)n * ((words_of(l) + 1) & ~1) * 8 : 0;
   // a plain product may pack A (mul_m4rm_plain) and may cut tiles into segments / slices with partial tiles in scratch
   size_t plain_ws = 0;
+  if (m > 0 && l > 1024 && widevec_shape(m, l, n)) return (size_t)n * ((words_of(l) + 1) & ~1) * 8;  // the transposed vectors
   if (m > 0 && l > 0 && n > 64) {
     bool pack = false;
     const TilePlan tp = plain_plan(m, l, n, &pack);

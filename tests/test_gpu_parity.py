@@ -814,6 +814,35 @@ def test_tall_skinny_shapes(pkg, dev, m, l, n):
     assert np.array_equal(C.to_words(), ref ^ c0)
 
 
+@pytest.mark.parametrize("m,l,n", [(300, 5000, 1), (1000, 70001, 1), (4097, 1500, 8), (2500, 3000, 33), (5000, 2049, 64), (64, 100000, 17),
+                                   (16, 600, 3), (2100, 513, 5), (3000, 1025, 9), (777, 8192, 32), (4096, 4096, 2), (150, 200000, 40),
+                                   (70000, 1100, 1), (33, 1000000, 4)])
+def test_wide_matrix_times_few_vectors(pkg, dev, m, l, n):
+    """`&A * &v` and blocks of up to 64 vectors on a matrix with LONG rows (mul_slice, binary_matrix.rs:416-431,528-542, on shapes
+    the reference's callers reach with a large square A): a wave per row, the inner dimension in slabs, 32 vectors per pass,
+    ragged everything; every algorithm selector gives the oracle's bits, with and without accumulation."""
+    a, b = g.random_words(m, l, 500 + n), g.random_words(l, n, 501 + (l % 97))
+    A, B = dev.DMat.from_words(a, l), dev.DMat.from_words(b, n)
+    ref = g.o_mul_m4rm(a, b, m, l, n, k=8)
+    for algo in ("naive", "auto", "m4rm"):
+        assert np.array_equal(dev.mul(A, B, algo=algo).to_words(), ref), (m, l, n, algo)
+    c0 = g.random_words(m, n, 502)
+    for algo in ("naive", "m4rm"):
+        C = dev.DMat.from_words(c0, n)
+        dev.mul(A, B, C, accumulate=True, algo=algo)
+        assert np.array_equal(C.to_words(), ref ^ c0), (m, l, n, algo, "accumulate")
+    # the pre-transposed entry (_mzd_mul_naive, mzd.rs:154-168) reads the vectors as the rows of Bt
+    Bt = dev.transpose(B)
+    assert np.array_equal(dev.mul_nt(A, Bt).to_words(), ref), (m, l, n, "nt")
+    C = dev.DMat.from_words(c0, n)
+    dev.mul_nt(A, Bt, C, accumulate=True)
+    assert np.array_equal(C.to_words(), ref ^ c0), (m, l, n, "nt accumulate")
+    if n == 1 and m * l <= 1 << 27:  # the friendly layer's matrix x vector on host matrices
+        M = pkg.BinMatrix.from_words(a, l)
+        v = pkg.BinVector.from_bools([bool(int(b[i, 0]) & 1) for i in range(l)])
+        assert (M * v).to_bools() == [bool(int(ref[i, 0]) & 1) for i in range(m)]
+
+
 @pytest.mark.parametrize("m,l,n,levels", [(8192, 8192, 8192, 3), (8192, 8192, 8192, 4), (8192, 8192, 8192, 5), (8192, 8192, 8192, 6),
                                           (4160, 8192, 4096, 5), (4096, 2048, 6144, 4), (1000 * 8, 3072, 1024, 3), (2048, 4096, 2048, 4)])
 def test_strassen_level_plans(dev, monkeypatch, m, l, n, levels):
