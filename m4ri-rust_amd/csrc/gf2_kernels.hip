@@ -1410,6 +1410,7 @@ __global__ __launch_bounds__(1024) void gf2_widevec_kernel(const u64 *__restrict
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+          if (t0 + 64 * u >= sw) break;  // (uniform: a short row does not pay for eight words per lane)
           const int t = min(t0 + 64 * u + lane, sw - 1);  // (a[u] is zero past the slab)
 #pragma unroll
           for (int j = 0; j < NJ; ++j) acc[j] ^= a[u] & bt[j * slab + t];

@@ -477,7 +477,11 @@ struct TilePlan {
 // tile's prologue / epilogue / hand-over, which v8_model adds separately ((3.4 + 0.6 RG) us per 128 quads there): the loop
 // itself takes 0.679 / 0.924 / 1.415 / 2.486 us (M4RI_HIP_V8_QUAD_NS overrides the four; checked against 49 leaves of
 // 5632^3 in 2048-row tiles: 1617 tiles x 176 quads in 1.63 ms = 1.47 us per quad and tile all in)
-static double v8_quad_us(int RG, bool packed) {
+// Unpacked A with LONG rows: a lane's 8-byte loads walk its own row, and from ~8192 bits on the lines the 4096 rows of a
+// tile keep open (64 bytes each) no longer survive in L2 until their next word is wanted -- every load fetches a line from
+// HBM (65536 x 65536 x 512: 1.14 ms unpacked, 0.78 ms with the packing pass; 65536 x 8192 x 512: 0.190 against 0.101 ms;
+// up to 7000 bits packing loses, 0.092 against 0.156 ms): the surcharge is five times as high from 8192 bits on.
+static double v8_quad_us(int RG, bool packed, int l = 0) {
   static const double unp0 = env_int("M4RI_HIP_V8_UNPACKED_BASE_NS", 100) * 1e-3, unp = env_int("M4RI_HIP_V8_UNPACKED_NS", 70) * 1e-3;
   static const std::array<double, 4> loop_us = [] {
     std::array<double, 4> t{0.679, 0.924, 1.415, 2.486};
@@ -489,7 +493,9 @@ static double v8_quad_us(int RG, bool packed) {
     return t;
   }();
   const int i = RG >= 8 ? 3 : RG >= 4 ? 2 : RG >= 2 ? 1 : 0;
-  return loop_us[i] + (packed ? 0.0 : unp0 + unp * RG);
+  static const double long_rows = env_int("M4RI_HIP_V8_UNPACKED_LONG_PCT", 500) * 1e-2;
+  const double stretch = l >= 8192 ? long_rows : 1.0;  // a cliff, not a slope: 65536 x l x 512 unpacked takes 0.092 ms at l = 7000 and 0.188 ms at 8192
+  return loop_us[i] + (packed ? 0.0 : (unp0 + unp * RG) * stretch);
 }
 
 // One v8 launch: `batch` products, variant cfg, the last n_rem tiles cut into about `want` segments (n_rem = 0: whole tiles only).
@@ -501,7 +507,7 @@ static bool v8_model(int m, int l, int n, int batch, bool packed, int cfg, long 
                       red_bw = env_int("M4RI_HIP_V8_REDUCE_GBS", 2500) * 1e9, two_part = env_int("M4RI_HIP_V8_TWO_PART_PCT", 180) * 1e-2;
   const int RG = cfg_v8_rg(cfg), R = 512 * RG, nw32 = (l + 31) / 32, Q = (nw32 + 1) / 2;
   const long long T = (long long)((m + R - 1) / R) * ((n + 511) / 512) * batch;
-  const double tq = v8_quad_us(RG, packed) * 1e-6, tile_bytes = R * 64.0;
+  const double tq = v8_quad_us(RG, packed, l) * 1e-6, tile_bytes = R * 64.0;
   const double tile_t = 2.0 * Q * tq + (3.4 + 0.6 * RG) * 1e-6;  // + prologue, epilogue (LDS transpose, stores), hand-over to the next workgroup
   c = TilePlan();
   c.cfg = cfg;
@@ -933,7 +939,16 @@ static size_t strassen_ws_words(int m, int l, int n, int L) {
 // 8-KiB row 8 bytes at a time per lane (65536^2 times one vector: 0.30 ms against 0.1).
 static bool widevec_shape(int m, int l, int n) {
   static const int on = env_int("M4RI_HIP_WIDEVEC", 1);
-  return on && n <= 64 && l > 512 && m >= 16 && !(n > 8 && m >= 2048 && l <= 1024);  // (the last: the tall-skinny table kernels)
+  if (!on || n > 64 || m < 1) return false;
+  // Where it wins, from an A/B grid against the older paths on one box (tools/ab_widevec.sh, profiles/r03_widevec_ab.txt;
+  // time of the wave-per-row kernel / time of what ran before, at m = 65536 and m = 1000):
+  //   n <= 16: l = 2048 0.28-0.48 / 0.8-1.1, 4096 0.37-0.63 / 0.6-0.9, 20000 0.08-0.16 / 0.4-0.6, 65536 0.08-0.16 / 0.4-0.55
+  //   n  = 32: l = 4096 1.27 / 0.74, 20000 0.31 / 0.59, 65536 0.30 / 0.97        n = 64: l = 20000 0.63 / 1.04, 65536 0.61 / 1.84
+  // (three instructions per vector and word bound it from 9 vectors on; a row per wave needs rows to fill the chip)
+  if (m <= 8) return l >= 8192 && (n <= 32 || m >= 4);  // against the v*A kernel: 8 x 65536 x 1 74 -> 9 us, x 64 120 -> 62 us
+  if (n <= 16) return l >= 2048;
+  if (n <= 32) return l >= 8192;
+  return l >= 16384 && m >= 8192;
 }
 static int mul_widevec(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int accumulate, hipStream_t s) {
   const int m = A->nrows, l = A->ncols, n = B->ncols;
@@ -955,6 +970,7 @@ static int mul_m4rm_plain(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int
     if (!accumulate) HIP_TRY(gf2k_xor2d(C->data, C->ld, nullptr, 0, nullptr, 0, m, words_of(n), s));
     return 0;
   }
+  if (widevec_shape(m, l, n)) return mul_widevec(C, A, B, accumulate, s);  // few columns, long rows: a wave per row
   // tall and skinny: tables over ALL of B, A streamed once.  Built for short inner dimensions (a batch of LPN samples: l = 256);
   // with a long one the tables are rebuilt every 256 bits and the tile kernel with split-K is ~10x faster (65536 x 65600 x 64:
   // 6.4 ms here), so the border strips of peeled products do not come this way
@@ -962,7 +978,6 @@ static int mul_m4rm_plain(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int
     HIP_TRY(gf2k_tallskinny(A->data, A->ld, B->data, B->ld, C->data, C->ld, m, l, n, accumulate, s));
     return 0;
   }
-  if (widevec_shape(m, l, n) && l > 1024) return mul_widevec(C, A, B, accumulate, s);
   if (m <= 8) {  // a handful of rows: stream B once (v*A path, binary_matrix.rs:552-563)
     if (!accumulate) HIP_TRY(gf2k_xor2d(C->data, C->ld, nullptr, 0, nullptr, 0, m, words_of(n), s));
     HIP_TRY(gf2k_va(A->data, A->ld, B->data, B->ld, C->data, C->ld, m, l, n, s));
@@ -1426,7 +1441,7 @@ extern "C" size_t gf2_mul_workspace_bytes(int m, int l, int n, int algo, int par
   if (algo == GF2_ALGO_NAIVE) return n <= 64 ? (size_t)n * ((words_of(l) + 1) & ~1) * 8 : 0;
   // a plain product may pack A (mul_m4rm_plain) and may cut tiles into segments / slices with partial tiles in scratch
   size_t plain_ws = 0;
-  if (m > 0 && l > 1024 && widevec_shape(m, l, n)) return (size_t)n * ((words_of(l) + 1) & ~1) * 8;  // the transposed vectors
+  if (m > 0 && widevec_shape(m, l, n)) return (size_t)n * ((words_of(l) + 1) & ~1) * 8;  // the transposed vectors
   if (m > 0 && l > 0 && n > 64) {
     bool pack = false;
     const TilePlan tp = plain_plan(m, l, n, &pack);
