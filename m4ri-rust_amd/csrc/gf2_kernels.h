@@ -92,6 +92,9 @@ hipError_t gf2k_widevec(const uint64_t *A, long long lda, const uint64_t *Bt, lo
                         int m, int l, int n, int accumulate, int jshift, hipStream_t stream);
 hipError_t gf2k_tallskinny(const uint64_t *A, long long lda, const uint64_t *B, long long ldb, uint64_t *C, long long ldc,
                            int m, int l, int n, int accumulate, hipStream_t stream);
+// n <= 64 vectors, any inner dimension: 4-bit tables per 512-bit slab, inner dimension divided among workgroups (atomic XOR into C)
+hipError_t gf2k_tallskinny_long(const uint64_t *A, long long lda, const uint64_t *B, long long ldb, uint64_t *C, long long ldc,
+                                int m, int l, int n, int accumulate, hipStream_t stream);
 hipError_t gf2k_va(const uint64_t *A, long long lda, const uint64_t *B, long long ldb, uint64_t *C, long long ldc, int m,
                    int l, int n, hipStream_t stream);
 hipError_t gf2k_xor2d(uint64_t *C, long long ldc, const uint64_t *A, long long lda, const uint64_t *B, long long ldb,

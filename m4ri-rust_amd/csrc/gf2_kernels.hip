@@ -28,7 +28,8 @@
 //    Four-Russians kernels with tables over B in LDS: gf2_tallskinny6_kernel (n <= 64: 4-bit tables, small streaming workgroups),
 //    gf2_tallskinny5_kernel (64 < n <= 256: 8-bit tables, every row read once), gf2_tallskinny4 / 3_kernel for 256 < l <= 1024;
 //    n <= 8 uses an AND/popcount kernel (gf2_narrow_kernel) that streams A at HBM speed; up to 64 vectors against LONG rows
-//    (l > 512: `&A * &v` on a big square A) take gf2_widevec_kernel, a wave per row with lanes along the row.
+//    (l > 512: `&A * &v` on a big square A) take gf2_widevec_kernel, a wave per row with lanes along the row, or gf2_tallskinny7_kernel,
+//    4-bit tables rebuilt per 512-bit slab with the inner dimension divided among workgroups (9-64 vectors).
 //  * the Strassen passes fuse three levels (and a virtual fourth) per kernel in registers (gf2_strassen_split3 / merge3_kernel);
 //    transpose, XOR, compare, fill, padding are HBM-streaming kernels with 16- or 8-byte accesses.  The elimination kernels live in gf2_elim.hip.
 #include <hip/hip_runtime.h>
@@ -1946,6 +1947,105 @@ __global__ __launch_bounds__(256) void gf2_tallskinny6_kernel(const u64 *__restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// up to 64 vectors against an inner dimension of ANY length: the 4-bit tables of gf2_tallskinny6_kernel, rebuilt per 512-bit
+// slab of the inner dimension, with the inner dimension also divided among workgroups (blockIdx.y) whose partial words
+// meet in C by 64-bit atomic XOR (C is one word per row: the atomics are m x splits, not a pass over a matrix).
+// A block of vectors times a big matrix (block Wiedemann / Lanczos; `mul_slice` with many rows of B) used to take the tile
+// kernel, which computes 512 columns to deliver 64 and finds a handful of tiles (4096 x 65536 x 64: ONE tile, 92 us for 32 MiB
+// of A), or the wave-per-row kernel, whose AND / XOR work grows with the vector count.  Here a lane owns RPT rows, reads 64
+// bytes of each per slab (one whole line: rows of any length stream), looks its 128 nibbles up in 128 sixteen-entry tables of
+// 8-byte entries (16 KiB; a table spans every LDS bank pair once: any mix of entries is conflict-free) and folds two lookups
+// per v_bitop3_b32 pair.  The build of a slab's tables is 8 entries per thread, ~6 % of the lookups at four rows per lane.
+// ---------------------------------------------------------------------------------------------
+template <int RPT>
+__global__ __launch_bounds__(256) void gf2_tallskinny7_kernel(const u64 *__restrict__ A, long long lda, const u64 *__restrict__ B,
+                                                              long long ldb, u64 *__restrict__ C, long long ldc, int m, int l,
+                                                              int n, int accumulate, int slabs_per_split, int atomic, int vec_ok) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  constexpr int EB = 8, TB = 16 * EB;            // bytes per entry / per table
+  u64 *bst = reinterpret_cast<u64 *>(lds + 128 * TB);  // the 512 rows of B of the slab (one word each)
+  const int tid = threadIdx.x;
+  const int wl = (l + 63) >> 6;
+  const u64 maskC = (n & 63) ? ((1ull << (n & 63)) - 1) : ~0ull;
+  const int nslabs = (l + 511) >> 9;
+  const int slab0 = blockIdx.y * slabs_per_split, slab1 = min(nslabs, slab0 + slabs_per_split);
+  const long long row0 = (long long)blockIdx.x * (256 * RPT) + tid;
+  u32 acc[RPT][2];
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) acc[r][0] = acc[r][1] = 0;
+  for (int slab = slab0; slab < slab1; ++slab) {
+    const int w0 = slab * 8;  // first word of the slab
+    // this lane's rows first: their loads are in flight across the staging and the build (words past the row read as zero;
+    // bits past the inner dimension meet tables built from zero rows of B)
+    u32 d[RPT][16];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      const long long row = min(row0 + (long long)r * 256, (long long)m - 1);  // clamped: stores are guarded
+      const u64 *ar = A + row * lda + w0;
+      if (vec_ok && w0 + 8 <= wl) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint4 v = reinterpret_cast<const uint4 *>(ar)[q];
+          d[r][4 * q] = v.x, d[r][4 * q + 1] = v.y, d[r][4 * q + 2] = v.z, d[r][4 * q + 3] = v.w;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const u64 v = w0 + q < wl ? ar[q] : 0;
+          d[r][2 * q] = (u32)v, d[r][2 * q + 1] = (u32)(v >> 32);
+        }
+      }
+    }
+    if (slab != slab0) __syncthreads();  // the previous slab's lookups are done
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = slab * 512 + h * 256 + tid;
+      bst[h * 256 + tid] = k < l ? (B[(long long)k * ldb] & maskC) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {  // 128 tables x 16 entries: entry e of table t = XOR of rows 4t + b of the slab for the set bits b of e
+      const int idx = tid + 256 * j, t = idx >> 4, e = idx & 15;
+      u64 v = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) v ^= bst[4 * t + b] & (0ull - (u64)((e >> b) & 1));
+      *reinterpret_cast<u64 *>(lds + idx * EB) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        u32 xe = (d[r][q] & 0x0f0f0f0fu) * (u32)EB, xo = ((d[r][q] >> 4) & 0x0f0f0f0fu) * (u32)EB;
+        asm("" : "+v"(xe), "+v"(xo));  // (pre-scaled entry offsets as bytes, see gf2_tallskinny6_kernel)
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+          const u32 t0 = (u32)(8 * q + k) * TB, t1 = t0 + TB;
+          const u32 o0 = __builtin_amdgcn_ubfe(xe, 4 * k, 8), o1 = __builtin_amdgcn_ubfe(xo, 4 * k, 8);
+          const u32x2v x = *reinterpret_cast<lds_cu32x2 *>(o0 + t0), y = *reinterpret_cast<lds_cu32x2 *>(o1 + t1);
+          asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][0]) : "v"(x.x), "v"(y.x));
+          asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][1]) : "v"(x.y), "v"(y.y));
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) {
+    const long long row = row0 + (long long)r * 256;
+    if (row < m) {
+      u64 v = (u64)acc[r][0] | ((u64)acc[r][1] << 32);
+      u64 *dst = C + row * ldc;
+      if (atomic) {
+        if (v) atomicXor(reinterpret_cast<unsigned long long *>(dst), (unsigned long long)v);
+      } else {
+        if (accumulate) v ^= *dst;
+        *dst = v;
+      }
+    }
+  }
+}
+
 // tall-skinny kernel with conflict-free lookups and no byte permutation ("generation" kernel; n <= 256).
 // The first kernel's lookups collide in the LDS banks (8-byte entries: 32 lanes on 32 random bank pairs, ~3.5 lanes on the
 // busiest); the skewed kernel avoids that by spreading the lanes over 32 / NW tables, which costs a byte permutation of every
@@ -2130,6 +2230,8 @@ template <int M>
 __global__ __launch_bounds__(256) void gf2_va_kernel(const u64 *__restrict__ A, long long lda,
                                                      const u64 *__restrict__ B, long long ldb, u64 *__restrict__ C,
                                                      long long ldc, int m, int l, int n, int rows_per_split) {
+  // rows_per_split is a multiple of 64: a split starts on a word of A.  The rows of B are fetched eight at a time (one row
+  // per iteration left every load exposed: 8 x 64 x 64 took 26 us, most of it 64 dependent latencies)
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   const int wn = (n + 63) >> 6;
   const int t0 = blockIdx.y * rows_per_split;
@@ -2138,14 +2240,18 @@ __global__ __launch_bounds__(256) void gf2_va_kernel(const u64 *__restrict__ A, 
 #pragma unroll
   for (int i = 0; i < M; ++i) acc[i] = 0;
   if (w < wn) {
-    for (int t = t0; t < t1; ++t) {
-      const u64 bw = B[(long long)t * ldb + w];
+    for (int tb = t0; tb < t1; tb += 64) {
+      u64 aw[M];
 #pragma unroll
-      for (int i = 0; i < M; ++i) {
-        if (i < m) {
-          const u64 aw = A[(long long)i * lda + (t >> 6)];  // wave-uniform
-          if ((aw >> (t & 63)) & 1) acc[i] ^= bw;
-        }
+      for (int i = 0; i < M; ++i) aw[i] = i < m ? A[(long long)i * lda + (tb >> 6)] : 0;  // wave-uniform
+      for (int tt = 0; tt < 64 && tb + tt < t1; tt += 8) {
+        u64 bw[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) bw[u] = tb + tt + u < t1 ? B[(long long)(tb + tt + u) * ldb + w] : 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int i = 0; i < M; ++i) acc[i] ^= bw[u] & (0ull - ((aw[i] >> (tt + u)) & 1ull));
       }
     }
     const u64 maskC = (n & 63) ? ((1ull << (n & 63)) - 1) : ~0ull;
@@ -3050,6 +3156,33 @@ extern "C" hipError_t gf2k_widevec(const u64 *A, long long lda, const u64 *Bt, l
   return e != hipSuccess ? e : hipGetLastError();
 }
 
+// n <= 64, any l and m: 4-bit tables per 512-bit slab, the inner dimension divided among workgroups.  With more than one
+// division the partial words are XORed into C atomically: C must then hold the value to accumulate into (the launcher
+// zeroes it for a plain product).
+extern "C" hipError_t gf2k_tallskinny_long(const u64 *A, long long lda, const u64 *B, long long ldb, u64 *C, long long ldc, int m,
+                                           int l, int n, int accumulate, hipStream_t stream) {
+  if (m <= 0 || n <= 0) return hipSuccess;
+  if (n > 64 || l <= 0) return hipErrorInvalidValue;
+  constexpr int RPT = 4;
+  const int nslabs = (l + 511) >> 9;
+  const long long rblocks = ((long long)m + 256 * RPT - 1) / (256 * RPT);
+  static const int want = getenv("M4RI_HIP_TS7_BLOCKS") ? atoi(getenv("M4RI_HIP_TS7_BLOCKS")) : 1024;  // (A/B measurements)
+  long long splits = rblocks >= want ? 1 : (want + rblocks - 1) / rblocks;
+  if (splits > nslabs) splits = nslabs;
+  const int sps = (int)((nslabs + splits - 1) / splits);
+  splits = (nslabs + sps - 1) / sps;
+  const int atomic = splits > 1;
+  if (atomic && !accumulate) {
+    hipError_t e = gf2k_xor2d(C, ldc, nullptr, 0, nullptr, 0, m, 1, stream);  // zero the one word per row
+    if (e != hipSuccess) return e;
+  }
+  const int vec_ok = (lda & 1) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
+  const size_t lds7 = 128 * 16 * 8 + 512 * 8;
+  hipLaunchKernelGGL((gf2_tallskinny7_kernel<RPT>), dim3((unsigned)rblocks, (unsigned)splits), dim3(256), lds7, stream, A, lda, B, ldb, C,
+                     ldc, m, l, n, accumulate, sps, atomic, vec_ok);
+  return hipGetLastError();
+}
+
 // n <= 256; returns hipErrorInvalidValue otherwise
 // Which kernel takes a tall-skinny product (n <= 256; measured cold at 2^20 x 256, us):
 //   l <= 256, n <= 64        gf2_tallskinny6_kernel<1>   4-bit tables, small streaming workgroups       11.8  (generation kernel 15.0)
@@ -3193,7 +3326,7 @@ extern "C" hipError_t gf2k_va(const u64 *A, long long lda, const u64 *B, long lo
   const int wn = (n + 63) >> 6;
   const int gx = (wn + 255) / 256;
   int splits = (2048 + gx - 1) / gx;  // aim at ~2048 blocks
-  int rps = (l + splits - 1) / splits;
+  int rps = ((l + splits - 1) / splits + 63) & ~63;  // whole words of A per split
   if (rps < 64) rps = 64;
   splits = (l + rps - 1) / rps;
   dim3 grid(gx, splits), block(256);

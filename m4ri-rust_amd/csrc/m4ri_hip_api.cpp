@@ -946,9 +946,27 @@ static bool widevec_shape(int m, int l, int n) {
   //   n  = 32: l = 4096 1.27 / 0.74, 20000 0.31 / 0.59, 65536 0.30 / 0.97        n = 64: l = 20000 0.63 / 1.04, 65536 0.61 / 1.84
   // (three instructions per vector and word bound it from 9 vectors on; a row per wave needs rows to fill the chip)
   if (m <= 8) return l >= 8192 && (n <= 32 || m >= 4);  // against the v*A kernel: 8 x 65536 x 1 74 -> 9 us, x 64 120 -> 62 us
-  if (n <= 16) return l >= 2048;
-  if (n <= 32) return l >= 8192;
+  static const int minl16 = env_int("M4RI_HIP_WIDEVEC_MINL16", 2048), minl32 = env_int("M4RI_HIP_WIDEVEC_MINL32", 8192);
+  // rows of 768 ... 2047 bits: up to 8 vectors and not too many rows (20000 x 1000 x 8: 19 us against 30 for the tile kernel and 44
+  // for the generation table kernel; at 2^20 rows the table kernel wins: 86 us against 220)
+  if (n <= 8 && l >= 768 && m <= 131072) return true;
+  if (n <= 16) return l >= minl16;
+  if (n <= 32) return l >= minl32;
   return l >= 16384 && m >= 8192;
+}
+// up to 64 vectors against a long inner dimension through 4-bit tables rebuilt per 512-bit slab (gf2_tallskinny7_kernel)
+static bool ts_long_shape(int m, int l, int n) {
+  static const int mode = env_int("M4RI_HIP_TS7", 1);  // 0 off, 1 by rule, 2 whenever it can (A/B)
+  if (!mode || n > 64 || l <= 256 || m < 1) return false;
+  if (mode == 2) return true;
+  // Where it wins (tools/ab_ts7.sh, profiles/r03_ts7_ab.txt: its time does not depend on n -- 65536^2: 0.21 ms, 2^20 x 4096: 0.18 ms --
+  // while the wave-per-row kernel costs three instructions per vector and word and the tile kernel computes 512 columns):
+  //   17-64 vectors: from 2048-bit rows on, or from 16384 rows on (65536^2 x 64: 0.72 -> 0.21 ms; 4096 x 65536 x 64: 92 -> 27 us)
+  //    9-16 vectors: many rows and rows of at most 8192 bits (65536 x 4096 x 16: 32 -> 19 us); longer rows stream faster per wave
+  //    1-8  vectors: many short rows (2^20 x 1000 x 8: 88 -> 49 us, where the generation table kernel used to run)
+  if (n > 16) return l >= 2048 || m >= 16384;
+  if (n > 8) return m >= 65536 && l <= 8192;
+  return m >= 65536 && l <= 2048;
 }
 static int mul_widevec(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int accumulate, hipStream_t s) {
   const int m = A->nrows, l = A->ncols, n = B->ncols;
@@ -970,11 +988,18 @@ static int mul_m4rm_plain(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int
     if (!accumulate) HIP_TRY(gf2k_xor2d(C->data, C->ld, nullptr, 0, nullptr, 0, m, words_of(n), s));
     return 0;
   }
+  if (ts_long_shape(m, l, n)) {
+    HIP_TRY(gf2k_tallskinny_long(A->data, A->ld, B->data, B->ld, C->data, C->ld, m, l, n, accumulate, s));
+    return 0;
+  }
   if (widevec_shape(m, l, n)) return mul_widevec(C, A, B, accumulate, s);  // few columns, long rows: a wave per row
   // tall and skinny: tables over ALL of B, A streamed once.  Built for short inner dimensions (a batch of LPN samples: l = 256);
   // with a long one the tables are rebuilt every 256 bits and the tile kernel with split-K is ~10x faster (65536 x 65600 x 64:
   // 6.4 ms here), so the border strips of peeled products do not come this way
-  if (n <= 256 && m >= 2048 && (n > 64 || l > 64) && l <= 1024) {
+  // the table kernels for 256 < l <= 1024 give a workgroup 4096 rows: below 2^19 rows they leave most of the chip idle
+  // (65536 x 1000 x 64: 44 us whatever the row count, against 15-45 us through the tile kernel; tools/ab_ts_long.sh)
+  static const int ts_long_min_rows = env_int("M4RI_HIP_TS_LONG_MIN_ROWS", 524288);
+  if (n <= 256 && m >= (l > 256 ? ts_long_min_rows : 2048) && (n > 64 || l > 64) && l <= 1024) {
     HIP_TRY(gf2k_tallskinny(A->data, A->ld, B->data, B->ld, C->data, C->ld, m, l, n, accumulate, s));
     return 0;
   }
@@ -1306,6 +1331,11 @@ static int mul_naive_dev(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int 
   const int m = A->nrows, l = A->ncols, n = B->ncols;
   if (n > 64 || l == 0) return mul_m4rm_plain(C, A, B, accumulate, s);
   if (m == 0 || n == 0) return 0;
+  if (ts_long_shape(m, l, n)) {
+    HIP_TRY(gf2k_tallskinny_long(A->data, A->ld, B->data, B->ld, C->data, C->ld, m, l, n, accumulate, s));
+    if (sync_free && hipStreamSynchronize(s) != hipSuccess) return fail(hipGetLastError(), "hipStreamSynchronize");
+    return 0;
+  }
   if (widevec_shape(m, l, n)) {  // long rows: a wave per row
     if (int rc = mul_widevec(C, A, B, accumulate, s)) return rc;
     if (sync_free && hipStreamSynchronize(s) != hipSuccess) return fail(hipGetLastError(), "hipStreamSynchronize");

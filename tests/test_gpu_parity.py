@@ -816,11 +816,13 @@ def test_tall_skinny_shapes(pkg, dev, m, l, n):
 
 @pytest.mark.parametrize("m,l,n", [(300, 5000, 1), (1000, 70001, 1), (4097, 1500, 8), (2500, 3000, 33), (5000, 2049, 64), (64, 100000, 17),
                                    (16, 600, 3), (2100, 513, 5), (3000, 1025, 9), (777, 8192, 32), (4096, 4096, 2), (150, 200000, 40),
-                                   (70000, 1100, 1), (33, 1000000, 4)])
+                                   (70000, 1100, 1), (33, 1000000, 4), (70000, 600, 7), (66000, 1000, 50), (140000, 300, 64), (20000, 5000, 12),
+                                   (66000, 2049, 10), (1100000, 513, 3)])
 def test_wide_matrix_times_few_vectors(pkg, dev, m, l, n):
     """`&A * &v` and blocks of up to 64 vectors on a matrix with LONG rows (mul_slice, binary_matrix.rs:416-431,528-542, on shapes
-    the reference's callers reach with a large square A): a wave per row, the inner dimension in slabs, 32 vectors per pass,
-    ragged everything; every algorithm selector gives the oracle's bits, with and without accumulation."""
+    the reference's callers reach with a large square A): the wave-per-row kernel (inner dimension in slabs, 32 vectors per pass)
+    and the slab-wise 4-bit table kernel (inner dimension divided among workgroups, atomic XOR into C), ragged everything;
+    every algorithm selector gives the oracle's bits, with and without accumulation."""
     a, b = g.random_words(m, l, 500 + n), g.random_words(l, n, 501 + (l % 97))
     A, B = dev.DMat.from_words(a, l), dev.DMat.from_words(b, n)
     ref = g.o_mul_m4rm(a, b, m, l, n, k=8)
@@ -837,6 +839,13 @@ def test_wide_matrix_times_few_vectors(pkg, dev, m, l, n):
     C = dev.DMat.from_words(c0, n)
     dev.mul_nt(A, Bt, C, accumulate=True)
     assert np.array_equal(C.to_words(), ref ^ c0), (m, l, n, "nt accumulate")
+    if m <= 70000:  # an odd row stride (caller-owned memory): the 16-byte loads of the fast paths do not apply
+        import torch
+        wl = (l + 63) // 64
+        t = torch.zeros((m, wl + 1 + (wl & 1)), dtype=torch.int64, device="cuda")
+        t[:, :wl] = torch.from_numpy(a.view(np.int64)).cuda()
+        Aodd = dev.DMat.wrap(t.data_ptr(), m, l, t.shape[1], keep=t)
+        assert np.array_equal(dev.mul(Aodd, B, algo="auto").to_words(), ref), (m, l, n, "odd row stride")
     if n == 1 and m * l <= 1 << 27:  # the friendly layer's matrix x vector on host matrices
         M = pkg.BinMatrix.from_words(a, l)
         v = pkg.BinVector.from_bools([bool(int(b[i, 0]) & 1) for i in range(l)])
