@@ -2229,10 +2229,13 @@ __global__ __launch_bounds__(NT) void gf2_tallskinny4_kernel(const u64 *__restri
 template <int M>
 __global__ __launch_bounds__(256) void gf2_va_kernel(const u64 *__restrict__ A, long long lda,
                                                      const u64 *__restrict__ B, long long ldb, u64 *__restrict__ C,
-                                                     long long ldc, int m, int l, int n, int rows_per_split) {
+                                                     long long ldc, int m, int l, int n, int rows_per_split, int wshift) {
   // rows_per_split is a multiple of 64: a split starts on a word of A.  The rows of B are fetched eight at a time (one row
-  // per iteration left every load exposed: 8 x 64 x 64 took 26 us, most of it 64 dependent latencies)
-  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  // per iteration left every load exposed: 8 x 64 x 64 took 26 us, most of it 64 dependent latencies).  A narrow B does not
+  // fill a workgroup with column words: its 256 threads are 2^wshift words x (256 >> wshift) interleaved 64-row blocks of
+  // the split (8 x 65536 x 256: four of 256 threads had work, 58 us)
+  const int lanes_w = 1 << wshift, sub = threadIdx.x >> wshift, nsub = 256 >> wshift;
+  const int w = blockIdx.x * lanes_w + (threadIdx.x & (lanes_w - 1));
   const int wn = (n + 63) >> 6;
   const int t0 = blockIdx.y * rows_per_split;
   const int t1 = min(l, t0 + rows_per_split);
@@ -2240,7 +2243,7 @@ __global__ __launch_bounds__(256) void gf2_va_kernel(const u64 *__restrict__ A, 
 #pragma unroll
   for (int i = 0; i < M; ++i) acc[i] = 0;
   if (w < wn) {
-    for (int tb = t0; tb < t1; tb += 64) {
+    for (int tb = t0 + 64 * sub; tb < t1; tb += 64 * nsub) {
       u64 aw[M];
 #pragma unroll
       for (int i = 0; i < M; ++i) aw[i] = i < m ? A[(long long)i * lda + (tb >> 6)] : 0;  // wave-uniform
@@ -2254,6 +2257,23 @@ __global__ __launch_bounds__(256) void gf2_va_kernel(const u64 *__restrict__ A, 
           for (int i = 0; i < M; ++i) acc[i] ^= bw[u] & (0ull - ((aw[i] >> (tt + u)) & 1ull));
       }
     }
+  }
+  // the interleaved blocks of a workgroup meet in LDS: one atomic per (workgroup, word, row), not one per thread
+  __shared__ u64 red[M][256];
+  const int nact = min(nsub, (max(t1 - t0, 0) + 63) >> 6);  // interleaved blocks that had rows at all
+  if (nact > 1) {
+    if (sub < nact) {
+#pragma unroll
+      for (int i = 0; i < M; ++i) red[i][threadIdx.x] = acc[i];
+    }
+    __syncthreads();
+    if (sub == 0) {
+      for (int s2 = 1; s2 < nact; ++s2)
+#pragma unroll
+        for (int i = 0; i < M; ++i) acc[i] ^= red[i][threadIdx.x + s2 * lanes_w];
+    }
+  }
+  if (w < wn && sub == 0) {
     const u64 maskC = (n & 63) ? ((1ull << (n & 63)) - 1) : ~0ull;
 #pragma unroll
     for (int i = 0; i < M; ++i)
@@ -3324,16 +3344,23 @@ extern "C" hipError_t gf2k_va(const u64 *A, long long lda, const u64 *B, long lo
   // C must already hold the value to accumulate into (zero for a plain product)
   if (m <= 0 || n <= 0 || l <= 0) return hipSuccess;
   const int wn = (n + 63) >> 6;
-  const int gx = (wn + 255) / 256;
-  int splits = (2048 + gx - 1) / gx;  // aim at ~2048 blocks
-  int rps = ((l + splits - 1) / splits + 63) & ~63;  // whole words of A per split
-  if (rps < 64) rps = 64;
+  int wshift = 8;  // threads of a workgroup along the words of a row of B: 256, or the power of two that covers a narrow row
+  while (wshift > 0 && (1 << (wshift - 1)) >= wn) --wshift;
+  const int lanes_w = 1 << wshift, nsub = 256 >> wshift;
+  const int gx = (wn + lanes_w - 1) / lanes_w;
+  // aim at ~2048 blocks, but at no less than 16 KiB of B per block (every block ends in atomics on the few words of a narrow C)
+  long long want = ((long long)l * wn * 8) >> 14;
+  want = want < 64 ? 64 : want > 2048 ? 2048 : want;
+  int splits = (int)((want + gx - 1) / gx);
+  const int unit = 64 * nsub;         // a split gives every interleaved block of 64 rows its share
+  int rps = ((l + splits - 1) / splits + unit - 1) / unit * unit;
+  if (rps < unit) rps = unit;
   splits = (l + rps - 1) / rps;
   dim3 grid(gx, splits), block(256);
   for (int i0 = 0; i0 < m; i0 += 8) {
     const int mm = (m - i0 < 8) ? (m - i0) : 8;
     hipLaunchKernelGGL((gf2_va_kernel<8>), grid, block, 0, stream, A + (long long)i0 * lda, lda, B, ldb,
-                       C + (long long)i0 * ldc, ldc, mm, l, n, rps);
+                       C + (long long)i0 * ldc, ldc, mm, l, n, rps, wshift);
   }
   return hipGetLastError();
 }
