@@ -992,6 +992,18 @@ static int mul_m4rm_plain(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int
     HIP_TRY(gf2k_tallskinny_long(A->data, A->ld, B->data, B->ld, C->data, C->ld, m, l, n, accumulate, s));
     return 0;
   }
+  // 65-128 columns against a long inner dimension: two passes of that kernel, one per word column of B and C, beat the tile
+  // kernel, which finds a single column tile here and a handful of row tiles (65536^2 x 128: 0.77 -> 0.35 ms; 20000^2 x 128: 142
+  // -> 59 us; 65536 x 8192 x 128: 193 -> 48 us).  Three or four passes do not (65536^2 x 200: 0.81 against 0.77 ms).
+  {
+    static const int mp = env_int("M4RI_HIP_TS7_MULTIPASS", 1);
+    const int passes = (n + 63) / 64;
+    if (mp && n > 64 && n <= 128 && m >= 256 && l >= 8192 && ts_long_shape(m, l, 64)) {
+      for (int j = 0; j < passes; ++j)
+        HIP_TRY(gf2k_tallskinny_long(A->data, A->ld, B->data + j, B->ld, C->data + j, C->ld, m, l, std::min(64, n - 64 * j), accumulate, s));
+      return 0;
+    }
+  }
   if (widevec_shape(m, l, n)) return mul_widevec(C, A, B, accumulate, s);  // few columns, long rows: a wave per row
   // tall and skinny: tables over ALL of B, A streamed once.  Built for short inner dimensions (a batch of LPN samples: l = 256);
   // with a long one the tables are rebuilt every 256 bits and the tile kernel with split-K is ~10x faster (65536 x 65600 x 64:

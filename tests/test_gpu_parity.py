@@ -852,6 +852,23 @@ def test_wide_matrix_times_few_vectors(pkg, dev, m, l, n):
         assert (M * v).to_bools() == [bool(int(ref[i, 0]) & 1) for i in range(m)]
 
 
+@pytest.mark.parametrize("m,l,n", [(3000, 9000, 100), (5000, 8192, 128), (300, 40000, 200), (2049, 33000, 256), (70000, 8200, 65), (1000, 70000, 129)])
+def test_narrow_products_with_long_rows_in_passes(dev, m, l, n):
+    """65-256 columns against a long inner dimension (brilliantrussian.rs:210-216 on a narrow B): one pass of the slab-wise table
+    kernel per word column where that beats the single column tile of the tile kernel; bits of the oracle, accumulate form too."""
+    a, b = g.random_words(m, l, 600 + n), g.random_words(l, n, 601)
+    A, B = dev.DMat.from_words(a, l), dev.DMat.from_words(b, n)
+    rows = np.unique(np.concatenate([np.arange(0, m, 37), [m - 1]]))
+    ref = g.o_mul_m4rm(np.ascontiguousarray(a[rows]), b, len(rows), l, n, k=8)
+    got = dev.mul(A, B, algo="m4rm")
+    assert np.array_equal(got.to_words()[rows], ref), (m, l, n)
+    assert dev.equal(got, dev.mul(A, B, algo="auto"))
+    c0 = g.random_words(m, n, 602)
+    C = dev.DMat.from_words(c0, n)
+    dev.mul(A, B, C, accumulate=True, algo="m4rm")
+    assert np.array_equal(C.to_words()[rows], c0[rows] ^ ref), (m, l, n, "accumulate")
+
+
 @pytest.mark.parametrize("m,l,n,levels", [(8192, 8192, 8192, 3), (8192, 8192, 8192, 4), (8192, 8192, 8192, 5), (8192, 8192, 8192, 6),
                                           (4160, 8192, 4096, 5), (4096, 2048, 6144, 4), (1000 * 8, 3072, 1024, 3), (2048, 4096, 2048, 4)])
 def test_strassen_level_plans(dev, monkeypatch, m, l, n, levels):
