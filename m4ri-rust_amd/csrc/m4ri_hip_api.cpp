@@ -1020,6 +1020,32 @@ static int mul_m4rm_plain(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int
     HIP_TRY(gf2k_va(A->data, A->ld, B->data, B->ld, C->data, C->ld, m, l, n, s));
     return 0;
   }
+  // 9 to 64 rows against a big B: the tile kernel would build its 256-entry tables for 64 rows (64 x 65536 x 65536: 0.86 ms for
+  // 0.1 ms worth of B).  Transposed, the product is n rows of l bits times m <= 64 vectors -- the slab table kernel's shape:
+  // C^T = B^T A^T, with B transposed once (one more pass over B) and the small operands transposed in and out.
+  {
+    static const int few = env_int("M4RI_HIP_FEW_ROWS_T", 1);
+    // (only for a B much taller than wide: the transposition of B costs a pass at 1.7 TB/s -- 64 x 65536 x 4096: 90 -> 62 us, but
+    // 64 x 20000 x 20000: 93 -> 151 us and 64 x 65536 x 65536: 0.86 -> 0.81 ms)
+    if (few && m > 8 && m <= 64 && n >= 1024 && l >= 8 * (long long)n && (long long)l * n >= (1ll << 26) && ts_long_shape(n, l, 64)) {
+      const long long ldl = (words_of(l) + 1) & ~1ll, wn = words_of(n), ldn = (wn + 1) & ~1ll;
+      const size_t wBt = (size_t)n * ldl, wAt = (size_t)l * 2, wCt = (size_t)n * 2, wTmp = accumulate ? (size_t)m * ldn : 0;
+      void *ws = nullptr;
+      if (stream_workspace(s, (wBt + wAt + wCt + wTmp) * sizeof(u64), &ws) == 0) {
+        u64 *Bt = static_cast<u64 *>(ws), *At = Bt + wBt, *Ct = At + wAt, *Tmp = Ct + wCt;
+        HIP_TRY(gf2k_transpose(Bt, ldl, B->data, B->ld, l, n, s));   // n x l
+        HIP_TRY(gf2k_transpose(At, 2, A->data, A->ld, m, l, s));     // l x m (one word per row)
+        HIP_TRY(gf2k_tallskinny_long(Bt, ldl, At, 2, Ct, 2, n, l, m, 0, s));  // n x m
+        if (accumulate) {
+          HIP_TRY(gf2k_transpose(Tmp, ldn, Ct, 2, n, m, s));         // m x n
+          HIP_TRY(gf2k_xor2d(C->data, C->ld, C->data, C->ld, Tmp, ldn, m, (int)wn, s));
+        } else {
+          HIP_TRY(gf2k_transpose(C->data, C->ld, Ct, 2, n, m, s));
+        }
+        return 0;
+      }
+    }
+  }
   // A tall product may first copy A into the row-group-packed layout (one extra pass over A, ~0.2 ms per GiB) so that the
   // paired tile kernels fetch it with contiguous loads: taken when the modelled launch gains more than the pass costs
   const long long wp = (words_of(l) + 1) & ~1ll, prow = ((long long)m + 63) & ~63ll;

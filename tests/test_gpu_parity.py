@@ -852,6 +852,21 @@ def test_wide_matrix_times_few_vectors(pkg, dev, m, l, n):
         assert (M * v).to_bools() == [bool(int(ref[i, 0]) & 1) for i in range(m)]
 
 
+@pytest.mark.parametrize("m,l,n", [(9, 4096, 16384), (64, 70000, 1024), (33, 40001, 2050), (17, 66000, 4099), (64, 4096, 16385)])
+def test_few_rows_times_a_big_matrix(dev, m, l, n):
+    """9 to 64 rows against a big B (a block of row vectors times a matrix, brilliantrussian.rs:210-216 with a short A): computed
+    transposed, C^T = B^T A^T, through the slab-wise table kernel; the oracle's bits, accumulate form too."""
+    a, b = g.random_words(m, l, 700 + m), g.random_words(l, n, 701)
+    A, B = dev.DMat.from_words(a, l), dev.DMat.from_words(b, n)
+    ref = g.o_mul_m4rm(a, b, m, l, n, k=8)
+    for algo in ("m4rm", "auto"):
+        assert np.array_equal(dev.mul(A, B, algo=algo).to_words(), ref), (m, l, n, algo)
+    c0 = g.random_words(m, n, 702)
+    C = dev.DMat.from_words(c0, n)
+    dev.mul(A, B, C, accumulate=True, algo="m4rm")
+    assert np.array_equal(C.to_words(), c0 ^ ref), (m, l, n, "accumulate")
+
+
 @pytest.mark.parametrize("m,l,n", [(3000, 9000, 100), (5000, 8192, 128), (300, 40000, 200), (2049, 33000, 256), (70000, 8200, 65), (1000, 70000, 129)])
 def test_narrow_products_with_long_rows_in_passes(dev, m, l, n):
     """65-256 columns against a long inner dimension (brilliantrussian.rs:210-216 on a narrow B): one pass of the slab-wise table
