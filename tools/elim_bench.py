@@ -23,6 +23,10 @@ def main():
     ap.add_argument("--cpu-max", type=int, default=8192)
     ap.add_argument("--reps", type=int, default=2)
     args = ap.parse_args()
+    if os.environ.get("AB_LIB"):  # A/B of two builds on one box: load this shared object instead
+        import m4ri_rust_amd  # noqa
+        from m4ri_rust_amd import _lib
+        _lib.LIB_PATH = os.environ["AB_LIB"]
     import __graft_entry__ as ge
     ge.build()
     import m4ri_rust_amd as pkg  # noqa: F401
