@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A grid of product shapes against a crude roofline -- max(operand bytes / 5 TB/s, bit-MACs / 7e15 per second of the 512-column tile
 kernel, 6 us) -- to find shapes whose kernel is the wrong one (development tool).
-    python tools/shape_holes.py [threshold=3]"""
+    python tools/shape_holes.py [threshold=3] [b]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,9 +9,14 @@ import torch
 import m4ri_rust_amd  # noqa
 from m4ri_rust_amd import device as dev
 thr = float(sys.argv[1]) if len(sys.argv) > 1 else 3.0
-dims_m = [1, 8, 64, 1000, 4096, 20000, 65536]
-dims_l = [64, 256, 1000, 4096, 20000, 65536]
-dims_n = [1, 8, 64, 200, 256, 1000, 4096, 20000, 65536]
+if len(sys.argv) > 2 and sys.argv[2] == "b":  # a second grid between the points of the first
+    dims_m = [16, 128, 300, 2048, 9000, 33000, 200000]
+    dims_l = [128, 600, 2048, 9000, 33000, 200000]
+    dims_n = [16, 40, 100, 300, 600, 2048, 9000, 33000]
+else:
+    dims_m = [1, 8, 64, 1000, 4096, 20000, 65536]
+    dims_l = [64, 256, 1000, 4096, 20000, 65536]
+    dims_n = [1, 8, 64, 200, 256, 1000, 4096, 20000, 65536]
 rows = []
 for m in dims_m:
     for l in dims_l:
