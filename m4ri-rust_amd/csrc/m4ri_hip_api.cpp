@@ -1020,27 +1020,33 @@ static int mul_m4rm_plain(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int
     HIP_TRY(gf2k_va(A->data, A->ld, B->data, B->ld, C->data, C->ld, m, l, n, s));
     return 0;
   }
-  // 9 to 64 rows against a big B: the tile kernel would build its 256-entry tables for 64 rows (64 x 65536 x 65536: 0.86 ms for
-  // 0.1 ms worth of B).  Transposed, the product is n rows of l bits times m <= 64 vectors -- the slab table kernel's shape:
-  // C^T = B^T A^T, with B transposed once (one more pass over B) and the small operands transposed in and out.
+  // 9 to 128 rows against a tall B: the tile kernel would build its 256-entry tables for a handful of rows (64 x 65536 x 4096:
+  // 90 us; 16 x 200000 x 600: 144 us for 15 MB of B).  Transposed, the product is n rows of l bits times at most 64 vectors per
+  // pass -- the slab table kernel's shape: C^T = B^T A^T, with B transposed once (one more pass over B) and the small operands
+  // transposed in and out.  Only for a B much taller than wide: the transposition of B runs at 1.7-1.9 TB/s (64 x 20000 x 20000:
+  // 93 -> 151 us, 64 x 65536 x 65536: 0.86 -> 0.81 ms).
   {
     static const int few = env_int("M4RI_HIP_FEW_ROWS_T", 1);
-    // (only for a B much taller than wide: the transposition of B costs a pass at 1.7 TB/s -- 64 x 65536 x 4096: 90 -> 62 us, but
-    // 64 x 20000 x 20000: 93 -> 151 us and 64 x 65536 x 65536: 0.86 -> 0.81 ms)
-    if (few && m > 8 && m <= 64 && n >= 1024 && l >= 8 * (long long)n && (long long)l * n >= (1ll << 26) && ts_long_shape(n, l, 64)) {
-      const long long ldl = (words_of(l) + 1) & ~1ll, wn = words_of(n), ldn = (wn + 1) & ~1ll;
-      const size_t wBt = (size_t)n * ldl, wAt = (size_t)l * 2, wCt = (size_t)n * 2, wTmp = accumulate ? (size_t)m * ldn : 0;
+    const bool tall = (n >= 1024 && l >= 8 * (long long)n && (long long)l * n >= (1ll << 26) && m <= 64) ||
+                      (n > 64 && n <= 1024 && l >= 16384 && l >= 8 * (long long)n && (long long)l * n >= (1ll << 23));
+    if (few && m > 8 && m <= 128 && tall) {
+      const int passes = (m + 63) / 64;
+      const long long ldl = (words_of(l) + 1) & ~1ll, wn = words_of(n), ldn = (wn + 1) & ~1ll, ldct = (passes + 1) & ~1ll;
+      const size_t wBt = (size_t)n * ldl, wAt = (size_t)l * 2, wCt = (size_t)n * ldct, wTmp = accumulate ? (size_t)m * ldn : 0;
       void *ws = nullptr;
       if (stream_workspace(s, (wBt + wAt + wCt + wTmp) * sizeof(u64), &ws) == 0) {
         u64 *Bt = static_cast<u64 *>(ws), *At = Bt + wBt, *Ct = At + wAt, *Tmp = Ct + wCt;
-        HIP_TRY(gf2k_transpose(Bt, ldl, B->data, B->ld, l, n, s));   // n x l
-        HIP_TRY(gf2k_transpose(At, 2, A->data, A->ld, m, l, s));     // l x m (one word per row)
-        HIP_TRY(gf2k_tallskinny_long(Bt, ldl, At, 2, Ct, 2, n, l, m, 0, s));  // n x m
+        HIP_TRY(gf2k_transpose(Bt, ldl, B->data, B->ld, l, n, s));  // n x l
+        for (int p = 0; p < passes; ++p) {
+          const int mp = std::min(64, m - 64 * p);
+          HIP_TRY(gf2k_transpose(At, 2, A->data + (long long)64 * p * A->ld, A->ld, mp, l, s));  // l x mp (one word per row)
+          HIP_TRY(gf2k_tallskinny_long(Bt, ldl, At, 2, Ct + p, ldct, n, l, mp, 0, s));           // word p of the n rows of C^T
+        }
         if (accumulate) {
-          HIP_TRY(gf2k_transpose(Tmp, ldn, Ct, 2, n, m, s));         // m x n
+          HIP_TRY(gf2k_transpose(Tmp, ldn, Ct, ldct, n, m, s));  // m x n
           HIP_TRY(gf2k_xor2d(C->data, C->ld, C->data, C->ld, Tmp, ldn, m, (int)wn, s));
         } else {
-          HIP_TRY(gf2k_transpose(C->data, C->ld, Ct, 2, n, m, s));
+          HIP_TRY(gf2k_transpose(C->data, C->ld, Ct, ldct, n, m, s));
         }
         return 0;
       }

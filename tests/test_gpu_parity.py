@@ -852,7 +852,8 @@ def test_wide_matrix_times_few_vectors(pkg, dev, m, l, n):
         assert (M * v).to_bools() == [bool(int(ref[i, 0]) & 1) for i in range(m)]
 
 
-@pytest.mark.parametrize("m,l,n", [(9, 4096, 16384), (64, 70000, 1024), (33, 40001, 2050), (17, 66000, 4099), (64, 4096, 16385)])
+@pytest.mark.parametrize("m,l,n", [(9, 4096, 16384), (64, 70000, 1024), (33, 40001, 2050), (17, 66000, 4099), (64, 4096, 16385),
+                                   (16, 200000, 600), (128, 150001, 100), (100, 20000, 300), (65, 33000, 700), (127, 16384, 65)])
 def test_few_rows_times_a_big_matrix(dev, m, l, n):
     """9 to 64 rows against a big B (a block of row vectors times a matrix, brilliantrussian.rs:210-216 with a short A): computed
     transposed, C^T = B^T A^T, through the slab-wise table kernel; the oracle's bits, accumulate form too."""
