@@ -1958,22 +1958,25 @@ __global__ __launch_bounds__(256) void gf2_tallskinny6_kernel(const u64 *__restr
 // 8-byte entries (16 KiB; a table spans every LDS bank pair once: any mix of entries is conflict-free) and folds two lookups
 // per v_bitop3_b32 pair.  The build of a slab's tables is 8 entries per thread, ~6 % of the lookups at four rows per lane.
 // ---------------------------------------------------------------------------------------------
-template <int RPT>
+template <int RPT, int NW>  // NW = words per row of C (n <= 64 NW): entries of 8 NW bytes, 16 KiB x NW of tables
 __global__ __launch_bounds__(256) void gf2_tallskinny7_kernel(const u64 *__restrict__ A, long long lda, const u64 *__restrict__ B,
                                                               long long ldb, u64 *__restrict__ C, long long ldc, int m, int l,
                                                               int n, int accumulate, int slabs_per_split, int atomic, int vec_ok) {
+  static_assert(NW == 1 || NW == 2, "a 16-entry table must not span more than the 64 banks");
   extern __shared__ __align__(16) unsigned char lds[];
-  constexpr int EB = 8, TB = 16 * EB;            // bytes per entry / per table
-  u64 *bst = reinterpret_cast<u64 *>(lds + 128 * TB);  // the 512 rows of B of the slab (one word each)
+  constexpr int EB = 8 * NW, TB = 16 * EB;       // bytes per entry / per table
+  u64 *bst = reinterpret_cast<u64 *>(lds + 128 * TB);  // the 512 rows of B of the slab (NW words each)
   const int tid = threadIdx.x;
-  const int wl = (l + 63) >> 6;
+  const int wl = (l + 63) >> 6, wn = (n + 63) >> 6;
   const u64 maskC = (n & 63) ? ((1ull << (n & 63)) - 1) : ~0ull;
   const int nslabs = (l + 511) >> 9;
   const int slab0 = blockIdx.y * slabs_per_split, slab1 = min(nslabs, slab0 + slabs_per_split);
   const long long row0 = (long long)blockIdx.x * (256 * RPT) + tid;
-  u32 acc[RPT][2];
+  u32 acc[RPT][2 * NW];
 #pragma unroll
-  for (int r = 0; r < RPT; ++r) acc[r][0] = acc[r][1] = 0;
+  for (int r = 0; r < RPT; ++r)
+#pragma unroll
+    for (int w = 0; w < 2 * NW; ++w) acc[r][w] = 0;
   for (int slab = slab0; slab < slab1; ++slab) {
     const int w0 = slab * 8;  // first word of the slab
     // this lane's rows first: their loads are in flight across the staging and the build (words past the row read as zero;
@@ -2001,16 +2004,28 @@ __global__ __launch_bounds__(256) void gf2_tallskinny7_kernel(const u64 *__restr
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int k = slab * 512 + h * 256 + tid;
-      bst[h * 256 + tid] = k < l ? (B[(long long)k * ldb] & maskC) : 0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        u64 v = (k < l && w < wn) ? B[(long long)k * ldb + w] : 0;
+        if (w == wn - 1) v &= maskC;
+        bst[(h * 256 + tid) * NW + w] = v;
+      }
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 8; ++j) {  // 128 tables x 16 entries: entry e of table t = XOR of rows 4t + b of the slab for the set bits b of e
       const int idx = tid + 256 * j, t = idx >> 4, e = idx & 15;
-      u64 v = 0;
+      u64 v[NW];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) v ^= bst[4 * t + b] & (0ull - (u64)((e >> b) & 1));
-      *reinterpret_cast<u64 *>(lds + idx * EB) = v;
+      for (int w = 0; w < NW; ++w) v[w] = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const u64 sel = 0ull - (u64)((e >> b) & 1);
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v[w] ^= bst[(4 * t + b) * NW + w] & sel;
+      }
+#pragma unroll
+      for (int w = 0; w < NW; ++w) *reinterpret_cast<u64 *>(lds + idx * EB + 8 * w) = v[w];
     }
     __syncthreads();
 #pragma unroll
@@ -2023,9 +2038,17 @@ __global__ __launch_bounds__(256) void gf2_tallskinny7_kernel(const u64 *__restr
         for (int k = 0; k < 8; k += 2) {
           const u32 t0 = (u32)(8 * q + k) * TB, t1 = t0 + TB;
           const u32 o0 = __builtin_amdgcn_ubfe(xe, 4 * k, 8), o1 = __builtin_amdgcn_ubfe(xo, 4 * k, 8);
-          const u32x2v x = *reinterpret_cast<lds_cu32x2 *>(o0 + t0), y = *reinterpret_cast<lds_cu32x2 *>(o1 + t1);
-          asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][0]) : "v"(x.x), "v"(y.x));
-          asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][1]) : "v"(x.y), "v"(y.y));
+          if constexpr (NW == 1) {
+            const u32x2v x = *reinterpret_cast<lds_cu32x2 *>(o0 + t0), y = *reinterpret_cast<lds_cu32x2 *>(o1 + t1);
+            asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][0]) : "v"(x.x), "v"(y.x));
+            asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][1]) : "v"(x.y), "v"(y.y));
+          } else {
+            const u32x4 x = *reinterpret_cast<lds_cu32x4 *>(o0 + t0), y = *reinterpret_cast<lds_cu32x4 *>(o1 + t1);
+            asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][0]) : "v"(x.x), "v"(y.x));
+            asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][1]) : "v"(x.y), "v"(y.y));
+            asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][2]) : "v"(x.z), "v"(y.z));
+            asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[r][3]) : "v"(x.w), "v"(y.w));
+          }
         }
       }
     }
@@ -2034,14 +2057,18 @@ __global__ __launch_bounds__(256) void gf2_tallskinny7_kernel(const u64 *__restr
   for (int r = 0; r < RPT; ++r) {
     const long long row = row0 + (long long)r * 256;
     if (row < m) {
-      u64 v = (u64)acc[r][0] | ((u64)acc[r][1] << 32);
-      u64 *dst = C + row * ldc;
-      if (atomic) {
-        if (v) atomicXor(reinterpret_cast<unsigned long long *>(dst), (unsigned long long)v);
-      } else {
-        if (accumulate) v ^= *dst;
-        *dst = v;
-      }
+#pragma unroll
+      for (int w = 0; w < NW; ++w)
+        if (w < wn) {
+          u64 v = (u64)acc[r][2 * w] | ((u64)acc[r][2 * w + 1] << 32);
+          u64 *dst = C + row * ldc + w;
+          if (atomic) {
+            if (v) atomicXor(reinterpret_cast<unsigned long long *>(dst), (unsigned long long)v);
+          } else {
+            if (accumulate) v ^= *dst;
+            *dst = v;
+          }
+        }
     }
   }
 }
@@ -3176,14 +3203,15 @@ extern "C" hipError_t gf2k_widevec(const u64 *A, long long lda, const u64 *Bt, l
   return e != hipSuccess ? e : hipGetLastError();
 }
 
-// n <= 64, any l and m: 4-bit tables per 512-bit slab, the inner dimension divided among workgroups.  With more than one
+// n <= 128 (one or two words per row of C), any l and m: 4-bit tables per 512-bit slab, the inner dimension divided among workgroups.  With more than one
 // division the partial words are XORed into C atomically: C must then hold the value to accumulate into (the launcher
 // zeroes it for a plain product).
 extern "C" hipError_t gf2k_tallskinny_long(const u64 *A, long long lda, const u64 *B, long long ldb, u64 *C, long long ldc, int m,
                                            int l, int n, int accumulate, hipStream_t stream) {
   if (m <= 0 || n <= 0) return hipSuccess;
-  if (n > 64 || l <= 0) return hipErrorInvalidValue;
+  if (n > 128 || l <= 0) return hipErrorInvalidValue;
   constexpr int RPT = 4;
+  const int nwC = (n + 63) >> 6;
   const int nslabs = (l + 511) >> 9;
   const long long rblocks = ((long long)m + 256 * RPT - 1) / (256 * RPT);
   static const int want = getenv("M4RI_HIP_TS7_BLOCKS") ? atoi(getenv("M4RI_HIP_TS7_BLOCKS")) : 8192;  // (65536^2 x 64: 0.21 ms with 1024 workgroups, 0.17 with 8192)
@@ -3193,13 +3221,17 @@ extern "C" hipError_t gf2k_tallskinny_long(const u64 *A, long long lda, const u6
   splits = (nslabs + sps - 1) / sps;
   const int atomic = splits > 1;
   if (atomic && !accumulate) {
-    hipError_t e = gf2k_xor2d(C, ldc, nullptr, 0, nullptr, 0, m, 1, stream);  // zero the one word per row
+    hipError_t e = gf2k_xor2d(C, ldc, nullptr, 0, nullptr, 0, m, nwC, stream);  // zero the word(s) of every row
     if (e != hipSuccess) return e;
   }
   const int vec_ok = (lda & 1) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
-  const size_t lds7 = 128 * 16 * 8 + 512 * 8;
-  hipLaunchKernelGGL((gf2_tallskinny7_kernel<RPT>), dim3((unsigned)rblocks, (unsigned)splits), dim3(256), lds7, stream, A, lda, B, ldb, C,
-                     ldc, m, l, n, accumulate, sps, atomic, vec_ok);
+  const size_t lds7 = (size_t)(128 * 16 * 8 + 512 * 8) * nwC;
+  if (nwC == 1)
+    hipLaunchKernelGGL((gf2_tallskinny7_kernel<RPT, 1>), dim3((unsigned)rblocks, (unsigned)splits), dim3(256), lds7, stream, A, lda, B, ldb,
+                       C, ldc, m, l, n, accumulate, sps, atomic, vec_ok);
+  else
+    hipLaunchKernelGGL((gf2_tallskinny7_kernel<RPT, 2>), dim3((unsigned)rblocks, (unsigned)splits), dim3(256), lds7, stream, A, lda, B, ldb,
+                       C, ldc, m, l, n, accumulate, sps, atomic, vec_ok);
   return hipGetLastError();
 }
 

@@ -992,15 +992,15 @@ static int mul_m4rm_plain(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int
     HIP_TRY(gf2k_tallskinny_long(A->data, A->ld, B->data, B->ld, C->data, C->ld, m, l, n, accumulate, s));
     return 0;
   }
-  // 65-128 columns against a long inner dimension: two passes of that kernel, one per word column of B and C, beat the tile
-  // kernel, which finds a single column tile here and a handful of row tiles (65536^2 x 128: 0.77 -> 0.35 ms; 20000^2 x 128: 142
-  // -> 59 us; 65536 x 8192 x 128: 193 -> 48 us).  Three or four passes do not (65536^2 x 200: 0.81 against 0.77 ms).
+  // 65-128 columns against a long inner dimension: that kernel with 16-byte entries, where the tile kernel finds a single column
+  // tile and a handful of row tiles (65536^2 x 128: 0.78 -> 0.27 ms; 20000^2 x 128: 143 -> 46 us; 9000 x 33000 x 100: 126 -> 37 us).
+  // A second pass for 129-256 columns does not pay (65536^2 x 200: 0.81 against 0.78 ms; M4RI_HIP_TS7_MAXN=256 to try).
   {
     static const int mp = env_int("M4RI_HIP_TS7_MULTIPASS", 1);
-    const int passes = (n + 63) / 64;
-    if (mp && n > 64 && n <= 128 && m >= 256 && l >= 8192 && ts_long_shape(m, l, 64)) {
-      for (int j = 0; j < passes; ++j)
-        HIP_TRY(gf2k_tallskinny_long(A->data, A->ld, B->data + j, B->ld, C->data + j, C->ld, m, l, std::min(64, n - 64 * j), accumulate, s));
+    static const int maxn = env_int("M4RI_HIP_TS7_MAXN", 128);
+    if (mp && n > 64 && n <= maxn && m >= 256 && l >= 8192 && ts_long_shape(m, l, 64)) {
+      for (int c0 = 0; c0 < n; c0 += 128)
+        HIP_TRY(gf2k_tallskinny_long(A->data, A->ld, B->data + c0 / 64, B->ld, C->data + c0 / 64, C->ld, m, l, std::min(128, n - c0), accumulate, s));
       return 0;
     }
   }
