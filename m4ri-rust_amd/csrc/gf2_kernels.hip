@@ -3215,7 +3215,9 @@ extern "C" hipError_t gf2k_tallskinny_long(const u64 *A, long long lda, const u6
   const int nslabs = (l + 511) >> 9;
   const long long rblocks = ((long long)m + 256 * RPT - 1) / (256 * RPT);
   static const int want = getenv("M4RI_HIP_TS7_BLOCKS") ? atoi(getenv("M4RI_HIP_TS7_BLOCKS")) : 8192;  // (65536^2 x 64: 0.21 ms with 1024 workgroups, 0.17 with 8192)
-  long long splits = rblocks >= want ? 1 : (want + rblocks - 1) / rblocks;
+  // (two words per row of C: fewer divisions -- the atomics on a C with 32-byte rows cost more: 65536^2 x 256 0.81 ms with 8192 workgroups, 0.53 with 2048)
+  const int want_eff = nwC == 1 ? want : (want + 3) / 4;
+  long long splits = rblocks >= want_eff ? 1 : (want_eff + rblocks - 1) / rblocks;
   if (splits > nslabs) splits = nslabs;
   const int sps = (int)((nslabs + splits - 1) / splits);
   splits = (nslabs + sps - 1) / sps;

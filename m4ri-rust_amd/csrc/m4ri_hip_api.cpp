@@ -994,11 +994,12 @@ static int mul_m4rm_plain(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int
   }
   // 65-128 columns against a long inner dimension: that kernel with 16-byte entries, where the tile kernel finds a single column
   // tile and a handful of row tiles (65536^2 x 128: 0.78 -> 0.27 ms; 20000^2 x 128: 143 -> 46 us; 9000 x 33000 x 100: 126 -> 37 us).
-  // A second pass for 129-256 columns does not pay (65536^2 x 200: 0.81 against 0.78 ms; M4RI_HIP_TS7_MAXN=256 to try).
+  // A second pass for 129-256 columns pays from 32768-bit rows on (65536^2 x 256: 0.78 -> 0.53 ms; 65536 x 8192 x 256: 98 -> 125 us).
   {
     static const int mp = env_int("M4RI_HIP_TS7_MULTIPASS", 1);
-    static const int maxn = env_int("M4RI_HIP_TS7_MAXN", 128);
-    if (mp && n > 64 && n <= maxn && m >= 256 && l >= 8192 && ts_long_shape(m, l, 64)) {
+    static const int maxn = env_int("M4RI_HIP_TS7_MAXN", 256);
+    // (129-192 columns would pay a whole second pass for at most 64 of them: 20000 x 40000 x 160 148 -> 165 us)
+    if (mp && n > 64 && n <= maxn && (n <= 128 ? m >= 256 && l >= 8192 : n > 192 && m >= 4096 && l >= 32768) && ts_long_shape(m, l, 64)) {
       for (int c0 = 0; c0 < n; c0 += 128)
         HIP_TRY(gf2k_tallskinny_long(A->data, A->ld, B->data + c0 / 64, B->ld, C->data + c0 / 64, C->ld, m, l, std::min(128, n - c0), accumulate, s));
       return 0;

@@ -868,7 +868,8 @@ def test_few_rows_times_a_big_matrix(dev, m, l, n):
     assert np.array_equal(C.to_words(), c0 ^ ref), (m, l, n, "accumulate")
 
 
-@pytest.mark.parametrize("m,l,n", [(3000, 9000, 100), (5000, 8192, 128), (300, 40000, 200), (2049, 33000, 256), (70000, 8200, 65), (1000, 70000, 129)])
+@pytest.mark.parametrize("m,l,n", [(3000, 9000, 100), (5000, 8192, 128), (300, 40000, 200), (2049, 33000, 256), (70000, 8200, 65), (1000, 70000, 129),
+                                   (4100, 33000, 200), (5000, 40000, 256), (4096, 32768, 193)])
 def test_narrow_products_with_long_rows_in_passes(dev, m, l, n):
     """65-256 columns against a long inner dimension (brilliantrussian.rs:210-216 on a narrow B): one pass of the slab-wise table
     kernel per word column where that beats the single column tile of the tile kernel; bits of the oracle, accumulate form too."""
