@@ -23,7 +23,9 @@ python3 tools/elim_bench.py 2>/dev/null | grep "^n=" > $O/elim.txt
 # at most 64 vectors against long rows, few rows against a matrix (wave-per-row, slab table and v*A kernels)
 python3 tools/shape_bench.py 65536,65536,1,naive,0,50 65536,65536,1,auto,0,50 65536,65536,8,auto,0,50 65536,65536,16,auto,0,30 65536,65536,32,auto,0,30 65536,65536,64,auto,0,30 \
    1048576,4096,64,auto,0,30 1048576,1000,8,auto,0,50 4096,65536,64,auto,0,100 20000,20000,64,auto,0,100 65536,4096,16,auto,0,100 1000,1000000,1,naive,0,50 \
-   1,65536,65536,auto,0,50 8,65536,65536,auto,0,50 8,65536,256,auto,0,200 8,64,64,auto,0,500 65536,65536,200,auto,0,10 65536,8192,512,auto,0,20 2>/dev/null | grep -v amdgpu > $O/vector_paths.txt
+   1,65536,65536,auto,0,50 8,65536,65536,auto,0,50 8,65536,256,auto,0,200 8,64,64,auto,0,500 65536,65536,128,auto,0,20 65536,65536,256,auto,0,20 20000,20000,128,auto,0,50 \
+   65536,8192,512,auto,0,20 16,200000,600,auto,0,100 64,65536,4096,auto,0,50 2>/dev/null | grep -v amdgpu > $O/vector_paths.txt
+python3 tools/transpose_bench.py 2>/dev/null | grep -v amdgpu > $O/transpose.txt
 echo "timings done"
 ( cd tools && { echo "== (the first kernel a process times runs 4-5 % slow: every list below starts with a throw-away entry)";
   echo "== 343 leaves of 4096^3, packed A: legacy v7 (90), v8 with 4096 / 2048 / 1024 / 512-row tiles (9-12)"; APACK=1 ./kbench 4096 343 3 9 90 9 10 11 12;
