@@ -1029,7 +1029,7 @@ static int mul_m4rm_plain(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int
   {
     static const int few = env_int("M4RI_HIP_FEW_ROWS_T", 1);
     const bool tall = (n >= 1024 && l >= 8 * (long long)n && (long long)l * n >= (1ll << 26) && m <= 64) ||
-                      (n > 64 && n <= 1024 && l >= 16384 && l >= 8 * (long long)n && (long long)l * n >= (1ll << 23));
+                      (n > 64 && n <= 1024 && l >= 16384 && l >= 8 * (long long)n && (long long)l * n >= (1ll << 21));
     if (few && m > 8 && m <= 128 && tall) {
       const int passes = (m + 63) / 64;
       const long long ldl = (words_of(l) + 1) & ~1ll, wn = words_of(n), ldn = (wn + 1) & ~1ll, ldct = (passes + 1) & ~1ll;
