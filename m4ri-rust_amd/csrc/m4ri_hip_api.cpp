@@ -968,6 +968,17 @@ static bool ts_long_shape(int m, int l, int n) {
   if (n > 8) return m >= 65536 && l <= 8192;
   return m >= 65536 && l <= 2048;
 }
+// 9-128 rows against a B much taller than wide: computed transposed (see mul_m4rm_plain)
+static bool few_rows_t_shape(int m, int l, int n) {
+  static const int few = env_int("M4RI_HIP_FEW_ROWS_T", 1);
+  const bool tall = (n >= 1024 && l >= 8 * (long long)n && (long long)l * n >= (1ll << 26) && m <= 64) ||
+                    (n > 64 && n <= 1024 && l >= 16384 && l >= 8 * (long long)n && (long long)l * n >= (1ll << 21));
+  return few && m > 8 && m <= 128 && tall;
+}
+static size_t few_rows_t_bytes(int m, int l, int n, int accumulate) {
+  const long long ldl = (words_of(l) + 1) & ~1ll, ldn = (words_of(n) + 1) & ~1ll, ldct = ((m + 63) / 64 + 1) & ~1ll;
+  return ((size_t)n * ldl + (size_t)l * 2 + (size_t)n * ldct + (accumulate ? (size_t)m * ldn : 0)) * sizeof(u64);
+}
 static int mul_widevec(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int accumulate, hipStream_t s) {
   const int m = A->nrows, l = A->ncols, n = B->ncols;
   const long long ldbt = (words_of(l) + 1) & ~1ll;
@@ -1027,10 +1038,7 @@ static int mul_m4rm_plain(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int
   // transposed in and out.  Only for a B much taller than wide: the transposition of B runs at 1.7-1.9 TB/s (64 x 20000 x 20000:
   // 93 -> 151 us, 64 x 65536 x 65536: 0.86 -> 0.81 ms).
   {
-    static const int few = env_int("M4RI_HIP_FEW_ROWS_T", 1);
-    const bool tall = (n >= 1024 && l >= 8 * (long long)n && (long long)l * n >= (1ll << 26) && m <= 64) ||
-                      (n > 64 && n <= 1024 && l >= 16384 && l >= 8 * (long long)n && (long long)l * n >= (1ll << 21));
-    if (few && m > 8 && m <= 128 && tall) {
+    if (few_rows_t_shape(m, l, n)) {
       const int passes = (m + 63) / 64;
       const long long ldl = (words_of(l) + 1) & ~1ll, wn = words_of(n), ldn = (wn + 1) & ~1ll, ldct = (passes + 1) & ~1ll;
       const size_t wBt = (size_t)n * ldl, wAt = (size_t)l * 2, wCt = (size_t)n * ldct, wTmp = accumulate ? (size_t)m * ldn : 0;
@@ -1516,7 +1524,9 @@ extern "C" size_t gf2_mul_workspace_bytes(int m, int l, int n, int algo, int par
   if (algo == GF2_ALGO_NAIVE) return n <= 64 ? (size_t)n * ((words_of(l) + 1) & ~1) * 8 : 0;
   // a plain product may pack A (mul_m4rm_plain) and may cut tiles into segments / slices with partial tiles in scratch
   size_t plain_ws = 0;
+  if (m > 0 && ts_long_shape(m, l, n)) return 0;                                          // tables in LDS, partial words meet in C
   if (m > 0 && widevec_shape(m, l, n)) return (size_t)n * ((words_of(l) + 1) & ~1) * 8;  // the transposed vectors
+  if (m > 8 && few_rows_t_shape(m, l, n)) return few_rows_t_bytes(m, l, n, 1);           // B^T and the small transposed operands
   if (m > 0 && l > 0 && n > 64) {
     bool pack = false;
     const TilePlan tp = plain_plan(m, l, n, &pack);
