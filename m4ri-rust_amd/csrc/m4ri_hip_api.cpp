@@ -552,6 +552,13 @@ static bool older_model(int m, int l, int n, int batch, bool packed, int cfg, Ti
   c.ksplit = ks;
   c.packed = packed;
   c.t = std::ceil(wg / 256.0) * (chunks * g.cyc_per_chunk + 6000.0) / 2.4e9 + 3e-6;
+  // measured against the v8 plans on narrow products with long rows (2048 x 33000 x 600: modelled 44 us, 83 measured with 256
+  // slices; 9000 x 33000 x 300: 82 / 127 with 51; 33000 x 9000 x 300: 77 / 111 with 15; the same shapes through v8 on packed A:
+  // 39-74 us): unpacked rows of 8192 bits and more cost these kernels 1.4x (they too read a row per lane or lane group), and
+  // every slice of the inner dimension another 0.2 %
+  static const double older_long = env_int("M4RI_HIP_OLDER_LONG_PCT", 140) * 1e-2, older_ks = env_int("M4RI_HIP_OLDER_KSPLIT_PPM", 2000) * 1e-6;
+  if (!packed && l >= 8192) c.t *= older_long;
+  c.t *= 1.0 + older_ks * ks;
   if (ks > 1) {
     const double part = (double)m * (double)(((words_of(n) + 1) & ~1) * 8) * batch;
     c.ws_bytes = (size_t)(part * ks);
