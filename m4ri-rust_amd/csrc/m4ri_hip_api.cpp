@@ -1017,7 +1017,8 @@ static int mul_m4rm_plain(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int
     static const int mp = env_int("M4RI_HIP_TS7_MULTIPASS", 1);
     static const int maxn = env_int("M4RI_HIP_TS7_MAXN", 256);
     // (129-192 columns would pay a whole second pass for at most 64 of them: 20000 x 40000 x 160 148 -> 165 us)
-    if (mp && n > 64 && n <= maxn && (n <= 128 ? m >= 256 && l >= 8192 : n > 192 && m >= 4096 && l >= 32768) && ts_long_shape(m, l, 64)) {
+    static const int minl128 = env_int("M4RI_HIP_TS7_MINL128", 1000);  // (65536 x 1000 x 128: 45 -> 17 us, 262144 x 4096 x 128: 327 -> 82 us)
+    if (mp && n > 64 && n <= maxn && (n <= 128 ? m >= 256 && l >= minl128 : n > 192 && m >= 4096 && l >= 32768) && ts_long_shape(m, l, 64)) {
       for (int c0 = 0; c0 < n; c0 += 128)
         HIP_TRY(gf2k_tallskinny_long(A->data, A->ld, B->data + c0 / 64, B->ld, C->data + c0 / 64, C->ld, m, l, std::min(128, n - c0), accumulate, s));
       return 0;
