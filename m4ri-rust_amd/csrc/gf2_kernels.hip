@@ -3441,61 +3441,63 @@ extern "C" hipError_t gf2k_diff(const u64 *A, long long lda, const u64 *B, long 
 // eight 64 x 64 blocks in registers and puts word w of the 512 output rows into LDS; the output rows then leave 64 bytes
 // at a time as well.
 __global__ __launch_bounds__(512) void gf2_transpose512_kernel(u64 *__restrict__ D, long long ldd, const u64 *__restrict__ S,
-                                                               long long lds_, int rows, int cols) {
+                                                               long long lds_, int rows, int cols, int ntiles_padded) {
   __shared__ u64 sin[8][64][9];
   __shared__ u64 sout[512][9];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rr = lane >> 3, w = lane & 7;
-  // tiles in super-tiles of 8 x 8 (4096 x 4096 bits), super-tiles row by row: the ~512 tiles in flight then read AND write runs of
-  // 512 bytes per row between them (in plain row-major tile order the writes of neighbouring tiles were 8 KiB apart)
-  const int tx_n = (((cols + 63) >> 6) + 7) >> 3, ty_n = (rows + 511) >> 9;
-  const int sx_n = (tx_n + 7) >> 3;
-  int tX, tY;
-  {
-    const int b = blockIdx.x, st = b >> 6, in = b & 63;
-    tX = (st % sx_n) * 8 + (in & 7);
-    tY = (st / sx_n) * 8 + (in >> 3);
-  }
-  if (tX >= tx_n || tY >= ty_n) return;  // (whole workgroup: the grid is padded to whole super-tiles)
-  const long long R0 = (long long)tY * 512;  // first source row of the tile
-  const int C0w = tX * 8;                    // first source word column
   const int sw = (cols + 63) >> 6, dwn = (rows + 63) >> 6;
   const u64 maskS = (cols & 63) ? ((1ull << (cols & 63)) - 1) : ~0ull;
+  // tiles in super-tiles of 8 x 8 (4096 x 4096 bits), super-tiles row by row.  Workgroups b and b + 8 share an XCD, hence an
+  // L2: they take column-adjacent tiles, whose 64-byte pieces are the two halves of the same 128-byte lines (with neighbours
+  // on different XCDs every line was fetched twice: FETCH_SIZE 1.07 GB for 0.54 GB -- which halved the traffic and gained 3 %).
+  // A workgroup may walk several tiles (grid cap), which changes nothing either: the kernel is bound by neither HBM bytes nor
+  // the dispatch of its workgroups.
+  const int tx_n = (((cols + 63) >> 6) + 7) >> 3, ty_n = (rows + 511) >> 9;
+  const int sx_n = (tx_n + 7) >> 3;
+  for (int b = blockIdx.x; b < ntiles_padded; b += gridDim.x) {
+    const int st = b >> 6, in = b & 63;
+    const int tX = (st % sx_n) * 8 + (in >> 3), tY = (st / sx_n) * 8 + (in & 7);
+    if (tX >= tx_n || tY >= ty_n) continue;  // (uniform: the tile count is padded to whole super-tiles)
+    const long long R0 = (long long)tY * 512;  // first source row of the tile
+    const int C0w = tX * 8;                    // first source word column
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const long long row = R0 + 64 * wave + 8 * k + rr;
-    const int wc = C0w + w;
-    u64 v = (row < rows && wc < sw) ? S[row * lds_ + wc] : 0;
-    if (wc == sw - 1) v &= maskS;
-    sin[wave][8 * k + rr][w] = v;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    u64 x = sin[wave][lane][j];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-      const u64 mask = (d == 32)  ? 0x00000000FFFFFFFFull
-                       : (d == 16) ? 0x0000FFFF0000FFFFull
-                       : (d == 8)  ? 0x00FF00FF00FF00FFull
-                       : (d == 4)  ? 0x0F0F0F0F0F0F0F0Full
-                       : (d == 2)  ? 0x3333333333333333ull
-                                   : 0x5555555555555555ull;
-      const u64 y = __shfl_xor(x, d, 64);
-      if (lane & d)
-        x = (x & ~mask) | ((y >> d) & mask);
-      else
-        x = (x & mask) | ((y << d) & ~mask);
+    for (int k = 0; k < 8; ++k) {
+      const long long row = R0 + 64 * wave + 8 * k + rr;
+      const int wc = C0w + w;
+      u64 v = (row < rows && wc < sw) ? S[row * lds_ + wc] : 0;
+      if (wc == sw - 1) v &= maskS;
+      sin[wave][8 * k + rr][w] = v;
     }
-    sout[64 * j + lane][wave] = x;  // output row 64 j + lane of the tile, word = this wave's source row block
-  }
-  __syncthreads();
+    __syncthreads();
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int ol = 64 * wave + 8 * k + rr;             // output row inside the tile
-    const long long orow = 64ll * C0w + ol;            // = source column
-    const long long ow = R0 / 64 + w;                  // output word = source row block
-    if (orow < cols && ow < dwn) D[orow * ldd + ow] = sout[ol][w];
+    for (int j = 0; j < 8; ++j) {
+      u64 x = sin[wave][lane][j];
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        const u64 mask = (d == 32)  ? 0x00000000FFFFFFFFull
+                         : (d == 16) ? 0x0000FFFF0000FFFFull
+                         : (d == 8)  ? 0x00FF00FF00FF00FFull
+                         : (d == 4)  ? 0x0F0F0F0F0F0F0F0Full
+                         : (d == 2)  ? 0x3333333333333333ull
+                                     : 0x5555555555555555ull;
+        const u64 y = __shfl_xor(x, d, 64);
+        if (lane & d)
+          x = (x & ~mask) | ((y >> d) & mask);
+        else
+          x = (x & mask) | ((y << d) & ~mask);
+      }
+      sout[64 * j + lane][wave] = x;  // output row 64 j + lane of the tile, word = this wave's source row block
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int ol = 64 * wave + 8 * k + rr;             // output row inside the tile
+      const long long orow = 64ll * C0w + ol;            // = source column
+      const long long ow = R0 / 64 + w;                  // output word = source row block
+      if (orow < cols && ow < dwn) D[orow * ldd + ow] = sout[ol][w];
+    }
+    // (the next tile's loads into sin are behind this tile's first barrier for every wave; its stores into sout behind the second)
   }
 }
 
@@ -3506,8 +3508,11 @@ extern "C" hipError_t gf2k_transpose(u64 *D, long long ldd, const u64 *S, long l
   static const int t512 = getenv("M4RI_HIP_TRANSPOSE512") ? atoi(getenv("M4RI_HIP_TRANSPOSE512")) : 1;  // (A/B measurements)
   if (t512 && (long long)rows * cols >= (1ll << 29)) {  // from 64 MiB on: below, both operands live in the Infinity Cache and the small blocks win
     const int tx_n = (sw + 7) / 8, ty_n = (rows + 511) / 512;
-    dim3 grid((unsigned)(((tx_n + 7) / 8) * ((ty_n + 7) / 8) * 64)), block(512);
-    hipLaunchKernelGGL(gf2_transpose512_kernel, grid, block, 0, stream, D, ldd, S, lds_, rows, cols);
+    const long long ntp = (long long)((tx_n + 7) / 8) * ((ty_n + 7) / 8) * 64;
+    if (ntp > 0x7fffffffLL) return hipErrorInvalidValue;
+    static const int tgrid = getenv("M4RI_HIP_TRANSPOSE_GRID") ? atoi(getenv("M4RI_HIP_TRANSPOSE_GRID")) : (1 << 20);  // (A/B: 512-4096 workgroups walking tiles, 0.64 ms at 65536^2, against one tile each, 0.60-0.62)
+    dim3 grid((unsigned)std::min<long long>(ntp, tgrid)), block(512);
+    hipLaunchKernelGGL(gf2_transpose512_kernel, grid, block, 0, stream, D, ldd, S, lds_, rows, cols, (int)ntp);
     return hipGetLastError();
   }
   dim3 grid((sw + 3) / 4, rb), block(256);
