@@ -89,6 +89,8 @@ typedef __attribute__((address_space(3))) const u64 lds_cu64;
 typedef __attribute__((address_space(3))) u64 lds_u64;
 typedef __attribute__((address_space(3))) u32 lds_u32;
 
+#include "gf2_lpn.inc"  // gf2_lpn8_kernel / gf2_lpn256_kernel: the l <= 256 tall-skinny products (BASELINE config 5)
+
 // ---------------------------------------------------------------------------------------------
 // M4RM tile kernel v3: instruction-count-minimal form ("issue model").
 // Measured on gfx950 (tools/ubench): a SIMD issues at most one instruction per ~2.2 cycles whatever
@@ -3253,6 +3255,61 @@ extern "C" hipError_t gf2k_tallskinny(const u64 *A, long long lda, const u64 *B,
   const int nw = (n + 63) / 64;
   static const int old_only = getenv("M4RI_HIP_TALLSKINNY_OLD") ? atoi(getenv("M4RI_HIP_TALLSKINNY_OLD")) : 0;
   static const int ts6 = getenv("M4RI_HIP_TS6") ? atoi(getenv("M4RI_HIP_TS6")) : 1;
+  // ---- l <= 256 (round 4): the single-phase streaming kernels of gf2_lpn.inc.  Measured cold at 2^20 x 256 (tools/lpn_lab, us):
+  //   n <= 64         gf2_lpn8_kernel<1>    8-bit tables, 8-byte entries, 2 workgroups per CU     8.7-8.9   (4-bit kernel 11.2-13.5)
+  //   64 < n <= 128   gf2_lpn8_kernel<2>    8-bit tables, 16-byte entries                         11.3      (14.5-15.1)
+  //   128 < n <= 256  gf2_lpn256_kernel     6/6/6/7/7-bit fields, 32-byte entries, ONE phase      17.3-17.7 (two phases: 20.0-21.4)
+  // Rows per workgroup = 512 x RPT with RPT chosen so that the launch has about one workgroup per CU (two for n <= 64): with
+  // few rows a batch of 4096 per workgroup leaves most of the chip idle (65536 x 256 x 256: 14.5 us with RPT = 8, 5.4 with 1).
+  // M4RI_HIP_LPN=0 restores the round-2/3 kernels (A/B runs).
+  static const int lpn = getenv("M4RI_HIP_LPN") ? atoi(getenv("M4RI_HIP_LPN")) : 1;
+  if (l <= 256 && !old_only && lpn) {
+    const bool a16 = (lda & 1) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
+    const bool c16 = nw == 1 || ((ldc & 1) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0);
+    const int mode = (l > 192 && a16 && c16) ? (lda == 4 ? 2 : 1) : 0;
+    const int target = nw == 1 ? 512 : 256;  // workgroups wanted
+    int rpt = nw == 1 ? 4 : 8;
+    while (rpt > 1 && ((long long)m + 512LL * rpt - 1) / (512LL * rpt) < target) rpt >>= 1;
+    const unsigned grid = (unsigned)(((long long)m + 512LL * rpt - 1) / (512LL * rpt));
+    hipError_t e = hipSuccess;
+#define GF2_LPN_GO(KERNEL, LDSB)                                                                                       \
+  do {                                                                                                                 \
+    e = lds_limit_once(reinterpret_cast<const void *>(&KERNEL), (int)(LDSB));                                          \
+    if (e != hipSuccess) return e;                                                                                     \
+    hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(512), (LDSB), stream, A, lda, B, ldb, C, ldc, m, l, n, accumulate);    \
+  } while (0)
+#define GF2_LPN_RPT(NWV, MODEV)                                                                                        \
+  do {                                                                                                                 \
+    if (rpt == 8) GF2_LPN_GO((gf2_lpn8_kernel<NWV, 512, 8, MODEV, 3>), kLpn8LdsBytes(NWV));                             \
+    else if (rpt == 4) GF2_LPN_GO((gf2_lpn8_kernel<NWV, 512, 4, MODEV, 3>), kLpn8LdsBytes(NWV));                        \
+    else if (rpt == 2) GF2_LPN_GO((gf2_lpn8_kernel<NWV, 512, 2, MODEV, 2>), kLpn8LdsBytes(NWV));                        \
+    else GF2_LPN_GO((gf2_lpn8_kernel<NWV, 512, 1, MODEV, 1>), kLpn8LdsBytes(NWV));                                      \
+  } while (0)
+#define GF2_LPN256_RPT(MODEV)                                                                                          \
+  do {                                                                                                                 \
+    if (rpt == 8) GF2_LPN_GO((gf2_lpn256_kernel<512, 8, MODEV, 3, 0, 5>), kLpn256LdsBytes);                             \
+    else if (rpt == 4) GF2_LPN_GO((gf2_lpn256_kernel<512, 4, MODEV, 3, 0, 5>), kLpn256LdsBytes);                        \
+    else if (rpt == 2) GF2_LPN_GO((gf2_lpn256_kernel<512, 2, MODEV, 2, 0, 5>), kLpn256LdsBytes);                        \
+    else GF2_LPN_GO((gf2_lpn256_kernel<512, 1, MODEV, 1, 0, 5>), kLpn256LdsBytes);                                      \
+  } while (0)
+    if (nw == 1) {
+      if (mode == 2) GF2_LPN_RPT(1, 2);
+      else if (mode == 1) GF2_LPN_RPT(1, 1);
+      else GF2_LPN_RPT(1, 0);
+    } else if (nw == 2) {
+      if (mode == 2) GF2_LPN_RPT(2, 2);
+      else if (mode == 1) GF2_LPN_RPT(2, 1);
+      else GF2_LPN_RPT(2, 0);
+    } else {
+      if (mode == 2) GF2_LPN256_RPT(2);
+      else if (mode == 1) GF2_LPN256_RPT(1);
+      else GF2_LPN256_RPT(0);
+    }
+#undef GF2_LPN256_RPT
+#undef GF2_LPN_RPT
+#undef GF2_LPN_GO
+    return hipGetLastError();
+  }
   if (l <= 256 && !old_only && (ts6 & (nw == 3 ? 4 : nw))) {
     const int vec_ok = l > 192 && (lda & 1) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
     long long blocks = ((long long)m + 255) / 256;

@@ -1403,6 +1403,15 @@ static int mul_naive_dev(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int 
     return 0;
   }
   if (n > 8 && m >= 2048) return mul_m4rm_plain(C, A, B, accumulate, s);  // batch of vectors: table kernel (see there)
+  // one to eight vectors against MANY short rows (`&A * &v` on 2^20 LPN samples): the 8-bit table kernel of gf2_lpn.inc streams A
+  // with wave-contiguous non-temporal loads and costs the same whatever n <= 64 is (2^20 x 256 x 1 cold: 9.4 us through the
+  // AND / popcount kernel below, 8.7-8.9 through the tables); with fewer rows the popcount kernel's small workgroups start faster
+  static const int narrow_lpn_rows = env_int("M4RI_HIP_NARROW_LPN_ROWS", 262144);
+  if (narrow_lpn_rows > 0 && m >= narrow_lpn_rows && l <= 256 && l > 64) {
+    HIP_TRY(gf2k_tallskinny(A->data, A->ld, B->data, B->ld, C->data, C->ld, m, l, n, accumulate, s));
+    if (sync_free && hipStreamSynchronize(s) != hipSuccess) return fail(hipGetLastError(), "hipStreamSynchronize");
+    return 0;
+  }
   if ((size_t)n * words_of(l) * 8 <= 65536) {  // one launch: B is transposed into LDS by every block
     hipError_t e1 = gf2k_narrow(A->data, A->ld, B->data, B->ld, C->data, C->ld, m, l, n, accumulate, s);
     if (e1 != hipSuccess) return fail(e1, "gf2k_narrow");

@@ -3,7 +3,7 @@
 
 Which generator produced which digest (BASELINE.md section 3 parity gate):
 
-* lpn_1048576x256x{1,64,256} (BASELINE config 5, 2^20 x 256 times 256 x V): the INDEPENDENT numpy product of
+* lpn_1048576x256x{1,64,128,256} (BASELINE config 5, 2^20 x 256 times 256 x V): the INDEPENDENT numpy product of
   make_golden.py (float32 matmul of the unpacked bits, mod 2; exact: sums <= 256), computed in row chunks.
   Shares no code with oracle/ or the kernels.
 * sq_32768 and sq_65536 (BASELINE configs 3 and 4): oracle_mul_fast (oracle/gf2_oracle.c: single-thread M4RM k=8 +
@@ -84,7 +84,7 @@ def main():
     if os.path.exists(out):
         with open(out) as f:
             dig = json.load(f)
-    want = sys.argv[1:] or ["lpn_1048576x256x1", "lpn_1048576x256x64", "lpn_1048576x256x256", "sq_32768", "sq_65536"]
+    want = sys.argv[1:] or ["lpn_1048576x256x1", "lpn_1048576x256x64", "lpn_1048576x256x128", "lpn_1048576x256x256", "sq_32768", "sq_65536"]
     for name in want:
         t0 = time.time()
         dig[name] = lpn(int(name.rsplit("x", 1)[1])) if name.startswith("lpn_") else square(int(name[3:]))

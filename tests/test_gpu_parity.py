@@ -98,7 +98,7 @@ def _large_digests():
         return json.load(f)
 
 
-@pytest.mark.parametrize("v", [1, 64, 256])
+@pytest.mark.parametrize("v", [1, 64, 128, 256])
 def test_full_size_config5_lpn_digests(pkg, dev, v):
     """BASELINE config 5 at its stated size, 2^20 x 256 times 256 x V (mul_slice / mzd_mul_naive path,
     binary_matrix.rs:416-431, mzd.rs:152): the device product through all three entry points' algorithms must hash to
@@ -812,6 +812,54 @@ def test_tall_skinny_shapes(pkg, dev, m, l, n):
     C = dev.DMat.from_words(c0, n)
     dev.mul(A, B, C, accumulate=True, algo="auto")
     assert np.array_equal(C.to_words(), ref ^ c0)
+
+
+def _strided(dev, words, ncols, ld, offset_words=0):
+    """A device matrix holding `words` with row stride `ld` (caller-owned torch memory), optionally starting `offset_words` into it."""
+    import torch
+    m, w = words.shape
+    t = torch.zeros(m * ld + offset_words + 8, dtype=torch.int64, device="cuda")
+    v = t[offset_words:offset_words + m * ld].view(m, ld)
+    v[:, :w] = torch.from_numpy(words.view(np.int64)).cuda()
+    return dev.DMat.wrap(t.data_ptr() + 8 * offset_words, m, ncols, ld, keep=t)
+
+
+@pytest.mark.parametrize("m,l,n", [(300001, 256, 64), (300001, 256, 100), (300001, 256, 256), (600007, 256, 129), (600007, 256, 200),
+                                   (270000, 200, 192), (270000, 192, 256), (2048, 256, 256), (131072, 256, 37), (1048577, 256, 7 * 8 + 9)])
+def test_lpn_kernels_rows_per_workgroup(dev, m, l, n):
+    """The single-phase l <= 256 kernels (gf2_lpn8_kernel / gf2_lpn256_kernel; mzd_mul_naive as mul_slice reaches it,
+    binary_matrix.rs:416-431) choose the rows of a workgroup by the row count: 2048 ... 2^20 + 1 rows cover 1, 2, 4 and 8 row steps
+    per lane, a ragged last wave (wave-contiguous loads clamp their addresses, the swapped stores are guarded per row), every entry
+    width (64 / 128 / 129-192 / 256 columns); the oracle's bits, overwrite and accumulate."""
+    a, b = g.random_words(m, l, 900 + n), g.random_words(l, n, 901 + l)
+    A, B = dev.DMat.from_words(a, l), dev.DMat.from_words(b, n)
+    ref = g.o_mul_m4rm(a, b, m, l, n)
+    assert np.array_equal(dev.mul(A, B, algo="naive").to_words(), ref)
+    c0 = g.random_words(m, n, 902)
+    C = dev.DMat.from_words(c0, n)
+    dev.mul(A, B, C, accumulate=True, algo="m4rm")
+    assert np.array_equal(C.to_words(), ref ^ c0)
+
+
+@pytest.mark.parametrize("n", [1 * 64, 100, 128, 150, 256])
+@pytest.mark.parametrize("lda,ldc_extra,off", [(4, 0, 0), (6, 2, 0), (5, 1, 0), (4, 0, 1), (8, 4, 2)])
+def test_lpn_kernels_strides_and_alignment(dev, n, lda, ldc_extra, off):
+    """The three load / store forms of the l <= 256 kernels: contiguous A (wave-contiguous 16-byte loads and lane swaps), an even
+    row stride (16-byte loads per row), an odd stride or a base that is not 16-byte aligned (8-byte loads); C with its natural stride
+    (wave-contiguous 16-byte stores at 256 columns), a wider even one, an odd one.  l = 256 and l = 250 (the last word masked)."""
+    m = 70001
+    for l in (256, 250):
+        a, b = g.random_words(m, l, 950 + n + lda), g.random_words(l, n, 951 + off)
+        ref = g.o_mul_m4rm(a, b, m, l, n)
+        A = _strided(dev, a, l, lda, off)
+        B = dev.DMat.from_words(b, n)
+        wn = (n + 63) // 64
+        ldc = wn + ldc_extra
+        c0 = g.random_words(m, n, 952)
+        for acc in (False, True):
+            C = _strided(dev, c0, n, ldc, off)
+            dev.mul(A, B, C, accumulate=acc, algo="naive")
+            assert np.array_equal(C.to_words(), ref ^ c0 if acc else ref), (n, l, lda, ldc, off, acc)
 
 
 @pytest.mark.parametrize("m,l,n", [(300, 5000, 1), (1000, 70001, 1), (4097, 1500, 8), (2500, 3000, 33), (5000, 2049, 64), (64, 100000, 17),

@@ -220,7 +220,7 @@ def _large():
         return json.load(f)
 
 
-@pytest.mark.parametrize("v", [1, 64, 256])
+@pytest.mark.parametrize("v", [1, 64, 128, 256])
 def test_oracle_reproduces_full_size_lpn_digest(v):
     """BASELINE config 5 at 2^20 rows: the oracle's Four-Russians product hashes to the digest of the independent numpy product."""
     import hashlib
