@@ -196,6 +196,98 @@ def _extra_configs(device, torch, stream, squares=True, lpn_v=(1, 64, 128, 256))
     return out
 
 
+def _host_path(torch, sizes=(32768, 65536)):
+    """SURVEY.md section 8(d) "wall-clock end-to-end through the C ABI incl. H2D/D2H": what a Rust caller of the drop-in library
+    gets on HOST mzd_t operands (m4ri-rust/src/friendly/binary_matrix.rs:459-472 `&A * &B`, :528-542 `&A * &v`, :272-279
+    `transposed()`), each beside its PCIe floor = bytes that must cross the link / the rate this box reaches in that direction
+    (measured here on pinned buffers; uploads and downloads overlap, so the floor is the larger of the two directions).
+    Never `value`: the headline is quoted on resident operands."""
+    import m4ri_rust_amd as pkg
+    L = pkg._lib.lib()
+    out = []
+    # PCIe rates of this box, pinned host memory, 256 MiB each way
+    nb = 256 << 20
+    h = torch.empty(nb, dtype=torch.uint8).pin_memory()
+    d = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    rates = {}
+    for name, fn in (("h2d", lambda: d.copy_(h, non_blocking=True)), ("d2h", lambda: h.copy_(d, non_blocking=True))):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(4):
+            fn()
+        torch.cuda.synchronize()
+        rates[name] = 4 * nb / (time.perf_counter() - t0)
+    del h, d
+
+    def floor_ms(up, down):
+        return max(up / rates["h2d"], down / rates["d2h"]) * 1e3
+
+    def best(fn, reps=3):
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return min(ts), ts[0]
+
+    # transposed() first: the first 512 MiB destination of this process has to be pinned (nothing of that size is in the pool yet)
+    n = 65536
+    mb = n * n / 8.0
+    A = pkg.BinMatrix.random(n, n)
+    t0 = time.perf_counter()
+    T = A.transposed()
+    t_first = time.perf_counter() - t0
+    del T  # its block goes into the pool: later destinations of this size find it there
+    t_warm, _ = best(lambda: A.transposed())
+    out.append({"workload": "mzd_transpose(NULL, A) on host mzd_t, %d^2" % n, "ms": t_warm * 1e3, "first_call_ms": t_first * 1e3,
+                "pcie_floor_ms": floor_ms(mb, mb), "bytes_up": mb, "bytes_down": mb,
+                "note": "first_call_ms: the destination's 512 MiB block is pinned inside the call (hipHostMalloc); later calls find a "
+                        "pooled block; gf2_mzd_prewarm(r, c, count) moves that cost out of the first call"})
+    del A
+    for n in sizes:
+        A, B = pkg.BinMatrix.random(n, n), pkg.BinMatrix.random(n, n)
+        mb = n * n / 8.0
+
+        def mul_null():
+            L.mzd_free(L.mzd_mul(None, A.mzd, B.mzd, 0))
+        first = time.perf_counter()
+        mul_null()  # the first product of this size in the process: grows the device arenas (and pins C's block if none is pooled)
+        first = time.perf_counter() - first
+        t_null, _ = best(mul_null)
+        Cp = pkg.BinMatrix.zero(n, n)
+        t_pre, _ = best(lambda: L.mzd_mul(Cp.mzd, A.mzd, B.mzd, 0))
+        out.append({"workload": "mzd_mul(NULL, A, B, 0) on host mzd_t, %d^3 (upload A, B; product; download C)" % n, "ms": t_null * 1e3,
+                    "first_call_ms": first * 1e3, "preallocated_c_ms": t_pre * 1e3, "pcie_floor_ms": floor_ms(2 * mb, mb),
+                    "bytes_up": 2 * mb, "bytes_down": mb, "bit_ops_per_s": 2.0 * n ** 3 / t_pre})
+        del Cp, A, B
+    # `&A * &v` with 2^20 LPN samples of 256 bits, as the C calls the Rust operator makes (binary_matrix.rs:416-431 mul_slice:
+    # from_slices -> transposed -> mzd_mul_naive(NULL, A, v^T); :528-542 as_vector: transposed): A uploaded on every call, and
+    # kept on the device (gf2_mzd_cache_on_device)
+    m, l = 1 << 20, 256
+    A = pkg.BinMatrix.random(m, l)
+    vrow = pkg.BinMatrix.random(1, l)
+
+    def a_times_v():
+        vt = L.mzd_transpose(None, vrow.mzd)            # l x 1
+        r = L.mzd_mul_naive(None, A.mzd, vt)             # m x 1
+        rt = L.mzd_transpose(None, r)                    # 1 x m: what as_vector copies out of
+        L.mzd_free(vt), L.mzd_free(r), L.mzd_free(rt)
+    a_times_v()
+    t_unc, _ = best(a_times_v, 5)
+    L.gf2_mzd_cache_on_device(A.mzd)
+    a_times_v()
+    t_c, _ = best(a_times_v, 5)
+    L.gf2_mzd_uncache(A.mzd)
+    out.append({"workload": "&A * &v on host operands, 2^20 x 256: mzd_transpose(v), mzd_mul_naive(NULL, A, v^T), mzd_transpose(result); "
+                            "A uploaded per call", "ms": t_unc * 1e3,
+                "pcie_floor_ms": floor_ms(m * l / 8.0, m * 8.0), "bytes_up": m * l / 8.0, "bytes_down": m * 8.0})
+    out.append({"workload": "the same with gf2_mzd_cache_on_device(A)", "ms": t_c * 1e3, "pcie_floor_ms": floor_ms(64.0, m * 8.0),
+                "bytes_up": 64.0, "bytes_down": m * 8.0,
+                "note": "C of a matrix x vector product is one 64-bit word per row in the M4RI layout: 8 MiB come back for 128 KiB of bits"})
+    return {"pcie_GBps": {k: v / 1e9 for k, v in rates.items()}, "entries": out}
+
+
 def _sharded_self_check(device, sharded, torch, Bp, Cfull_t, n, world, stream):
     """Cheap default check of a multi-GPU step (rank 0): eight consecutive rows out of every rank's row block (at least 32
     rows in all, offsets from a fixed seed) are re-multiplied by rank 0 alone from the seeded generator and compared with the
@@ -237,6 +329,7 @@ def main():
                          "but 4 x 32768x65536x16384 take 31 ms; from 4 GPUs on the transfer is the longer leg)")
     ap.add_argument("--bcast", default="broadcast", choices=["broadcast", "allgather"],
                     help="how a panel of B reaches the ranks: one broadcast, or scatter from rank 0 + all-gather")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the end-to-end legs on host mzd_t (C ABI incl. PCIe)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--check", action="store_true", help="spot-check rows of C against the oracle after timing")
     ap.add_argument("--no-configs", action="store_true",
@@ -504,6 +597,11 @@ def main():
                 np.array_equal(device.mul(Ad, Bd, algo=args.algo, param=args.levels).to_words(), cpu_sample))
     if world == 1 and not args.no_configs and args.density == "half":
         out["configs"] = _extra_configs(device, torch, stream)
+    if world == 1 and not args.no_host_path and args.density == "half":
+        del A, B, C, A_t, B_t, C_t  # the resident operands and (gf2_trim) the 15 GiB arena go back first
+        torch.cuda.empty_cache()
+        device._lib.lib().gf2_trim()
+        out["host_path"] = _host_path(torch)
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -237,6 +237,13 @@ mzd_t *gf2_mul_multi(mzd_t *C, mzd_t const *A, mzd_t const *B, int algo, int par
 int gf2_mzd_cache_on_device(mzd_t const *M);
 void gf2_mzd_uncache(mzd_t const *M);
 
+/* Host blocks of at least M4RI_HIP_PIN_MIN_BYTES (1 MiB) are pinned so that uploads and downloads run at the PCIe rate; pinning
+ * fresh pages costs about 100 ms per 512 MiB, so freed blocks are pooled (up to M4RI_HIP_PIN_CACHE_BYTES, 8 GiB).  A caller that
+ * knows its sizes can fill the pool ahead of time: gf2_mzd_prewarm(r, c, count) creates `count` pinned blocks of the size of an
+ * r x c matrix (returns how many it added).  The first mzd_init / mzd_mul(NULL, ...) / mzd_transpose(NULL, ...) of that size is
+ * then as fast as the later ones. */
+int gf2_mzd_prewarm(rci_t r, rci_t c, int count);
+
 /* give cached device memory (per-stream scratch arenas, block cache) of the current device back to the driver;
  * waits for the device first.  The library otherwise keeps what it allocated: the arena of a 131072^3 product is 141 GiB. */
 int gf2_trim(void);

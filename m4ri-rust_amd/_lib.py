@@ -113,6 +113,7 @@ _PROTOS = {
     "gf2_mul_multi": (MzdP, [MzdP, MzdP, MzdP, _I, _I, ctypes.POINTER(_I), _I]),
     "gf2_mzd_cache_on_device": (_I, [MzdP]),
     "gf2_mzd_uncache": (None, [MzdP]),
+    "gf2_mzd_prewarm": (_I, [_I, _I, _I]),
     "gf2_trim": (_I, []),
     "gf2_mul_host_small": (_I, [MzdP, MzdP, MzdP, _I]),
     "gf2_mul_nt_host_small": (_I, [MzdP, MzdP, MzdP, _I]),

@@ -2452,8 +2452,13 @@ __global__ __launch_bounds__(256) void gf2_transpose_kernel(u64 *__restrict__ D,
 
 __global__ __launch_bounds__(256) void gf2_strassen_split_kernel(u64 *__restrict__ dst, long long ldd, long long dstStride,
                                                                  const u64 *__restrict__ src, long long lds_,
-                                                                 long long srcStride, int h, int w, int side) {
+                                                                 long long srcStride, int h, int w, int side_) {
   // dst holds 7 consecutive operands per batch element: operand q at dst + (7*b + q)*dstStride
+  // side_ 2 (round 4): the A side with its operands written ROW-GROUP PACKED (word c of row r at ((r / 64) w + c) 64 + r % 64), the
+  // layout the paired tile kernels read with contiguous loads -- a single level used to hand them unpacked leaves, whose rows of
+  // 8192 bits and more run the tile kernel at half its rate (14336^3 with one level: 1.52 ms against 0.55 without any)
+  const bool pack = side_ == 2;
+  const int side = pack ? 0 : side_;
   const int b = blockIdx.z;
   const u64 *X = src + (long long)b * srcStride;
   u64 *Y = dst + (long long)b * 7 * dstStride;
@@ -2461,7 +2466,14 @@ __global__ __launch_bounds__(256) void gf2_strassen_split_kernel(u64 *__restrict
   const long long total = (long long)h * pairs;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
-    const int r = (int)(idx / pairs), c = (int)(idx % pairs) * 2;
+    int r, c;
+    if (pack) {  // a wave takes the 64 rows of a group at one pair of words: its 8-byte stores are 512 consecutive bytes
+      const long long rest = idx >> 6;
+      r = (int)(rest / pairs) * 64 + (int)(idx & 63);
+      c = (int)(rest % pairs) * 2;
+    } else {
+      r = (int)(idx / pairs), c = (int)(idx % pairs) * 2;
+    }
     const uint4 x11 = *reinterpret_cast<const uint4 *>(X + (long long)r * lds_ + c);
     const uint4 x12 = *reinterpret_cast<const uint4 *>(X + (long long)r * lds_ + w + c);
     const uint4 x21 = *reinterpret_cast<const uint4 *>(X + (long long)(r + h) * lds_ + c);
@@ -2484,11 +2496,20 @@ __global__ __launch_bounds__(256) void gf2_strassen_split_kernel(u64 *__restrict
       o[5] = xor4(x11, x12);
       o[6] = xor4(x21, x22);
     }
+    if (pack) {
+      const long long pk = ((long long)(r >> 6) * w + c) * 64 + (r & 63);
 #pragma unroll
-    for (int q = 0; q < 7; ++q) *reinterpret_cast<uint4 *>(Y + q * dstStride + (long long)r * ldd + c) = o[q];
+      for (int q = 0; q < 7; ++q) {
+        u64 *Yq = Y + q * dstStride;
+        Yq[pk] = (u64)o[q].x | ((u64)o[q].y << 32);
+        Yq[pk + 64] = (u64)o[q].z | ((u64)o[q].w << 32);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 7; ++q) *reinterpret_cast<uint4 *>(Y + q * dstStride + (long long)r * ldd + c) = o[q];
+    }
   }
 }
-
 __global__ __launch_bounds__(256) void gf2_strassen_merge_kernel(u64 *__restrict__ dst, long long ldd, long long dstStride,
                                                                  const u64 *__restrict__ src, long long lds_,
                                                                  long long srcStride, int h, int w, int accumulate) {
@@ -3497,64 +3518,122 @@ extern "C" hipError_t gf2k_diff(const u64 *A, long long lda, const u64 *B, long 
 // to the lane-per-row layout of the butterfly through LDS (rows padded to 72 bytes: conflict-free both ways), transposes its
 // eight 64 x 64 blocks in registers and puts word w of the 512 output rows into LDS; the output rows then leave 64 bytes
 // at a time as well.
-__global__ __launch_bounds__(512) void gf2_transpose512_kernel(u64 *__restrict__ D, long long ldd, const u64 *__restrict__ S,
-                                                               long long lds_, int rows, int cols, int ntiles_padded) {
-  __shared__ u64 sin[8][64][9];
-  __shared__ u64 sout[512][9];
+// Round 4: what bounded the first form of this kernel was its instruction stream, not its bytes -- rocprofv3 SQ counters on
+// 65536^2 (profiles/r04_transpose_counters.txt): 995 VALU + 1147 SALU + 128 LDS instructions per wave and tile (a 64-bit
+// __shfl_xor is two ds_bpermute_b32, and the lane-dependent 64-bit select around it about twenty more instructions, 48 times
+// per wave), a wave alive for 43600 cycles per tile of which 62 % parked on s_waitcnt / barriers (nothing of the next tile was
+// in flight while this one was shuffled).  Now the six butterfly rounds of a 64 x 64 block are register operations: distance
+// 32 and 16 are ONE v_permlane32_swap_b32 / v_permlane16_swap_b32 on the two halves that change places (gfx950), distances
+// 8, 4, 2, 1 a DPP move (row_ror:8; row_half_mirror + quad_perm for 4; quad_perm for 2 and 1), a per-lane rotate and a
+// v_bfi_b32 per dword -- 32 VALU instructions per block, no LDS traffic --, the staging of a wave's own rows needs no workgroup
+// barrier (only the exchange of the transposed blocks between the waves does), and the two exchanges share one 36 KiB buffer so
+// that four workgroups fit a CU: 65536^2 0.61 -> 0.36 ms.
+__device__ __forceinline__ u32 tr_dpp_xor(u32 y, int d) {
+  if (d == 8) return (u32)__builtin_amdgcn_update_dpp(0, (int)y, 0x128, 0xf, 0xf, true);   // row_ror:8: lane i <- lane i ^ 8 of its row
+  if (d == 2) return (u32)__builtin_amdgcn_update_dpp(0, (int)y, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
+  if (d == 1) return (u32)__builtin_amdgcn_update_dpp(0, (int)y, 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
+  const u32 m = (u32)__builtin_amdgcn_update_dpp(0, (int)y, 0x141, 0xf, 0xf, true);        // row_half_mirror: i <- 7 - i = i ^ 7
+  return (u32)__builtin_amdgcn_update_dpp(0, (int)m, 0x1B, 0xf, 0xf, true);                // quad_perm [3,2,1,0]: ^ 3, together ^ 4
+}
+
+// transposes the 64 x 64 bit block whose row L is {lo, hi} of lane L (lo = columns 0-31)
+__device__ __forceinline__ void tr_block64(u32 &lo, u32 &hi, const u32 (&keep)[4], const u32 (&rot)[4]) {
+  // distance 32: columns 32-63 of lanes 0-31 <-> columns 0-31 of lanes 32-63
+  asm("v_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+  // distance 16: split by column bit 4 (p0 = the low halves of both dwords), swap p0 of rows 16-31 / 48-63 with p1 of rows 0-15 / 32-47.
+  // The remaining rounds act inside 16-bit groups, so they run on (p0, p1) as they are and the halves are put back at the end.
+  u32 p0 = __builtin_amdgcn_perm(hi, lo, 0x05040100u), p1 = __builtin_amdgcn_perm(hi, lo, 0x07060302u);
+  asm("v_permlane16_swap_b32 %0, %1" : "+v"(p0), "+v"(p1));
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int d = 8 >> k;
+    // a lane whose bit d is set keeps the bits at column positions with bit d set and takes the others from its partner's
+    // upper positions (partner >> d); the other lane the mirror image.  rot = d or 32 - d: the rotation's wrapped bits fall
+    // where `keep` selects the lane's own value
+    const u32 y0 = tr_dpp_xor(p0, d), y1 = tr_dpp_xor(p1, d);
+    const u32 z0 = __builtin_amdgcn_alignbit(y0, y0, rot[k]), z1 = __builtin_amdgcn_alignbit(y1, y1, rot[k]);
+    p0 = (p0 & keep[k]) | (z0 & ~keep[k]);
+    p1 = (p1 & keep[k]) | (z1 & ~keep[k]);
+  }
+  lo = __builtin_amdgcn_perm(p1, p0, 0x05040100u);
+  hi = __builtin_amdgcn_perm(p1, p0, 0x07060302u);
+}
+
+__global__ __launch_bounds__(512, 8) void gf2_transpose512_kernel(u64 *__restrict__ D, long long ldd, const u64 *__restrict__ S,
+                                                                  long long lds_, int rows, int cols, int ntiles_padded, int flags) {
+  // ONE 36 KiB buffer for both exchanges (four workgroups per CU): rows 64 w .. 64 w + 63 are wave w's private staging rows on
+  // the way in and the output rows wave w stores on the way out; in between every wave writes its word of all 512 output rows,
+  // after the barrier that also says every wave has taken its staged rows out.
+  __shared__ u64 sbuf[512][9];
+  u64 (*sin)[64][9] = reinterpret_cast<u64 (*)[64][9]>(sbuf);
+  u64 (*sout)[9] = sbuf;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rr = lane >> 3, w = lane & 7;
   const int sw = (cols + 63) >> 6, dwn = (rows + 63) >> 6;
   const u64 maskS = (cols & 63) ? ((1ull << (cols & 63)) - 1) : ~0ull;
+  // per-lane constants of the four in-row rounds (distance 8, 4, 2, 1)
+  u32 keep[4], rot[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int d = 8 >> k;
+    const u32 mask = d == 8 ? 0x00FF00FFu : d == 4 ? 0x0F0F0F0Fu : d == 2 ? 0x33333333u : 0x55555555u;
+    keep[k] = (lane & d) ? ~mask : mask;
+    rot[k] = (lane & d) ? (u32)d : (u32)(32 - d);
+  }
   // tiles in super-tiles of 8 x 8 (4096 x 4096 bits), super-tiles row by row.  Workgroups b and b + 8 share an XCD, hence an
   // L2: they take column-adjacent tiles, whose 64-byte pieces are the two halves of the same 128-byte lines (with neighbours
-  // on different XCDs every line was fetched twice: FETCH_SIZE 1.07 GB for 0.54 GB -- which halved the traffic and gained 3 %).
-  // A workgroup may walk several tiles (grid cap), which changes nothing either: the kernel is bound by neither HBM bytes nor
-  // the dispatch of its workgroups.
+  // on different XCDs every line was fetched twice: FETCH_SIZE 1.07 GB for 0.54 GB).
   const int tx_n = (((cols + 63) >> 6) + 7) >> 3, ty_n = (rows + 511) >> 9;
   const int sx_n = (tx_n + 7) >> 3;
-  for (int b = blockIdx.x; b < ntiles_padded; b += gridDim.x) {
+  auto tile_of = [&](int b, int &tX, int &tY) -> bool {
     const int st = b >> 6, in = b & 63;
-    const int tX = (st % sx_n) * 8 + (in >> 3), tY = (st / sx_n) * 8 + (in & 7);
-    if (tX >= tx_n || tY >= ty_n) continue;  // (uniform: the tile count is padded to whole super-tiles)
-    const long long R0 = (long long)tY * 512;  // first source row of the tile
-    const int C0w = tX * 8;                    // first source word column
+    if (flags & 1) {  // the eight tiles an XCD (b mod 8) takes out of a super-tile form a 2 x 4 block: both 64-byte halves of every line meet in one L2, source and destination side
+      const int x = in & 7, slot = in >> 3;
+      tX = (st % sx_n) * 8 + 2 * (x & 3) + (slot & 1), tY = (st / sx_n) * 8 + 4 * (x >> 2) + (slot >> 1);
+    } else {
+      tX = (st % sx_n) * 8 + (in >> 3), tY = (st / sx_n) * 8 + (in & 7);
+    }
+    return tX < tx_n && tY < ty_n;  // (uniform: the tile count is padded to whole super-tiles)
+  };
+  for (int b = blockIdx.x; b < ntiles_padded; b += gridDim.x) {
+    int tX, tY;
+    if (!tile_of(b, tX, tY)) continue;
+    // ---- this wave's 64 rows of the tile (8 rows x 64 bytes per instruction) into its private staging rows (pitch 9 words:
+    // conflict-free both ways), back with lane = row.  (Requesting the next tile's rows before this one is shuffled -- persistent
+    // workgroups, 16 more registers -- measured 0.39-0.43 ms at 65536^2 against 0.36 for a plain walk: four workgroups per CU
+    // overlap their phases better than one workgroup overlaps its own.)
+    const int C0w = tX * 8;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const long long row = R0 + 64 * wave + 8 * k + rr;
+      const long long row = (long long)tY * 512 + 64 * wave + 8 * k + rr;
       const int wc = C0w + w;
-      u64 v = (row < rows && wc < sw) ? S[row * lds_ + wc] : 0;
+      u64 v = (row < rows && wc < sw) ? __builtin_nontemporal_load(S + row * lds_ + wc) : 0;
       if (wc == sw - 1) v &= maskS;
       sin[wave][8 * k + rr][w] = v;
     }
-    __syncthreads();
+    u32 lo[8], hi[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      u64 x = sin[wave][lane][j];
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) {
-        const u64 mask = (d == 32)  ? 0x00000000FFFFFFFFull
-                         : (d == 16) ? 0x0000FFFF0000FFFFull
-                         : (d == 8)  ? 0x00FF00FF00FF00FFull
-                         : (d == 4)  ? 0x0F0F0F0F0F0F0F0Full
-                         : (d == 2)  ? 0x3333333333333333ull
-                                     : 0x5555555555555555ull;
-        const u64 y = __shfl_xor(x, d, 64);
-        if (lane & d)
-          x = (x & ~mask) | ((y >> d) & mask);
-        else
-          x = (x & mask) | ((y << d) & ~mask);
-      }
-      sout[64 * j + lane][wave] = x;  // output row 64 j + lane of the tile, word = this wave's source row block
+      const u64 x = sin[wave][lane][j];  // (same wave wrote it: LDS operations of a wave execute in order)
+      lo[j] = (u32)x, hi[j] = (u32)(x >> 32);
     }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) tr_block64(lo[j], hi[j], keep, rot);
+    __syncthreads();  // every wave has taken its staged rows out (and, from the second tile on, stored its output rows)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sout[64 * j + lane][wave] = (u64)lo[j] | ((u64)hi[j] << 32);  // output row 64 j + lane, word = this wave's row block
     __syncthreads();
+    const long long R0 = (long long)tY * 512;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int ol = 64 * wave + 8 * k + rr;             // output row inside the tile
       const long long orow = 64ll * C0w + ol;            // = source column
       const long long ow = R0 / 64 + w;                  // output word = source row block
-      if (orow < cols && ow < dwn) D[orow * ldd + ow] = sout[ol][w];
+      if (orow < cols && ow < dwn) {
+        if (flags & 2) D[orow * ldd + ow] = sout[ol][w];
+        else __builtin_nontemporal_store(sout[ol][w], D + orow * ldd + ow);
+      }
     }
-    // (the next tile's loads into sin are behind this tile's first barrier for every wave; its stores into sout behind the second)
   }
 }
 
@@ -3567,9 +3646,10 @@ extern "C" hipError_t gf2k_transpose(u64 *D, long long ldd, const u64 *S, long l
     const int tx_n = (sw + 7) / 8, ty_n = (rows + 511) / 512;
     const long long ntp = (long long)((tx_n + 7) / 8) * ((ty_n + 7) / 8) * 64;
     if (ntp > 0x7fffffffLL) return hipErrorInvalidValue;
-    static const int tgrid = getenv("M4RI_HIP_TRANSPOSE_GRID") ? atoi(getenv("M4RI_HIP_TRANSPOSE_GRID")) : (1 << 20);  // (A/B: 512-4096 workgroups walking tiles, 0.64 ms at 65536^2, against one tile each, 0.60-0.62)
+    static const int tgrid = getenv("M4RI_HIP_TRANSPOSE_GRID") ? atoi(getenv("M4RI_HIP_TRANSPOSE_GRID")) : (1 << 20);  // (A/B: workgroups that walk several tiles)
     dim3 grid((unsigned)std::min<long long>(ntp, tgrid)), block(512);
-    hipLaunchKernelGGL(gf2_transpose512_kernel, grid, block, 0, stream, D, ldd, S, lds_, rows, cols, (int)ntp);
+    static const int tflags = getenv("M4RI_HIP_TRANSPOSE_FLAGS") ? atoi(getenv("M4RI_HIP_TRANSPOSE_FLAGS")) : 1;  // (A/B on one box at 65536^2: 0 = column-adjacent tiles per XCD 0.405 ms, 1 = 2 x 4 tile blocks per XCD 0.380; 2 = plain instead of non-temporal stores: no difference)
+    hipLaunchKernelGGL(gf2_transpose512_kernel, grid, block, 0, stream, D, ldd, S, lds_, rows, cols, (int)ntp, tflags);
     return hipGetLastError();
   }
   dim3 grid((sw + 3) / 4, rb), block(256);

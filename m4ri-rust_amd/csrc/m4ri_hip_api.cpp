@@ -828,12 +828,12 @@ static std::vector<PlanStep> strassen_plan(int L) {
   return p;
 }
 
-// Does the last split pass of an L-level product write the A leaves row-group packed?  (It must be a fused pass -- the
-// single-level kernel has no packed form -- and the leaf rows a multiple of 64; M4RI_HIP_APACK=0 switches the layout off.)
+// Does the last split pass of an L-level product write the A leaves row-group packed?  (Every split kernel has a packed form --
+// the single-level one since round 4 --; the leaf rows must be a multiple of 64; M4RI_HIP_APACK=0 switches the layout off.)
 static bool strassen_packs_a(int m, int L) {
   static const int apack_on = env_int("M4RI_HIP_APACK", 1);
-  if (!apack_on || L < 2) return false;
-  return ((m >> L) & 63) == 0;  // L >= 2: the last step of every plan is a fused one
+  if (!apack_on || L < 1) return false;
+  return ((m >> L) & 63) == 0;
 }
 
 static size_t pow7(int i) {
@@ -914,7 +914,6 @@ static int pick_levels_uncached(int m, int l, int n, int req, int leaf_min, doub
       continue;
     }
     double t = level_time_model(m, l, n, L);
-    if (L == 1) t *= 1.15;  // the single-level pass kernels (unfused, unpacked A leaves) run well below the model: 20480^3 2.21 ms against 1.82
     // tools/levels_sweep.py (profiles/r03_levels_sweep.txt): the model is 3-10 % pessimistic for 0 and 2 levels and within 3 % for
     // 3 and more, so a further level must promise 1.5 % (up to two levels) / 3 % (beyond) over the best count below it
     if (L == 0 || t < best_t * (L >= 3 ? 0.97 : 0.985)) {
@@ -1164,7 +1163,7 @@ static int mul_strassen(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int a
     u64 *dst = isA ? Aop[i] : Bop[i];
     const long long dstStride = (long long)rows_i * words_i;
     const int kside = pack ? 2 : side;
-    if (st.k == 1) return (int)gf2k_strassen_split(dst, words_i, dstStride, src, lds_, srcStride, rows_i, words_i, side, batch, s);
+    if (st.k == 1) return (int)gf2k_strassen_split(dst, words_i, dstStride, src, lds_, srcStride, rows_i, words_i, kside, batch, s);
     if (st.k == 2) return (int)gf2k_strassen_split2(dst, words_i, dstStride, src, lds_, srcStride, rows_i, words_i, kside, batch, s);
     const u64 *s0[7], *s1[7];
     int groups = 1;
@@ -1914,6 +1913,12 @@ int host_mul_range(mzd_t *C, const mzd_t *A, const mzd_t *B, int r0, int r1, int
   const bool plain_layout = !(A->flags & mzd_flag_windowed_zerooffset) && !(C->flags & mzd_flag_windowed_zerooffset) &&
                             A->rowstride >= 1 && C->rowstride >= 1;
   const bool whole = r0 == 0 && r1 == A->nrows;
+  // (Round 4 measured a 2 x 2 plan for mid-sized products -- the four quadrants of C as units, A in two row blocks, B in two
+  // column panels by 2-D copies, upload order A_0, B_0, B_1, A_1 -- against the row blocks below at 32768^3: 8.6 against 8.8 ms.
+  // The 2-D copies run at the linear rate (hipMemcpy2DAsync, 2 KiB rows: 54 GB/s), but a 16384 x 32768 x 16384 quadrant takes
+  // 1.33-1.40 ms -- 49 leaves = 392 tiles = 1.5 rounds, run as a whole round plus a tail launch -- where a quarter of the whole
+  // product's time would be 1.1: four of them are 5.5 ms of device work behind the 2.4 ms the first two pieces take to arrive.
+  // Not kept: the floor of either decomposition is the rate of its sub-products, profiles/r04_host_path_timeline.txt.)
   if (pipe_blocks >= 2 && !accumulate && plain_layout && rows >= 16384 && rows % (pipe_blocks * 64) == 0 &&
       (long long)A->ncols * B->ncols >= (1ll << 28) && !(whole && cache_lookup(A))) {
     // Units: row blocks of A and C (contiguous rows) x halves of the inner dimension (contiguous rows of B):
