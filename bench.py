@@ -327,8 +327,9 @@ def main():
                     help="column panels of B per step when N > 1 (RCCL/compute overlap); 0 = 2 panels on 2 GPUs, 4 above "
                          "(measured per-rank products: thin panels cost Strassen efficiency, 32768x65536x32768 takes 13.0 ms "
                          "but 4 x 32768x65536x16384 take 31 ms; from 4 GPUs on the transfer is the longer leg)")
-    ap.add_argument("--bcast", default="broadcast", choices=["broadcast", "allgather"],
-                    help="how a panel of B reaches the ranks: one broadcast, or scatter from rank 0 + all-gather")
+    ap.add_argument("--bcast", default=None, choices=["broadcast", "allgather"],
+                    help="how a panel of B reaches the ranks: one broadcast, or scatter from rank 0 + all-gather; left unset together "
+                         "with --panels 0 the run times three untimed steps of every candidate first and keeps the fastest")
     ap.add_argument("--no-host-path", action="store_true", help="skip the end-to-end legs on host mzd_t (C ABI incl. PCIe)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--check", action="store_true", help="spot-check rows of C against the oracle after timing")
@@ -386,6 +387,51 @@ def main():
     A_t = torch.empty((rows, ldw), dtype=torch.int64, device="cuda")
     A = device.DMat.from_torch(A_t, n)
     sharded.fill_row_block(A, seed=1, row0=rank * rows, stream=stream)
+    def make_panels(P_):
+        """B and C as P_ column panels ("tiles"), each contiguous, so that a panel can be broadcast / gathered by RCCL while the
+        previous one is being multiplied; B's panels filled on rank 0."""
+        wp_, ncp_ = ldw // P_, n // P_
+        Bp_t_ = [torch.empty((n, wp_), dtype=torch.int64, device="cuda") for _ in range(P_)]
+        Cp_t_ = [torch.empty((rows, wp_), dtype=torch.int64, device="cuda") for _ in range(P_)]
+        Bp_ = [device.DMat.from_torch(t, ncp_) for t in Bp_t_]
+        Cp_ = [device.DMat.from_torch(t, ncp_) for t in Cp_t_]
+        Cfull_t_ = [torch.empty((n, wp_), dtype=torch.int64, device="cuda") for _ in range(P_)] if rank == 0 else None
+        if rank == 0:
+            for pnl in range(P_):
+                sharded.fill_block(Bp_[pnl], 2, 0, pnl * wp_, n, stream)
+        return Bp_t_, Cp_t_, Bp_, Cp_, Cfull_t_
+
+    panel_tuning = None
+    if world > 1 and args.panels <= 0 and args.bcast is None:
+        # No multi-GPU run of this repository exists yet, so the first one tunes itself: three untimed steps of every candidate
+        # (panel count x how a panel travels), barrier + synchronize around them, the slowest rank's time decides on every rank
+        # alike.  Priors from one-GPU timings of the per-rank panel shapes: DESIGN.md section 6.
+        panel_tuning = []
+        for P_ in (1, 2, 4):
+            if ldw % (2 * P_) or (n // P_) % 128:
+                continue
+            bufs = make_panels(P_)
+            for mode in ("broadcast", "allgather"):
+                if mode == "allgather" and n % world:
+                    continue
+                for it in range(4):  # the first one untimed (arenas, communicators)
+                    if it == 1:
+                        torch.cuda.synchronize()
+                        dist.barrier()
+                        t0_ = time.perf_counter()
+                    sharded.step_pipelined(A, bufs[0], bufs[1], bufs[4], bufs[2], bufs[3], algo=args.algo, levels=args.levels,
+                                           stream=stream, bcast=mode)
+                torch.cuda.synchronize()
+                dist.barrier()
+                tm = torch.tensor([(time.perf_counter() - t0_) / 3.0], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                panel_tuning.append({"panels": P_, "bcast": mode, "ms_per_step": float(tm.item()) * 1e3})
+            del bufs
+            torch.cuda.empty_cache()
+        bestc = min(panel_tuning, key=lambda c: c["ms_per_step"])
+        args.panels, args.bcast = bestc["panels"], bestc["bcast"]
+    if args.bcast is None:
+        args.bcast = "broadcast"
     P = (args.panels if args.panels > 0 else (2 if world == 2 else 4)) if world > 1 else 1
     assert ldw % (2 * P) == 0
     wp, ncp = ldw // P, n // P
@@ -409,22 +455,18 @@ def main():
                             t_.bitwise_and_(tmp_t)
                     del tmp, tmp_t
     else:
-        # B and C are kept as P column panels ("tiles"), each contiguous, so that a panel can be broadcast /
-        # gathered by RCCL while the previous one is being multiplied
-        Bp_t = [torch.empty((n, wp), dtype=torch.int64, device="cuda") for _ in range(P)]
-        Cp_t = [torch.empty((rows, wp), dtype=torch.int64, device="cuda") for _ in range(P)]
-        Bp = [device.DMat.from_torch(t, ncp) for t in Bp_t]
-        Cp = [device.DMat.from_torch(t, ncp) for t in Cp_t]
-        Cfull_t = [torch.empty((n, wp), dtype=torch.int64, device="cuda") for _ in range(P)] if rank == 0 else None
-        if rank == 0:
-            for pnl in range(P):
-                sharded.fill_block(Bp[pnl], 2, 0, pnl * wp, n, stream)
+        Bp_t, Cp_t, Bp, Cp, Cfull_t = make_panels(P)
     torch.cuda.synchronize()
 
-    def step():
+    step_events = []  # filled during the timed steps only
+
+    def step(record=False):
         if world > 1:
+            ev = [] if record else None
             sharded.step_pipelined(A, Bp_t, Cp_t, Cfull_t, Bp, Cp, algo=args.algo, levels=args.levels, stream=stream,
-                                   bcast=args.bcast)
+                                   bcast=args.bcast, events=ev)
+            if record:
+                step_events.append(ev)
         else:
             device.mul(A, B, C=C, algo=args.algo, param=args.levels, stream=stream)
 
@@ -446,7 +488,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        step(record=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -464,7 +506,8 @@ def main():
     rank_info = None
     if world > 1:
         mine = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(),
-                "name": torch.cuda.get_device_name(torch.cuda.current_device()), "timed_region_ms": dt_local * 1e3}
+                "name": torch.cuda.get_device_name(torch.cuda.current_device()), "timed_region_ms": dt_local * 1e3,
+                "step_breakdown": sharded.breakdown(step_events)}
         rank_info = [None] * world
         dist.all_gather_object(rank_info, mine)
     if rank != 0:
@@ -572,6 +615,20 @@ def main():
         out["ranks_seen"] = dist.get_world_size()
         out["backend"] = dist.get_backend()
         out["ranks"] = rank_info
+        # where a step's time goes, per-rank maxima of the marks on the compute stream (per column panel: waiting for B, the local
+        # product; then the wait for the gathers of C): the longer leg is what to tune next
+        bds = [r["step_breakdown"] for r in rank_info if r and r.get("step_breakdown")]
+        if bds:
+            Pn = len(bds[0]["wait_b_ms"])
+            out["step_breakdown"] = {
+                "wait_b_ms": [max(b["wait_b_ms"][p] for b in bds) for p in range(Pn)],
+                "product_ms": [max(b["product_ms"][p] for b in bds) for p in range(Pn)],
+                "gather_tail_ms": max(b["gather_tail_ms"] for b in bds),
+                "step_ms": max(b["step_ms"] for b in bds),
+                "note": "per-rank maxima; marks recorded on the compute stream inside the timed steps"}
+        if panel_tuning is not None:
+            out["panel_tuning"] = {"candidates": panel_tuning, "chosen": {"panels": P, "bcast": args.bcast},
+                                   "note": "three untimed steps per candidate before the timed loop; --panels / --bcast pin a choice"}
         if self_check is not None:
             out["self_check"] = self_check
             out["parity_rows_ok"] = self_check["ok"]

@@ -655,13 +655,15 @@ static TilePlan plan_tiles_uncached(int m, int l, int n, int batch, bool packed,
       best.cfg = forced;
       best.packed = false;
       best.ksplit = m4rm_ksplit_for(m, l, n, batch, forced);
+      TilePlan est;  // (its time: the estimate of whole 512-row tiles, so that the level / shape planners never see a free launch)
+      if (v8_model(m, l, n, batch, false, 12, 0, 0, est)) best.t = est.t;
     }
     return best;
   }
   const bool v8_only = (mode & PLAN_V8_ONLY) != 0;
   if (m <= 256 && !packed && !v8_only) {
     if (older_model(m, l, n, batch, packed, 20, c)) consider(c);
-    return best;
+    if (have) return best;  // (rejected only when its split-K scratch exceeds M4RI_HIP_SPLITK_WS_MIB: the general candidates follow)
   }
   if (!v8_only) {
     if (!packed && older_model(m, l, n, batch, packed, 7, c)) consider(c);
@@ -693,6 +695,9 @@ static TilePlan plan_tiles_uncached(int m, int l, int n, int batch, bool packed,
       consider(head);
     }
   }
+  // nothing accepted (every candidate wanted more scratch than the cap allows): whole, unsplit 512-row tiles need none, so the
+  // plan always carries a real estimate (a default-constructed plan would price the launch as free for pick_levels / plan_shape)
+  if (!have && v8_model(m, l, n, batch, packed, 12, 0, 0, c)) consider(c);
   return best;
 }
 
@@ -998,43 +1003,70 @@ static int mul_widevec(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int ac
   return 0;
 }
 
+// Which kernel family a plain (no Strassen) product takes -- ONE decision, used by mul_m4rm_plain and by
+// gf2_mul_workspace_bytes (the query had drifted from the dispatch order).
+enum PlainPath {
+  kPathNothing,      // an empty operand
+  kPathZeroInner,    // l == 0: C is zero
+  kPathSlabTables,   // gf2k_tallskinny_long: up to 128 columns against a long inner dimension, no scratch
+  kPathSlabPasses,   // the same in passes of 128 columns
+  kPathWideVec,      // a wave per row: scratch = the transposed vectors
+  kPathTallSkinny,   // tables over all of B in LDS (l <= 1024): no scratch
+  kPathFewRows,      // m <= 8: v*A kernel, no scratch
+  kPathFewRowsT,     // 9-128 rows against a tall B, computed transposed: scratch = few_rows_t_bytes
+  kPathTiles         // the planned tile kernels (maybe a packed copy of A and stream-K / split-K partial tiles)
+};
+static PlainPath plain_path(int m, int l, int n) {
+  if (m == 0 || n == 0) return kPathNothing;
+  if (l == 0) return kPathZeroInner;
+  if (ts_long_shape(m, l, n)) return kPathSlabTables;
+  {
+    static const int mp = env_int("M4RI_HIP_TS7_MULTIPASS", 1);
+    static const int maxn = env_int("M4RI_HIP_TS7_MAXN", 256);
+    // (129-192 columns would pay a whole second pass for at most 64 of them: 20000 x 40000 x 160 148 -> 165 us)
+    static const int minl128 = env_int("M4RI_HIP_TS7_MINL128", 1000);  // (65536 x 1000 x 128: 45 -> 17 us, 262144 x 4096 x 128: 327 -> 82 us)
+    if (mp && n > 64 && n <= maxn && (n <= 128 ? m >= 256 && l >= minl128 : n > 192 && m >= 4096 && l >= 32768) && ts_long_shape(m, l, 64))
+      return kPathSlabPasses;
+  }
+  if (widevec_shape(m, l, n)) return kPathWideVec;
+  // the table kernels for 256 < l <= 1024 give a workgroup 4096 rows: below 2^19 rows they leave most of the chip idle
+  // (65536 x 1000 x 64: 44 us whatever the row count, against 15-45 us through the tile kernel; tools/ab_ts_long.sh)
+  static const int ts_long_min_rows = env_int("M4RI_HIP_TS_LONG_MIN_ROWS", 524288);
+  if (n <= 256 && m >= (l > 256 ? ts_long_min_rows : 2048) && (n > 64 || l > 64) && l <= 1024) return kPathTallSkinny;
+  if (m <= 8) return kPathFewRows;
+  if (few_rows_t_shape(m, l, n)) return kPathFewRowsT;
+  return kPathTiles;
+}
+
 static int mul_m4rm_plain(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int accumulate, hipStream_t s) {
   const int m = A->nrows, l = A->ncols, n = B->ncols;
-  if (m == 0 || n == 0) return 0;
-  if (l == 0) {
+  const PlainPath path = plain_path(m, l, n);
+  if (path == kPathNothing) return 0;
+  if (path == kPathZeroInner) {
     if (!accumulate) HIP_TRY(gf2k_xor2d(C->data, C->ld, nullptr, 0, nullptr, 0, m, words_of(n), s));
     return 0;
   }
-  if (ts_long_shape(m, l, n)) {
+  if (path == kPathSlabTables) {
     HIP_TRY(gf2k_tallskinny_long(A->data, A->ld, B->data, B->ld, C->data, C->ld, m, l, n, accumulate, s));
     return 0;
   }
   // 65-128 columns against a long inner dimension: that kernel with 16-byte entries, where the tile kernel finds a single column
   // tile and a handful of row tiles (65536^2 x 128: 0.78 -> 0.27 ms; 20000^2 x 128: 143 -> 46 us; 9000 x 33000 x 100: 126 -> 37 us).
   // A second pass for 129-256 columns pays from 32768-bit rows on (65536^2 x 256: 0.78 -> 0.53 ms; 65536 x 8192 x 256: 98 -> 125 us).
-  {
-    static const int mp = env_int("M4RI_HIP_TS7_MULTIPASS", 1);
-    static const int maxn = env_int("M4RI_HIP_TS7_MAXN", 256);
-    // (129-192 columns would pay a whole second pass for at most 64 of them: 20000 x 40000 x 160 148 -> 165 us)
-    static const int minl128 = env_int("M4RI_HIP_TS7_MINL128", 1000);  // (65536 x 1000 x 128: 45 -> 17 us, 262144 x 4096 x 128: 327 -> 82 us)
-    if (mp && n > 64 && n <= maxn && (n <= 128 ? m >= 256 && l >= minl128 : n > 192 && m >= 4096 && l >= 32768) && ts_long_shape(m, l, 64)) {
-      for (int c0 = 0; c0 < n; c0 += 128)
-        HIP_TRY(gf2k_tallskinny_long(A->data, A->ld, B->data + c0 / 64, B->ld, C->data + c0 / 64, C->ld, m, l, std::min(128, n - c0), accumulate, s));
-      return 0;
-    }
+  if (path == kPathSlabPasses) {
+    for (int c0 = 0; c0 < n; c0 += 128)
+      HIP_TRY(gf2k_tallskinny_long(A->data, A->ld, B->data + c0 / 64, B->ld, C->data + c0 / 64, C->ld, m, l, std::min(128, n - c0), accumulate, s));
+    return 0;
   }
-  if (widevec_shape(m, l, n)) return mul_widevec(C, A, B, accumulate, s);  // few columns, long rows: a wave per row
+  if (path == kPathWideVec) return mul_widevec(C, A, B, accumulate, s);  // few columns, long rows: a wave per row
   // tall and skinny: tables over ALL of B, A streamed once.  Built for short inner dimensions (a batch of LPN samples: l = 256);
   // with a long one the tables are rebuilt every 256 bits and the tile kernel with split-K is ~10x faster (65536 x 65600 x 64:
   // 6.4 ms here), so the border strips of peeled products do not come this way
-  // the table kernels for 256 < l <= 1024 give a workgroup 4096 rows: below 2^19 rows they leave most of the chip idle
-  // (65536 x 1000 x 64: 44 us whatever the row count, against 15-45 us through the tile kernel; tools/ab_ts_long.sh)
-  static const int ts_long_min_rows = env_int("M4RI_HIP_TS_LONG_MIN_ROWS", 524288);
-  if (n <= 256 && m >= (l > 256 ? ts_long_min_rows : 2048) && (n > 64 || l > 64) && l <= 1024) {
+  if (path == kPathTallSkinny) {
     HIP_TRY(gf2k_tallskinny(A->data, A->ld, B->data, B->ld, C->data, C->ld, m, l, n, accumulate, s));
     return 0;
   }
-  if (m <= 8) {  // a handful of rows: stream B once (v*A path, binary_matrix.rs:552-563)
+  if (path == kPathFewRows) {  // a handful of rows: stream B once (v*A path, binary_matrix.rs:552-563)
     if (!accumulate) HIP_TRY(gf2k_xor2d(C->data, C->ld, nullptr, 0, nullptr, 0, m, words_of(n), s));
     HIP_TRY(gf2k_va(A->data, A->ld, B->data, B->ld, C->data, C->ld, m, l, n, s));
     return 0;
@@ -1045,7 +1077,7 @@ static int mul_m4rm_plain(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int
   // transposed in and out.  Only for a B much taller than wide: the transposition of B runs at 1.7-1.9 TB/s (64 x 20000 x 20000:
   // 93 -> 151 us, 64 x 65536 x 65536: 0.86 -> 0.81 ms).
   {
-    if (few_rows_t_shape(m, l, n)) {
+    if (path == kPathFewRowsT) {
       const int passes = (m + 63) / 64;
       const long long ldl = (words_of(l) + 1) & ~1ll, wn = words_of(n), ldn = (wn + 1) & ~1ll, ldct = (passes + 1) & ~1ll;
       const size_t wBt = (size_t)n * ldl, wAt = (size_t)l * 2, wCt = (size_t)n * ldct, wTmp = accumulate ? (size_t)m * ldn : 0;
@@ -1537,17 +1569,30 @@ extern "C" int gf2_mul_nt_dev(gf2_dmat *C, gf2_dmat const *A, gf2_dmat const *Bt
 }
 
 extern "C" size_t gf2_mul_workspace_bytes(int m, int l, int n, int algo, int param) {
-  if (algo == GF2_ALGO_NAIVE) return n <= 64 ? (size_t)n * ((words_of(l) + 1) & ~1) * 8 : 0;
-  // a plain product may pack A (mul_m4rm_plain) and may cut tiles into segments / slices with partial tiles in scratch
-  size_t plain_ws = 0;
-  if (m > 0 && ts_long_shape(m, l, n)) return 0;                                          // tables in LDS, partial words meet in C
-  if (m > 0 && widevec_shape(m, l, n)) return (size_t)n * ((words_of(l) + 1) & ~1) * 8;  // the transposed vectors
-  if (m > 8 && few_rows_t_shape(m, l, n)) return few_rows_t_bytes(m, l, n, 1);           // B^T and the small transposed operands
-  if (m > 0 && l > 0 && n > 64) {
-    bool pack = false;
-    const TilePlan tp = plain_plan(m, l, n, &pack);
-    plain_ws = tp.scratch() + (pack ? (size_t)((m + 63) & ~63) * (size_t)((words_of(l) + 1) & ~1) * 8 : 0);
+  // the scratch of a plain product follows the path mul_m4rm_plain takes (plain_path): a packed copy of A and partial tiles for
+  // the planned tile kernels, the transposed vectors for the wave-per-row kernel, nothing for the table kernels
+  auto plain_bytes = [&]() -> size_t {
+    switch (plain_path(m, l, n)) {
+      case kPathWideVec: return (size_t)n * ((words_of(l) + 1) & ~1) * 8;
+      case kPathFewRowsT: return few_rows_t_bytes(m, l, n, 1);
+      case kPathTiles: {
+        bool pack = false;
+        const TilePlan tp = plain_plan(m, l, n, &pack);
+        return tp.scratch() + (pack ? (size_t)((m + 63) & ~63) * (size_t)((words_of(l) + 1) & ~1) * 8 : 0);
+      }
+      default: return 0;
+    }
+  };
+  if (algo == GF2_ALGO_NAIVE) {
+    // mul_naive_dev: wide products are forwarded to mul_m4rm_plain; up to 64 columns take the table / wave-per-row kernels or the
+    // AND / popcount kernels, which need at most the transposed B
+    if (n > 64 || l == 0) return plain_bytes();
+    if (m > 0 && ts_long_shape(m, l, n)) return 0;
+    if (m > 0 && widevec_shape(m, l, n)) return (size_t)n * ((words_of(l) + 1) & ~1) * 8;
+    if (n > 8 && m >= 2048) return plain_bytes();
+    return (size_t)n * ((words_of(l) + 1) & ~1) * 8;
   }
+  const size_t plain_ws = plain_bytes();
   if (algo == GF2_ALGO_M4RM) return plain_ws;
   static const int leaf_min = env_int("M4RI_HIP_STRASSEN_LEAF_MIN", 2048);
   const int L = pick_levels(m, l, n, param, leaf_min);
@@ -1699,6 +1744,7 @@ extern "C" double gf2_tile_plan(int m, int l, int n, int batch, int packed, long
 
 // the row band of the same plan: out = {rows of the band (0: none), its variant, its stream-K cut (tiles, segments), its scratch}
 extern "C" void gf2_tile_plan_band(int m, int l, int n, int batch, int packed, long long out[5]) {
+  if (!out) return;
   const TilePlan tp = plan_tiles(m, l, n, batch < 1 ? 1 : batch, packed != 0);
   out[0] = tp.band_rows;
   out[1] = tp.band_cfg;

@@ -523,9 +523,14 @@ extern "C" mzd_t *mzd_invert_naive(mzd_t *inv, mzd_t const *A, mzd_t const *iden
   }
   mzd_t *H = mzd_concat(nullptr, A, identity ? identity : I);
   if (I) mzd_free(I);
-  const rci_t rank = mzd_echelonize(H, 1);
-  bool ok = rank >= n;
-  for (rci_t i = 0; ok && i < n; ++i) ok = read_bit(H, i, i) == 1;  // reduced form of a full-rank left block: the identity
+  // [A | I] always has rank n (the identity block), so the rank says nothing about A.  What does: in the FULLY REDUCED echelon
+  // form (full = 1 -- both the device path and the small-size host path of mzd_echelonize deliver it; tests/test_gpu_elim.py::
+  // test_invert_naive runs both) the left block is the identity exactly when A is invertible -- a singular A leaves a pivot
+  // right of column n and a zero on the diagonal.  (Upstream M4RI returns NULL for a singular A only when the rank is 0; here
+  // every singular A gives NULL: INTEGRATION.md section 3.)
+  (void)mzd_echelonize(H, 1);
+  bool ok = true;
+  for (rci_t i = 0; ok && i < n; ++i) ok = read_bit(H, i, i) == 1;
   mzd_t *out = nullptr;
   if (ok) out = mzd_submatrix(inv, H, 0, n, n, 2 * n);
   mzd_free(H);

@@ -134,19 +134,52 @@ def mul_row_sharded_pipelined(a_block, b_panels, c_panels, c_full_panels, ncols_
         w.wait()
 
 
-def step_pipelined(A, Bp_t, Cp_t, Cfull_t, Bp, Cp, algo="auto", levels=0, stream=None, bcast="broadcast"):
-    """bench.py's timed step for N > 1 ranks, B in column panels (DMat wrappers pre-built)."""
+def step_pipelined(A, Bp_t, Cp_t, Cfull_t, Bp, Cp, algo="auto", levels=0, stream=None, bcast="broadcast", events=None):
+    """bench.py's timed step for N > 1 ranks, B in column panels (DMat wrappers pre-built).
+
+    events: None, or a list that receives this step's torch.cuda.Event marks on the compute stream --
+    [start, (B panel p arrived, product p enqueued) for every p, all gathers done] -- from which `breakdown()` derives, per panel,
+    how long the compute stream waited for B and how long the product took, and the tail spent waiting for the gathers: the
+    first real multi-GPU run then says by itself which leg (RCCL transfer or local product) bounds a step."""
+    import torch
     import torch.distributed as dist
     world, rank, P = dist.get_world_size(), dist.get_rank(), len(Bp_t)
+
+    def mark():
+        if events is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()  # torch's current stream = the bench's compute stream
+            events.append(e)
+    mark()
     bcasts = [distribute_panel(Bp_t[p], bcast) for p in range(P)]
     gathers = []
     for p in range(P):
         bcasts[p].wait()
+        mark()
         device.mul(A, Bp[p], C=Cp[p], algo=algo, param=levels, stream=stream)
+        mark()
         glist = list(Cfull_t[p].chunk(world, dim=0)) if rank == 0 else None
         gathers.append(dist.gather(Cp_t[p], gather_list=glist, dst=0, async_op=True))
     for w in gathers:
         w.wait()
+    mark()
+
+
+def breakdown(step_events):
+    """Per-step means (ms) out of the marks `step_pipelined` recorded: {"wait_b_ms": [per panel], "product_ms": [per panel],
+    "gather_tail_ms": x, "step_ms": y}.  Call after torch.cuda.synchronize()."""
+    if not step_events:
+        return None
+    P = (len(step_events[0]) - 2) // 2
+    wait_b, prod, tail, total = [0.0] * P, [0.0] * P, 0.0, 0.0
+    for ev in step_events:
+        for p in range(P):
+            wait_b[p] += ev[2 * p].elapsed_time(ev[2 * p + 1])
+            prod[p] += ev[2 * p + 1].elapsed_time(ev[2 * p + 2])
+        tail += ev[2 * P].elapsed_time(ev[2 * P + 1])
+        total += ev[0].elapsed_time(ev[2 * P + 1])
+    k = float(len(step_events))
+    return {"wait_b_ms": [x / k for x in wait_b], "product_ms": [x / k for x in prod], "gather_tail_ms": tail / k, "step_ms": total / k}
 
 
 def step(A_t, B_t, C_t, Cfull_t, A, B, C, algo="auto", levels=0, stream=None):

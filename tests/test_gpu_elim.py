@@ -412,3 +412,9 @@ def test_invert_naive(pkg, monkeypatch, small_work):
     z[3, 0] = 5
     Z = pkg.BinMatrix.from_words(z, 20)
     assert not L.mzd_invert_naive(None, Z.mzd, None)
+    # rank n - 1 (a product of an n x (n - 1) and an (n - 1) x n matrix): [A | I] still has rank n, so only the reduced form's
+    # left block tells -- NULL on both the device path and the host path of the size dispatch
+    for n in (33, 200):
+        low = g.o_mul_naive(g.random_words(n, n - 1, 70 + n), g.random_words(n - 1, n, 71 + n), n, n - 1, n)
+        assert g.o_inverse(low, n) is None
+        assert not L.mzd_invert_naive(None, pkg.BinMatrix.from_words(low, n).mzd, None)

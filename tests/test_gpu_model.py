@@ -18,7 +18,11 @@ def dev(built):
     return device
 
 SHAPES = [(8192, 8192, 8192), (12288, 12288, 12288), (16384, 16384, 16384), (24576, 24576, 24576), (8192, 32768, 16384)]
-TOLERANCE = 0.25  # boxes of the pool differ by 7 % on one binary and the model is 3-10 % pessimistic by design (it was fitted so)
+# The model may be at most 20 % optimistic (the round-3 failure: a plan that ran 2.1 x above its price) and at most 35 % pessimistic:
+# its constants were fitted at the clock the chip holds under a long load, products of a few hundred microseconds run before the
+# clock has come down, and the boxes of the pool differ on exactly those (12288^3 without levels: 0.291 ms on one box, 0.362 on
+# another, modelled 0.371)
+OPTIMISTIC, PESSIMISTIC = 0.20, 0.35
 
 
 @pytest.mark.parametrize("m,l,n", SHAPES)
@@ -49,8 +53,8 @@ def test_model_time_tracks_measured_time(dev, m, l, n):
             dt = (time.perf_counter() - t0) / reps
             best = dt if best is None else min(best, dt)
         report.append((L, best, model))
-    bad = [(L, round(t * 1e3, 3), round(mod * 1e3, 3)) for L, t, mod in report if abs(mod - t) > TOLERANCE * t]
-    assert not bad, "levels whose modelled time is more than %d %% off the measured one (L, measured ms, model ms): %s" % (TOLERANCE * 100, bad)
+    bad = [(L, round(t * 1e3, 3), round(mod * 1e3, 3)) for L, t, mod in report if mod < (1 - OPTIMISTIC) * t or mod > (1 + PESSIMISTIC) * t]
+    assert not bad, "levels whose modelled time is more than 20 %% below / 35 %% above the measured one (L, measured ms, model ms): %s" % bad
     # and the automatic choice is within 5 % of the best explicit level count
     auto = lib.gf2_strassen_levels(m, l, n, dev.ALGOS["auto"], 0)
     t_auto = next(t for L, t, _ in report if L == auto) if any(L == auto for L, _, _ in report) else None

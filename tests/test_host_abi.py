@@ -396,7 +396,7 @@ def test_shape_plans_without_gpu(built):
 
     assert plan(65536, 65536, 65536) == (4, 0, (65536, 65536, 65536))
     assert plan(32768, 32768, 32768) == (3, 0, (32768, 32768, 32768))
-    assert plan(8192, 65536, 65536)[0] == 0                       # two row tiles: too short for a level to pay
+    assert plan(8192, 65536, 65536)[0] == 1                       # two row tiles: ONE level (packed A leaves since round 4: 4.70 against 4.91 ms measured), not two
     lv, kind, dims = plan(60000, 60000, 60000)                        # does not divide: padded up or peeled down, by modelled time
     assert kind in (1, 2) and lv in (3, 4) and all(57344 <= d <= 61440 for d in dims)
     assert dims[0] % (64 << lv) == 0 and dims[1] % (128 << lv) == 0 and dims[2] % (128 << lv) == 0
@@ -404,7 +404,8 @@ def test_shape_plans_without_gpu(built):
     assert kind == 2 and lv == 4 and dims == (65536, 65536, 65536)   # peeled: 64 rows / columns of border
     lv, kind, dims = plan(70000, 70000, 70000)
     assert kind == 2 and lv == 4 and dims[0] == 65536            # a 65536-row core (whole 4096-row leaf tiles), not 69632
-    assert plan(12288, 12288, 12288) == (0, 0, (12288, 12288, 12288))  # a level must promise 8 % to be taken
+    assert plan(12288, 12288, 12288)[0] in (0, 1)                     # one level at most (L0 0.312-0.362 ms, L1 0.310-0.338 measured: a tie)
+    assert plan(4096, 4096, 4096) == (0, 0, (4096, 4096, 4096))       # BASELINE config 2: no level pays
     assert plan(1000, 1000, 1000) == (0, 0, (1000, 1000, 1000))
     assert plan(65536, 65536, 65536, algo=1) == (0, 0, (65536, 65536, 65536))   # mzd_mul_m4rm: no levels
     lv, kind, dims = plan(5000, 4000, 4100, algo=2, param=2)         # explicit level count on a shape that does not divide

@@ -138,7 +138,7 @@ def test_row_block_generator_matches_full_matrix():
 # ---- the driver's own invocation, rehearsed on the GPU box ---------------------------------------------
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("bcast", ["broadcast", "allgather"])
+@pytest.mark.parametrize("bcast", ["broadcast", "allgather", None])
 def test_bench_two_ranks_from_a_bare_shell(bcast):
     """`python bench.py --gpus 2 ...` with WORLD_SIZE unset -- exactly how the driver starts the scaling runs -- must launch
     its own two ranks (torch.distributed.run children; the parent never touches the GPU), run the row-sharded step
@@ -149,7 +149,7 @@ def test_bench_two_ranks_from_a_bare_shell(bcast):
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--check", "--dim", "8192",
-           "--no-cpu", "--steps", "2", "--warmup", "1", "--bcast", bcast]
+           "--no-cpu", "--steps", "2", "--warmup", "1"] + (["--bcast", bcast] if bcast else [])
     r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -157,3 +157,15 @@ def test_bench_two_ranks_from_a_bare_shell(bcast):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["sharded_result_matches_single_gpu"] is True
     assert out["scaling"] == "strong" and out["value"] > 0 and out["config"]["n"] == 8192
+    # the line says where a step's time went (marks on the compute stream, per-rank maxima) ...
+    bd = out["step_breakdown"]
+    assert len(bd["wait_b_ms"]) == len(bd["product_ms"]) >= 1 and bd["step_ms"] > 0 and bd["gather_tail_ms"] >= 0
+    assert all(r["step_breakdown"] for r in out["ranks"])
+    if bcast is None:  # ... and, with --panels / --bcast left alone, the run chose its panel plan from its own timings
+        tune = out["panel_tuning"]
+        assert {(c["panels"], c["bcast"]) for c in tune["candidates"]} == {(p, b) for p in (1, 2, 4) for b in ("broadcast", "allgather")}
+        assert tune["chosen"] in [{"panels": c["panels"], "bcast": c["bcast"]} for c in tune["candidates"]]
+        best = min(tune["candidates"], key=lambda c: c["ms_per_step"])
+        assert tune["chosen"] == {"panels": best["panels"], "bcast": best["bcast"]}
+    else:
+        assert "panel_tuning" not in out
