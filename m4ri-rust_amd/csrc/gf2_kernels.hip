@@ -46,6 +46,14 @@
 typedef uint64_t u64;
 typedef uint32_t u32;
 
+// A/B switches of the launchers: read from the environment in development builds only (tools/libm4ri_hip_dev.so); the shipped
+// library uses the default
+#ifdef GF2K_DEV_VARIANTS
+#define GF2K_DEV_ENV(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#else
+#define GF2K_DEV_ENV(name, dflt) (dflt)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // M4RM tile kernel
 // ---------------------------------------------------------------------------------------------
@@ -1606,6 +1614,10 @@ __global__ __launch_bounds__(NT) void gf2_tallskinny3_kernel(const u64 *__restri
   }
 }
 
+// The round-2/3 kernels for l <= 256 (gf2_tallskinny5_kernel: 8-bit tables, two phases at n > 128; gf2_tallskinny6_kernel: 4-bit
+// tables, small streaming workgroups) were replaced by gf2_lpn.inc in round 4 and no shape selects them any more: they are
+// compiled into development builds only (tools/libm4ri_hip_dev.so, M4RI_HIP_LPN=0 for A/B runs).
+#ifdef GF2K_DEV_VARIANTS
 // ---------------------------------------------------------------------------------------------
 // tall-skinny kernel for an inner dimension of at most 256 bits (BASELINE config 5: l = 256) and 64 < n <= 256: the skewed
 // lookups of gf2_tallskinny3_kernel with every row of A read exactly ONCE.
@@ -1948,6 +1960,8 @@ __global__ __launch_bounds__(256) void gf2_tallskinny6_kernel(const u64 *__restr
       }
   }
 }
+
+#endif  // GF2K_DEV_VARIANTS (gf2_tallskinny5 / 6)
 
 // ---------------------------------------------------------------------------------------------
 // up to 64 vectors against an inner dimension of ANY length: the 4-bit tables of gf2_tallskinny6_kernel, rebuilt per 512-bit
@@ -3177,7 +3191,7 @@ extern "C" hipError_t gf2k_narrow(const u64 *A, long long lda, const u64 *B, lon
   const size_t lds = (size_t)n * wl * 8;
   if (n > 64 || lds > 65536 || l <= 0) return hipErrorInvalidValue;
   long long blocks = ((long long)m + 255) / 256;
-  static const int cap_env = getenv("M4RI_HIP_NARROW_BLOCKS") ? atoi(getenv("M4RI_HIP_NARROW_BLOCKS")) : 0;  // (A/B measurements)
+  static const int cap_env = GF2K_DEV_ENV("M4RI_HIP_NARROW_BLOCKS", 0);  // (A/B measurements)
   if (blocks > (cap_env > 0 ? cap_env : 2048)) blocks = cap_env > 0 ? cap_env : 2048;  // grid-stride: every block pays the B transpose once
   dim3 grid((unsigned)blocks), block(256);
   const bool vec_ok = (lda % 2 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
@@ -3237,7 +3251,7 @@ extern "C" hipError_t gf2k_tallskinny_long(const u64 *A, long long lda, const u6
   const int nwC = (n + 63) >> 6;
   const int nslabs = (l + 511) >> 9;
   const long long rblocks = ((long long)m + 256 * RPT - 1) / (256 * RPT);
-  static const int want = getenv("M4RI_HIP_TS7_BLOCKS") ? atoi(getenv("M4RI_HIP_TS7_BLOCKS")) : 8192;  // (65536^2 x 64: 0.21 ms with 1024 workgroups, 0.17 with 8192)
+  static const int want = GF2K_DEV_ENV("M4RI_HIP_TS7_BLOCKS", 8192);  // (65536^2 x 64: 0.21 ms with 1024 workgroups, 0.17 with 8192)
   // (two words per row of C: fewer divisions -- the atomics on a C with 32-byte rows cost more: 65536^2 x 256 0.81 ms with 8192 workgroups, 0.53 with 2048)
   const int want_eff = nwC == 1 ? want : (want + 3) / 4;
   long long splits = rblocks >= want_eff ? 1 : (want_eff + rblocks - 1) / rblocks;
@@ -3274,8 +3288,10 @@ extern "C" hipError_t gf2k_tallskinny(const u64 *A, long long lda, const u64 *B,
   if (m <= 0 || n <= 0) return hipSuccess;
   if (n > 256 || l <= 0) return hipErrorInvalidValue;
   const int nw = (n + 63) / 64;
-  static const int old_only = getenv("M4RI_HIP_TALLSKINNY_OLD") ? atoi(getenv("M4RI_HIP_TALLSKINNY_OLD")) : 0;
-  static const int ts6 = getenv("M4RI_HIP_TS6") ? atoi(getenv("M4RI_HIP_TS6")) : 1;
+  static const int old_only = GF2K_DEV_ENV("M4RI_HIP_TALLSKINNY_OLD", 0);
+#ifdef GF2K_DEV_VARIANTS
+  static const int ts6 = GF2K_DEV_ENV("M4RI_HIP_TS6", 1);
+#endif
   // ---- l <= 256 (round 4): the single-phase streaming kernels of gf2_lpn.inc.  Measured cold at 2^20 x 256 (tools/lpn_lab, us):
   //   n <= 64         gf2_lpn8_kernel<1>    8-bit tables, 8-byte entries, 2 workgroups per CU     8.7-8.9   (4-bit kernel 11.2-13.5)
   //   64 < n <= 128   gf2_lpn8_kernel<2>    8-bit tables, 16-byte entries                         11.3      (14.5-15.1)
@@ -3283,7 +3299,7 @@ extern "C" hipError_t gf2k_tallskinny(const u64 *A, long long lda, const u64 *B,
   // Rows per workgroup = 512 x RPT with RPT chosen so that the launch has about one workgroup per CU (two for n <= 64): with
   // few rows a batch of 4096 per workgroup leaves most of the chip idle (65536 x 256 x 256: 14.5 us with RPT = 8, 5.4 with 1).
   // M4RI_HIP_LPN=0 restores the round-2/3 kernels (A/B runs).
-  static const int lpn = getenv("M4RI_HIP_LPN") ? atoi(getenv("M4RI_HIP_LPN")) : 1;
+  static const int lpn = GF2K_DEV_ENV("M4RI_HIP_LPN", 1);
   if (l <= 256 && !old_only && lpn) {
     const bool a16 = (lda & 1) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
     const bool c16 = nw == 1 || ((ldc & 1) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0);
@@ -3331,10 +3347,11 @@ extern "C" hipError_t gf2k_tallskinny(const u64 *A, long long lda, const u64 *B,
 #undef GF2_LPN_GO
     return hipGetLastError();
   }
+#ifdef GF2K_DEV_VARIANTS  // (reached with M4RI_HIP_LPN=0 in development builds only)
   if (l <= 256 && !old_only && (ts6 & (nw == 3 ? 4 : nw))) {
     const int vec_ok = l > 192 && (lda & 1) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
     long long blocks = ((long long)m + 255) / 256;
-    static const int cap_env = getenv("M4RI_HIP_TS6_BLOCKS") ? atoi(getenv("M4RI_HIP_TS6_BLOCKS")) : 0;  // (A/B measurements)
+    static const int cap_env = GF2K_DEV_ENV("M4RI_HIP_TS6_BLOCKS", 0);  // (A/B measurements)
     const long long cap = cap_env > 0 ? cap_env : (nw <= 2 ? 2048 : 1024);  // 8 (4) workgroups per CU
     if (blocks > cap) blocks = cap;
 #define GF2_TS6_LAUNCH(NWV)                                                                                                       \
@@ -3369,6 +3386,7 @@ extern "C" hipError_t gf2k_tallskinny(const u64 *A, long long lda, const u64 *B,
 #undef GF2_TS5_LAUNCH
     return hipGetLastError();
   }
+#endif
   if (nw == 1) {  // generation kernel (replicated tables, skew inside a 64-bit word)
     constexpr int RPT4 = 4, NT4 = 1024;
     const unsigned grid4 = (unsigned)(((long long)m + NT4 * RPT4 - 1) / (NT4 * RPT4));
@@ -3641,14 +3659,14 @@ extern "C" hipError_t gf2k_transpose(u64 *D, long long ldd, const u64 *S, long l
                                      hipStream_t stream) {
   if (rows <= 0 || cols <= 0) return hipSuccess;
   const int sw = (cols + 63) / 64, rb = (rows + 63) / 64;
-  static const int t512 = getenv("M4RI_HIP_TRANSPOSE512") ? atoi(getenv("M4RI_HIP_TRANSPOSE512")) : 1;  // (A/B measurements)
+  static const int t512 = GF2K_DEV_ENV("M4RI_HIP_TRANSPOSE512", 1);  // (A/B measurements)
   if (t512 && (long long)rows * cols >= (1ll << 29)) {  // from 64 MiB on: below, both operands live in the Infinity Cache and the small blocks win
     const int tx_n = (sw + 7) / 8, ty_n = (rows + 511) / 512;
     const long long ntp = (long long)((tx_n + 7) / 8) * ((ty_n + 7) / 8) * 64;
     if (ntp > 0x7fffffffLL) return hipErrorInvalidValue;
-    static const int tgrid = getenv("M4RI_HIP_TRANSPOSE_GRID") ? atoi(getenv("M4RI_HIP_TRANSPOSE_GRID")) : (1 << 20);  // (A/B: workgroups that walk several tiles)
+    static const int tgrid = GF2K_DEV_ENV("M4RI_HIP_TRANSPOSE_GRID", (1 << 20));  // (A/B: workgroups that walk several tiles)
     dim3 grid((unsigned)std::min<long long>(ntp, tgrid)), block(512);
-    static const int tflags = getenv("M4RI_HIP_TRANSPOSE_FLAGS") ? atoi(getenv("M4RI_HIP_TRANSPOSE_FLAGS")) : 1;  // (A/B on one box at 65536^2: 0 = column-adjacent tiles per XCD 0.405 ms, 1 = 2 x 4 tile blocks per XCD 0.380; 2 = plain instead of non-temporal stores: no difference)
+    static const int tflags = GF2K_DEV_ENV("M4RI_HIP_TRANSPOSE_FLAGS", 1);  // (A/B on one box at 65536^2: 0 = column-adjacent tiles per XCD 0.405 ms, 1 = 2 x 4 tile blocks per XCD 0.380; 2 = plain instead of non-temporal stores: no difference)
     hipLaunchKernelGGL(gf2_transpose512_kernel, grid, block, 0, stream, D, ldd, S, lds_, rows, cols, (int)ntp, tflags);
     return hipGetLastError();
   }
@@ -3692,11 +3710,11 @@ extern "C" hipError_t gf2k_strassen_split3(u64 *dst, long long ldd, long long ds
     srcs.b[g] = src1 ? src1[g] : nullptr;
   }
   const long long total = (long long)h * w;
-  static const int cap = getenv("M4RI_HIP_PASS_GRID") ? atoi(getenv("M4RI_HIP_PASS_GRID")) : 8192;
+  static const int cap = GF2K_DEV_ENV("M4RI_HIP_PASS_GRID", 8192);
   const int gx = grid_for(total, 256, (cap + batch * groups - 1) / (batch * groups));
   const dim3 grid(gx, groups, batch);
   // non-temporal stores: the 343 operand streams are not re-read before the leaf launch (measured: -3 % / -6 % pass time)
-  static const int nt = getenv("M4RI_HIP_PASS_NT") ? atoi(getenv("M4RI_HIP_PASS_NT")) : 1;
+  static const int nt = GF2K_DEV_ENV("M4RI_HIP_PASS_NT", 1);
   if (side == 2 && nt)
     hipLaunchKernelGGL((gf2_strassen_split3_kernel<0, true, true>), grid, dim3(256), 0, stream, dst, ldd, dstStride, srcs, lds_, srcStride, h, w);
   else if (side == 2)
@@ -3718,7 +3736,7 @@ extern "C" hipError_t gf2k_strassen_merge3(u64 *dst, long long ldd, long long ds
   if (h <= 0 || w <= 0 || batch <= 0 || groups <= 0) return hipSuccess;
   const long long total = (long long)h * w;
   const int gx = grid_for(total, 256, (8192 + batch * groups - 1) / (batch * groups));
-  static const int ntl = getenv("M4RI_HIP_PASS_NTL") ? atoi(getenv("M4RI_HIP_PASS_NTL")) : 1;  // the products are read once: non-temporal loads, -7 % (1.25 -> 1.15 ms)
+  static const int ntl = GF2K_DEV_ENV("M4RI_HIP_PASS_NTL", 1);  // the products are read once: non-temporal loads, -7 % (1.25 -> 1.15 ms)
   if (ntl)
     hipLaunchKernelGGL(gf2_strassen_merge3_kernel<true>, dim3(gx, groups, batch), dim3(256), 0, stream, dst, ldd, dstStride, src, lds_,
                        srcStride, h, w, accumulate);

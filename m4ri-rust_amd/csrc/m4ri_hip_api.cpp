@@ -393,6 +393,14 @@ static int env_int(const char *name, int dflt) {
   const char *e = std::getenv(name);
   return e ? std::atoi(e) : dflt;
 }
+// Fitted model constants and A/B switches: read from the environment in development builds only (tools/libm4ri_hip_dev.so,
+// built with -DGF2K_DEV_VARIANTS; the A/B scripts under tools/ load it through AB_LIB).  The shipped library uses the default:
+// INTEGRATION.md section 6 lists which variables it still reads.
+#ifdef GF2K_DEV_VARIANTS
+#define dev_env_int(name, dflt) env_int(name, dflt)
+#else
+#define dev_env_int(name, dflt) (dflt)
+#endif
 
 // ---- launch geometry of the tile kernel (shared by the launcher and the level chooser) ----
 // tile geometry and measured cost of the OLDER kernel variants (gf2_kernels.hip): 8 = v6 2048 x 1024 tile, two chunks per lookup step, one
@@ -418,7 +426,7 @@ static int cfg_v8_rg(int cfg) { return cfg == 9 ? 8 : cfg == 10 ? 4 : cfg == 11 
 // split-K factor of the older kernels (v3, v6): when a product has too few tiles to fill 256 CUs, the inner dimension is cut into
 // slices of at least 128 bits; the slices' partial products are combined by a second kernel
 static int m4rm_ksplit_for(int m, int l, int n, int batch, int cfg) {
-  static const int forced = env_int("M4RI_HIP_M4RM_KSPLIT", 0);
+  static const int forced = dev_env_int("M4RI_HIP_M4RM_KSPLIT", 0);
   if (forced > 0) return forced;
   const long long wg = tiles_of(tile_geom(cfg), m, n) * batch;
   const int nw32 = (l + 31) / 32;
@@ -426,7 +434,7 @@ static int m4rm_ksplit_for(int m, int l, int n, int batch, int cfg) {
     // All tiles of a launch take the same time, so 520 workgroups cost three rounds of 256 where 2.03 would do.  A single plain
     // product may cut the inner dimension into a few slices to even the rounds out (the slices' partial tiles cost one write and
     // one read of C per slice): rounds(ks) / ks tile-times + ks passes over C, minimised over ks <= 8.
-    static const int balance = env_int("M4RI_HIP_SPLITK_BALANCE", 1);
+    static const int balance = dev_env_int("M4RI_HIP_SPLITK_BALANCE", 1);
     static const long long cap = (long long)env_int("M4RI_HIP_SPLITK_WS_MIB", 2048) << 20;
     if (!balance || batch != 1 || wg > 2048) return 1;
     const TileGeom g = tile_geom(cfg, cfg == 8);
@@ -482,18 +490,20 @@ struct TilePlan {
 // HBM (65536 x 65536 x 512: 1.14 ms unpacked, 0.78 ms with the packing pass; 65536 x 8192 x 512: 0.190 against 0.101 ms;
 // up to 7000 bits packing loses, 0.092 against 0.156 ms): the surcharge is five times as high from 8192 bits on.
 static double v8_quad_us(int RG, bool packed, int l = 0) {
-  static const double unp0 = env_int("M4RI_HIP_V8_UNPACKED_BASE_NS", 100) * 1e-3, unp = env_int("M4RI_HIP_V8_UNPACKED_NS", 70) * 1e-3;
+  static const double unp0 = dev_env_int("M4RI_HIP_V8_UNPACKED_BASE_NS", 100) * 1e-3, unp = dev_env_int("M4RI_HIP_V8_UNPACKED_NS", 70) * 1e-3;
   static const std::array<double, 4> loop_us = [] {
     std::array<double, 4> t{0.679, 0.924, 1.415, 2.486};
+#ifdef GF2K_DEV_VARIANTS  // (M4RI_HIP_V8_QUAD_NS=a,b,c,d: the loop's nanoseconds per quad at 512 / 1024 / 2048 / 4096 rows, for model fits)
     if (const char *e = getenv("M4RI_HIP_V8_QUAD_NS")) {
       int v[4];
       if (std::sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4)
         for (int i = 0; i < 4; ++i) t[i] = v[i] * 1e-3;
     }
+#endif
     return t;
   }();
   const int i = RG >= 8 ? 3 : RG >= 4 ? 2 : RG >= 2 ? 1 : 0;
-  static const double long_rows = env_int("M4RI_HIP_V8_UNPACKED_LONG_PCT", 500) * 1e-2;
+  static const double long_rows = dev_env_int("M4RI_HIP_V8_UNPACKED_LONG_PCT", 500) * 1e-2;
   const double stretch = l >= 8192 ? long_rows : 1.0;  // a cliff, not a slope: 65536 x l x 512 unpacked takes 0.092 ms at l = 7000 and 0.188 ms at 8192
   return loop_us[i] + (packed ? 0.0 : (unp0 + unp * RG) * stretch);
 }
@@ -503,8 +513,8 @@ static double v8_quad_us(int RG, bool packed, int l = 0) {
 // scratch exceeds the cap.
 static bool v8_model(int m, int l, int n, int batch, bool packed, int cfg, long long n_rem, long long want, TilePlan &c) {
   static const long long cap = (long long)env_int("M4RI_HIP_SPLITK_WS_MIB", 2048) << 20;
-  static const double seg_fix = env_int("M4RI_HIP_V8_SEG_FIX_NS", 3500) * 1e-9, seg_rg = env_int("M4RI_HIP_V8_SEG_RG_NS", 2600) * 1e-9,
-                      red_bw = env_int("M4RI_HIP_V8_REDUCE_GBS", 2500) * 1e9, two_part = env_int("M4RI_HIP_V8_TWO_PART_PCT", 180) * 1e-2;
+  static const double seg_fix = dev_env_int("M4RI_HIP_V8_SEG_FIX_NS", 3500) * 1e-9, seg_rg = dev_env_int("M4RI_HIP_V8_SEG_RG_NS", 2600) * 1e-9,
+                      red_bw = dev_env_int("M4RI_HIP_V8_REDUCE_GBS", 2500) * 1e9, two_part = dev_env_int("M4RI_HIP_V8_TWO_PART_PCT", 180) * 1e-2;
   const int RG = cfg_v8_rg(cfg), R = 512 * RG, nw32 = (l + 31) / 32, Q = (nw32 + 1) / 2;
   const long long T = (long long)((m + R - 1) / R) * ((n + 511) / 512) * batch;
   const double tq = v8_quad_us(RG, packed, l) * 1e-6, tile_bytes = R * 64.0;
@@ -556,7 +566,7 @@ static bool older_model(int m, int l, int n, int batch, bool packed, int cfg, Ti
   // slices; 9000 x 33000 x 300: 82 / 127 with 51; 33000 x 9000 x 300: 77 / 111 with 15; the same shapes through v8 on packed A:
   // 39-74 us): unpacked rows of 8192 bits and more cost these kernels 1.4x (they too read a row per lane or lane group), and
   // every slice of the inner dimension another 0.2 %
-  static const double older_long = env_int("M4RI_HIP_OLDER_LONG_PCT", 140) * 1e-2, older_ks = env_int("M4RI_HIP_OLDER_KSPLIT_PPM", 2000) * 1e-6;
+  static const double older_long = dev_env_int("M4RI_HIP_OLDER_LONG_PCT", 140) * 1e-2, older_ks = dev_env_int("M4RI_HIP_OLDER_KSPLIT_PPM", 2000) * 1e-6;
   if (!packed && l >= 8192) c.t *= older_long;
   c.t *= 1.0 + older_ks * ks;
   if (ks > 1) {
@@ -610,9 +620,9 @@ static TilePlan plan_tiles_uncached(int m, int l, int n, int batch, bool packed,
     return -1;
 #endif
   }();
-  static const int forced_ks = env_int("M4RI_HIP_M4RM_KSPLIT", 0);
-  static const int streamk = env_int("M4RI_HIP_STREAMK", 1);      // 0: whole tiles only
-  static const int tails = env_int("M4RI_HIP_TAIL_LAUNCH", 1);    // 0: never cut a batched launch in two
+  static const int forced_ks = dev_env_int("M4RI_HIP_M4RM_KSPLIT", 0);
+  static const int streamk = dev_env_int("M4RI_HIP_STREAMK", 1);      // 0: whole tiles only
+  static const int tails = dev_env_int("M4RI_HIP_TAIL_LAUNCH", 1);    // 0: never cut a batched launch in two
   TilePlan best, c;
   bool have = false;
   auto consider = [&](const TilePlan &x) {
@@ -672,8 +682,8 @@ static TilePlan plan_tiles_uncached(int m, int l, int n, int batch, bool packed,
   for (int cfg = 9; cfg <= 12; ++cfg) v8(cfg);
   // a row band: whole tile rows of 4096 (2048) in the main launch, the rows below them in a launch of their own with the
   // tile height that suits them (the same B, disjoint rows of A and C; the band's partial tiles reuse the scratch)
-  static const int bands = env_int("M4RI_HIP_ROW_BANDS", 1);
-  static const double band_gain = env_int("M4RI_HIP_ROW_BAND_MIN_GAIN_PCT", 3) * 1e-2;
+  static const int bands = dev_env_int("M4RI_HIP_ROW_BANDS", 1);
+  static const double band_gain = dev_env_int("M4RI_HIP_ROW_BAND_MIN_GAIN_PCT", 3) * 1e-2;
   if (bands && (mode & PLAN_BAND) && have) {
     const TilePlan uniform = best;
     for (int R = 4096; R >= 2048; R >>= 1) {
@@ -713,7 +723,7 @@ static double leaf_time_model(int m, int l, int n, int batch, bool may_pack) {
 static const double kPackLaunch = 5.0e-6;
 // ... of a plain product, which may pack A itself first (mul_m4rm_plain makes the same comparison)
 static double plain_time_model(int m, int l, int n) {
-  static const double bw = (double)env_int("M4RI_HIP_STREAM_GBS", 5000) * 1e9;
+  static const double bw = (double)dev_env_int("M4RI_HIP_STREAM_GBS", 5000) * 1e9;
   static const int plain_pack = env_int("M4RI_HIP_PLAIN_APACK", 1);
   double t = m4rm_time_model(m, l, n, 1, false);
   const long long wp = (words_of(l) + 1) & ~1ll, prow = ((long long)m + 63) & ~63ll;
@@ -765,7 +775,7 @@ static int launch_planned(gf2k_mul_args a, const TilePlan &tp, hipStream_t s) {
 
 // the plan of a plain product: A unpacked, or packed by a pass of its own when the model says that pays
 static TilePlan plain_plan(int m, int l, int n, bool *pack) {
-  static const double bw = (double)env_int("M4RI_HIP_STREAM_GBS", 5000) * 1e9;
+  static const double bw = (double)dev_env_int("M4RI_HIP_STREAM_GBS", 5000) * 1e9;
   static const int plain_pack = env_int("M4RI_HIP_PLAIN_APACK", 1);
   TilePlan tp = plan_tiles(m, l, n, 1, false);
   *pack = false;
@@ -876,7 +886,7 @@ static double strassen_pass_bytes(double m, double l, double n, int L) {
 // per plan step).  5 us: with 3 us the model preferred two levels at 8192^3 (133 against 138 us), which measures 0.123 against 0.115 ms
 static const double kPassLaunch = 5.0e-6;
 static double level_time_model(int m, int l, int n, int L) {
-  static const double bw = (double)env_int("M4RI_HIP_STREAM_GBS", 5000) * 1e9;        // streaming B/s
+  static const double bw = (double)dev_env_int("M4RI_HIP_STREAM_GBS", 5000) * 1e9;        // streaming B/s
   if (L <= 0) return plain_time_model(m, l, n);
   const int d = 1 << L;
   if (L > 6 || m % d || l % (128 * d) || n % (128 * d)) return -1.0;  // leaf rows integral, leaf widths an even word count
@@ -949,7 +959,7 @@ static size_t strassen_ws_words(int m, int l, int n, int L) {
 // would compute 512 columns to deliver n (65536^2 times 64 vectors: 1.18 ms against 0.3), the lane-per-row kernels read an
 // 8-KiB row 8 bytes at a time per lane (65536^2 times one vector: 0.30 ms against 0.1).
 static bool widevec_shape(int m, int l, int n) {
-  static const int on = env_int("M4RI_HIP_WIDEVEC", 1);
+  static const int on = dev_env_int("M4RI_HIP_WIDEVEC", 1);
   if (!on || n > 64 || m < 1) return false;
   // Where it wins, from an A/B grid against the older paths on one box (tools/ab_widevec.sh, profiles/r03_widevec_ab.txt;
   // time of the wave-per-row kernel / time of what ran before, at m = 65536 and m = 1000):
@@ -957,7 +967,7 @@ static bool widevec_shape(int m, int l, int n) {
   //   n  = 32: l = 4096 1.27 / 0.74, 20000 0.31 / 0.59, 65536 0.30 / 0.97        n = 64: l = 20000 0.63 / 1.04, 65536 0.61 / 1.84
   // (three instructions per vector and word bound it from 9 vectors on; a row per wave needs rows to fill the chip)
   if (m <= 8) return l >= 8192 && (n <= 32 || m >= 4);  // against the v*A kernel: 8 x 65536 x 1 74 -> 9 us, x 64 120 -> 62 us
-  static const int minl16 = env_int("M4RI_HIP_WIDEVEC_MINL16", 2048), minl32 = env_int("M4RI_HIP_WIDEVEC_MINL32", 8192);
+  static const int minl16 = dev_env_int("M4RI_HIP_WIDEVEC_MINL16", 2048), minl32 = dev_env_int("M4RI_HIP_WIDEVEC_MINL32", 8192);
   // rows of 768 ... 2047 bits: up to 8 vectors and not too many rows (20000 x 1000 x 8: 19 us against 30 for the tile kernel and 44
   // for the generation table kernel; at 2^20 rows the table kernel wins: 86 us against 220)
   if (n <= 8 && l >= 768 && m <= 131072) return true;
@@ -967,7 +977,7 @@ static bool widevec_shape(int m, int l, int n) {
 }
 // up to 64 vectors against a long inner dimension through 4-bit tables rebuilt per 512-bit slab (gf2_tallskinny7_kernel)
 static bool ts_long_shape(int m, int l, int n) {
-  static const int mode = env_int("M4RI_HIP_TS7", 1);  // 0 off, 1 by rule, 2 whenever it can (A/B)
+  static const int mode = dev_env_int("M4RI_HIP_TS7", 1);  // 0 off, 1 by rule, 2 whenever it can (A/B)
   if (!mode || n > 64 || l <= 256 || m < 1) return false;
   if (mode == 2) return true;
   // Where it wins (tools/ab_ts7.sh, profiles/r03_ts7_ab.txt: its time does not depend on n -- 65536^2: 0.21 ms, 2^20 x 4096: 0.18 ms --
@@ -981,7 +991,7 @@ static bool ts_long_shape(int m, int l, int n) {
 }
 // 9-128 rows against a B much taller than wide: computed transposed (see mul_m4rm_plain)
 static bool few_rows_t_shape(int m, int l, int n) {
-  static const int few = env_int("M4RI_HIP_FEW_ROWS_T", 1);
+  static const int few = dev_env_int("M4RI_HIP_FEW_ROWS_T", 1);
   const bool tall = (n >= 1024 && l >= 8 * (long long)n && (long long)l * n >= (1ll << 26) && m <= 64) ||
                     (n > 64 && n <= 1024 && l >= 16384 && l >= 8 * (long long)n && (long long)l * n >= (1ll << 21));
   return few && m > 8 && m <= 128 && tall;
@@ -1021,17 +1031,17 @@ static PlainPath plain_path(int m, int l, int n) {
   if (l == 0) return kPathZeroInner;
   if (ts_long_shape(m, l, n)) return kPathSlabTables;
   {
-    static const int mp = env_int("M4RI_HIP_TS7_MULTIPASS", 1);
-    static const int maxn = env_int("M4RI_HIP_TS7_MAXN", 256);
+    static const int mp = dev_env_int("M4RI_HIP_TS7_MULTIPASS", 1);
+    static const int maxn = dev_env_int("M4RI_HIP_TS7_MAXN", 256);
     // (129-192 columns would pay a whole second pass for at most 64 of them: 20000 x 40000 x 160 148 -> 165 us)
-    static const int minl128 = env_int("M4RI_HIP_TS7_MINL128", 1000);  // (65536 x 1000 x 128: 45 -> 17 us, 262144 x 4096 x 128: 327 -> 82 us)
+    static const int minl128 = dev_env_int("M4RI_HIP_TS7_MINL128", 1000);  // (65536 x 1000 x 128: 45 -> 17 us, 262144 x 4096 x 128: 327 -> 82 us)
     if (mp && n > 64 && n <= maxn && (n <= 128 ? m >= 256 && l >= minl128 : n > 192 && m >= 4096 && l >= 32768) && ts_long_shape(m, l, 64))
       return kPathSlabPasses;
   }
   if (widevec_shape(m, l, n)) return kPathWideVec;
   // the table kernels for 256 < l <= 1024 give a workgroup 4096 rows: below 2^19 rows they leave most of the chip idle
   // (65536 x 1000 x 64: 44 us whatever the row count, against 15-45 us through the tile kernel; tools/ab_ts_long.sh)
-  static const int ts_long_min_rows = env_int("M4RI_HIP_TS_LONG_MIN_ROWS", 524288);
+  static const int ts_long_min_rows = dev_env_int("M4RI_HIP_TS_LONG_MIN_ROWS", 524288);
   if (n <= 256 && m >= (l > 256 ? ts_long_min_rows : 2048) && (n > 64 || l > 64) && l <= 1024) return kPathTallSkinny;
   if (m <= 8) return kPathFewRows;
   if (few_rows_t_shape(m, l, n)) return kPathFewRowsT;
@@ -1313,22 +1323,22 @@ static ShapePlan plan_shape(int m, int l, int n, int req, int leaf_min) {
   return sp;
 }
 static ShapePlan plan_shape_uncached(int m, int l, int n, int req, int leaf_min) {
-  static const double bw = (double)env_int("M4RI_HIP_STREAM_GBS", 5000) * 1e9;
+  static const double bw = (double)dev_env_int("M4RI_HIP_STREAM_GBS", 5000) * 1e9;
   static const int max_auto = env_int("M4RI_HIP_STRASSEN_MAX_LEVELS", 5);
-  static const int debug = env_int("M4RI_HIP_DEBUG_PLAN", 0);
+  static const int debug = dev_env_int("M4RI_HIP_DEBUG_PLAN", 0);
   ShapePlan best;
   const double plain = plain_model(m, l, n);
   best.t = plain;
   if (debug) std::fprintf(stderr, "m4ri_hip plan %d x %d x %d: plain %.3f ms\n", m, l, n, best.t * 1e3);
   const int lo = req > 0 ? (req > 6 ? 6 : req) : 1, hi = req > 0 ? lo : max_auto;
   bool forced_done = false;
-  static const int only_kind = env_int("M4RI_HIP_SHAPE_KIND", 0);  // A/B measurements: 1 = padded plans only, 2 = peeled plans only
+  static const int only_kind = dev_env_int("M4RI_HIP_SHAPE_KIND", 0);  // A/B measurements: 1 = padded plans only, 2 = peeled plans only
   auto consider = [&](int kind, int L, long long mm, long long ll, long long nn, double t) {
     if (only_kind && kind != only_kind) return;
     if (debug) std::fprintf(stderr, "  L=%d %s %lld x %lld x %lld: %.3f ms\n", L, kind == 1 ? "pad " : "peel", mm, ll, nn, t * 1e3);
     // (not forced:) the model is coarse: a plan must promise 5 % over plain M4RM to be taken (8 % until the tile model stopped counting
     // the per-tile overhead twice; 30000^3 then sat exactly on the threshold: padded 3.71 ms, plain 4.06 ms measured)
-    static const double min_gain = env_int("M4RI_HIP_SHAPE_MIN_GAIN_PCT", 5) * 1e-2;
+    static const double min_gain = dev_env_int("M4RI_HIP_SHAPE_MIN_GAIN_PCT", 5) * 1e-2;
     if ((req > 0 && !forced_done) || (t < best.t && (req > 0 || t < (1.0 - min_gain) * plain))) best = {kind, L, (int)mm, (int)ll, (int)nn, t}, forced_done = true;
   };
   for (int L = lo; L <= hi; ++L) {
@@ -1437,7 +1447,7 @@ static int mul_naive_dev(gf2_dmat *C, const gf2_dmat *A, const gf2_dmat *B, int 
   // one to eight vectors against MANY short rows (`&A * &v` on 2^20 LPN samples): the 8-bit table kernel of gf2_lpn.inc streams A
   // with wave-contiguous non-temporal loads and costs the same whatever n <= 64 is (2^20 x 256 x 1 cold: 9.4 us through the
   // AND / popcount kernel below, 8.7-8.9 through the tables); with fewer rows the popcount kernel's small workgroups start faster
-  static const int narrow_lpn_rows = env_int("M4RI_HIP_NARROW_LPN_ROWS", 262144);
+  static const int narrow_lpn_rows = dev_env_int("M4RI_HIP_NARROW_LPN_ROWS", 262144);
   if (narrow_lpn_rows > 0 && m >= narrow_lpn_rows && l <= 256 && l > 64) {
     HIP_TRY(gf2k_tallskinny(A->data, A->ld, B->data, B->ld, C->data, C->ld, m, l, n, accumulate, s));
     if (sync_free && hipStreamSynchronize(s) != hipSuccess) return fail(hipGetLastError(), "hipStreamSynchronize");
@@ -2408,7 +2418,7 @@ int echelonize_dev(gf2_dmat *A, int full, int col_limit, int *rank_out, int *piv
   // is taken when at most 256 columns can matter (1000 x 64: 94 us against 139; 10 x 10: 60 against 109)
   const int cols_to_visit = limit < m + 64 ? limit : m + 64;
   // (cols_to_visit is an estimate: a rank-deficient input walks all `limit` columns serially, hence the second bound)
-  if (m <= 1024 && (long long)m * (aw | 1) <= 19000 && cols_to_visit <= 256 && limit <= 4096 && env_int("M4RI_HIP_ELIM_SMALL", 1)) {
+  if (m <= 1024 && (long long)m * (aw | 1) <= 19000 && cols_to_visit <= 256 && limit <= 4096 && dev_env_int("M4RI_HIP_ELIM_SMALL", 1)) {
     HIP_TRY(gf2k_elim_small(A->data, lda, m, ncols, limit, full, reinterpret_cast<int *>(st.p), pv.as<int>(), s));
     HIP_TRY(hipMemcpyAsync(rank_out, st.p, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));

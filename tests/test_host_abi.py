@@ -514,3 +514,19 @@ def test_mzd_pointer_keeps_its_owner_alive(pkg):
     assert p.contents.nrows == 300 and L.mzd_equal(p, pkg.BinMatrix.from_words(a, 300).mzd) == 1
     assert L.mzd_equal(pkg.BinMatrix.from_words(a, 300).mzd, pkg.BinMatrix.from_words(a, 300).mzd) == 1
     del junk
+
+
+def test_integration_lists_every_knob():
+    """INTEGRATION.md section 6a is the generated table of tools/knob_table.py: every M4RI_HIP_* variable the sources read is listed,
+    with the development-only ones (read only under GF2K_DEV_VARIANTS) in their own table."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("knob_table", os.path.join(ROOT, "tools", "knob_table.py"))
+    kt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kt)
+    k = kt.knobs()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = doc[doc.index("<!-- knob table: begin"):doc.index("<!-- knob table: end")]
+    shipped, dev = sec.split("**Development builds only")
+    for name, e in k.items():
+        assert ("`%s`" % name) in (dev if e["dev"] else shipped), name
+    assert sum(1 for e in k.values() if not e["dev"]) <= 16  # the shipped library's surface stays small
