@@ -201,6 +201,11 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&Cs[i], (size_t)m * 32 + (size_t)(i + 1) * (1 << 20)));  // different distances between A_i and C_i
     hipLaunchKernelGGL(fill_kernel, dim3((m * 4 + 255) / 256), dim3(256), 0, 0, As[i], (long long)m * 4, 100 + i);
   }
+  {  // the stamp buffer of the instrumented variants always exists (a stamped kernel launched without one would write through NULL)
+    unsigned long long *st0;
+    CK(hipMalloc(&st0, (size_t)4096 * 16 * 8));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(lpn_dbg_stamps), &st0, sizeof(st0)));
+  }
   u64 *B, *Cref;
   unsigned long long *cnt;
   CK(hipMalloc(&B, 256 * 32));
@@ -296,6 +301,7 @@ int main(int argc, char **argv) {
     const bool profile = getenv("LAB_PROFILE");  // a few launches per variant, no timing loops (counter runs)
     for (auto &v : vs) {
       if (only && v.name.find(only) == std::string::npos) continue;
+      if (profile && v.name.find("stamps") != std::string::npos) continue;  // (a counter run wants the plain kernels)
       if (profile) {
         for (int i = 0; i < 8; ++i) v.launch(As[i % NBUF], B, Cs[(3 * i + 1) % NBUF], m, V);
         CK(hipDeviceSynchronize());
