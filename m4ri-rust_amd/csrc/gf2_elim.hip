@@ -62,7 +62,7 @@ __global__ __launch_bounds__(1024) void gf2_elim_pivot_kernel(const u64 *__restr
   __shared__ int f_pos[64];
   __shared__ unsigned char s_chosen[256];  // rows scan0 .. scan0+255 picked by this step
   __shared__ int s_lead[4];
-  __shared__ u64 stage[64 * 64];
+  __shared__ int s_col2k[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r_cur = st->r_cur;
   const int jbase = r_cur - st->r0;
@@ -198,48 +198,40 @@ __global__ __launch_bounds__(1024) void gf2_elim_pivot_kernel(const u64 *__restr
     const int ns = scan0 + adv;
     st->scan = ns < m ? ns : m;
   }
-  // the chosen rows over the block's columns [c0w, c0w+sw) and the tracking words [0, uw), each with its own unit bit
-  for (int idx = tid; idx < np * 64; idx += 1024) {
+  // The chosen rows over the block's columns [c0w, c0w+sw) and the tracking words [0, uw), each with its own unit bit, AS READ
+  // (row k = insertion index k), and the 16 x 16 selector map that turns a row's bits on the pivot columns into the set of
+  // these raw rows to add: reduced pivot row k = XOR of the raw rows in b_trk[k], so a row whose word selects the pivot columns
+  // s must add the raw rows  XOR over c in s of b_trk[k(c)]  =  XOR over the nibbles of s of smap[nibble position][nibble].
+  // (Round 4.  Until round 3 this kernel combined the 64 reduced rows itself -- 4-bit tables over the selector bits, ten
+  // workgroup barriers, 11.5 of the step's ~47 us on ONE CU; the update kernel's tables are now built from the raw rows and
+  // every row's selector goes through the 2-KiB map first: sixteen 8-byte lookups per eight rows and lane group.)
+  for (int idx = tid; idx < 64 * 64; idx += 1024) {
     const int k = idx >> 6, wd = idx & 63;
-    const long long r = b_row[k];
     u64 v = 0;
-    if (wd < sw) {
-      v = A[r * lda + c0w + wd];
-    } else if (wd < sw + uw) {
-      const int u = wd - sw, jj = jbase + f_pos[k];
-      v = U[r * ldu + u] ^ ((jj >> 6) == u ? 1ull << (jj & 63) : 0);
-    }
-    stage[idx] = v;
-  }
-  __syncthreads();
-  // reduced pivot row k = XOR of the staged rows selected by b_trk[k], stored at its column-ordered position.  Four
-  // Russians over the 64 selector bits in 4-bit groups, 32 words at a time: 16 groups x 16 entries x 32 words = 64 KiB
-  // of (dynamic) LDS, 16 lookups per output word instead of ~32 dependent reads
-  extern __shared__ __attribute__((aligned(16))) u64 t4[];  // [group 16][entry 16][word 32]
-  for (int h = 0; h < 2; ++h) {
-    for (int it = tid; it < 16 * 5 * 32; it += 1024) {  // entry 0 and the single-row entries
-      const int w = it & 31, e5 = (it >> 5) % 5, g = (it >> 5) / 5;
-      const int e = e5 ? 1 << (e5 - 1) : 0;
-      const int k2 = g * 4 + (e5 - 1);
-      t4[(g * 16 + e) * 32 + w] = (e5 && k2 < np) ? stage[k2 * 64 + h * 32 + w] : 0;
-    }
-    __syncthreads();
-    for (int bits = 2; bits <= 4; ++bits) {
-      for (int it = tid; it < 16 * 16 * 32; it += 1024) {
-        const int w = it & 31, e = (it >> 5) & 15, g = it >> 9;
-        if (__popc(e) == bits) t4[(g * 16 + e) * 32 + w] = t4[(g * 16 + (e & (e - 1))) * 32 + w] ^ t4[(g * 16 + (e & -e)) * 32 + w];
+    if (k < np) {
+      const long long r = b_row[k];
+      if (wd < sw) {
+        v = A[r * lda + c0w + wd];
+      } else if (wd < sw + uw) {
+        const int u = wd - sw, jj = jbase + f_pos[k];
+        v = U[r * ldu + u] ^ ((jj >> 6) == u ? 1ull << (jj & 63) : 0);
       }
-      __syncthreads();
     }
-    for (int it = tid; it < np * 32; it += 1024) {
-      const int k = it >> 5, w = it & 31;
-      const u64 t = b_trk[k];
-      u64 acc = 0;
+    ptab[idx] = v;
+  }
+  if (tid < 64) s_col2k[tid] = -1;
+  __syncthreads();
+  if (tid < np) s_col2k[b_col[tid]] = tid;
+  __syncthreads();
+  if (tid < 256) {
+    const int g = tid >> 4, v4 = tid & 15;
+    u64 x = 0;
 #pragma unroll
-      for (int g = 0; g < 16; ++g) acc ^= t4[(g * 16 + (int)((t >> (4 * g)) & 15)) * 32 + w];
-      ptab[f_pos[k] * 64 + h * 32 + w] = acc;
+    for (int b2 = 0; b2 < 4; ++b2) {
+      const int k = s_col2k[4 * g + b2];
+      if (((v4 >> b2) & 1) && k >= 0) x ^= b_trk[k];
     }
-    __syncthreads();  // the table is rebuilt for the other half of the words
+    ptab[64 * 64 + tid] = x;
   }
 }
 
@@ -247,7 +239,7 @@ __global__ __launch_bounds__(1024) void gf2_elim_pivot_kernel(const u64 *__restr
 // overwritten with their reduced form, which is the single-bit table entry of their pivot column.  Four Russians with 4-bit groups: for each nibble of
 // the 64-bit selector word a 16-entry table of XOR combinations, 16 x 16 entries of 512 B (one LDS bank row each:
 // lane = word, conflict-free) = 128 KiB, built once per workgroup; a row then costs 16 lookups.
-constexpr int kUpdLds = 16 * 16 * 64 * 8;
+constexpr int kUpdLds = 16 * 16 * 64 * 8 + 256 * 8;  // the tables and the selector map
 __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__ A, long long lda, int m, int full,
                                                                long long c0w, int sw, int j, u64 *__restrict__ U,
                                                                long long ldu, int uw, const gf2k_elim_state *st,
@@ -258,15 +250,17 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
   const int np = st->np, r0s = st->r0;
   const u64 pcmask = st->pcmask;
   if (np == 0) return;
-  // level 0/1: entry 0 and the single-bit entries (bit b of the word = pivot popcount(pcmask below b), or nothing)
+  // level 0/1: entry 0 and the single-bit entries: bit i = the step's i-th chosen row as the pivot kernel read it (raw; rows past
+  // np are zero).  The selector map (see the pivot kernel) goes into LDS behind the tables.
+  u64 *smap = tab + 16 * 16 * 64;
+  if (tid < 256) smap[tid] = ptab[64 * 64 + tid];
   for (int it = tid; it < 16 * 5 * 64; it += 1024) {
     const int wd = it & 63, e5 = (it >> 6) % 5, g = (it >> 6) / 5;
     u64 v = 0;
     int e = 0;
     if (e5) {
       e = 1 << (e5 - 1);
-      const int b = g * 4 + (e5 - 1);
-      if ((pcmask >> b) & 1) v = ptab[__popcll(pcmask & ((1ull << b) - 1)) * 64 + wd];
+      v = ptab[(g * 4 + (e5 - 1)) * 64 + wd];
     }
     tab[(g * 16 + e) * 64 + wd] = v;
   }
@@ -289,33 +283,46 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
   const int gw = blockIdx.x * 16 + wave, nw = gridDim.x * 16;
   constexpr int RG = 8;
   for (long long r0 = rows_lo + (long long)gw * RG; r0 < m; r0 += (long long)nw * RG) {
-    u64 sel[RG], old[RG];
+    u64 old[RG];
     const long long rf = r0 + (lane & 7);
     const int flv = rf < m ? rowflag[rf] : 0;  // lanes 0..7: flags of the pass's rows
+    // lane group q = lane / 8 maps the selector of row r0 + q: its word's bits on the pivot columns (a pivot row of this step: the
+    // single bit of its pivot column, i.e. its reduced form), two nibbles per lane, folded over the eight lanes by DPP
+    const long long rq = r0 + (lane >> 3);
+    const int flq = rq < m ? rowflag[rq] : 0;
+    u64 sq = rq < m ? A[rq * lda + wc] & pcmask : 0;
+    if (flq >= 1 && flq <= 64) sq = 1ull << (flq - 1);
 #pragma unroll
     for (int q = 0; q < RG; ++q) {
       const long long r = r0 + q;
-      sel[q] = r < m ? A[r * lda + wc] & pcmask : 0;
       old[q] = (act && r < m) ? base[r * ld] : 0;
+    }
+    const int h2 = (lane & 7) * 2;
+    u64 x = smap[h2 * 16 + (int)((sq >> (4 * h2)) & 15)] ^ smap[(h2 + 1) * 16 + (int)((sq >> (4 * h2 + 4)) & 15)];
+    {
+      unsigned lo = (unsigned)x, hi = (unsigned)(x >> 32);
+      lo ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]: lane ^ 1
+      hi ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, 0xB1, 0xf, 0xf, true);
+      lo ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0x4E, 0xf, 0xf, true);  // quad_perm [2,3,0,1]: lane ^ 2
+      hi ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, 0x4E, 0xf, 0xf, true);
+      lo ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0x141, 0xf, 0xf, true);  // row_half_mirror: lane ^ 7 (the quads are uniform by now)
+      hi ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, 0x141, 0xf, 0xf, true);
+      x = (u64)lo | ((u64)hi << 32);
     }
 #pragma unroll
     for (int q = 0; q < RG; ++q) {
       const int fl = __builtin_amdgcn_readlane(flv, q);
-      if (fl >= 1 && fl <= 64) {  // pivot of this step with pivot column fl-1: the row becomes its reduced form
-        const int c = fl - 1;
-        if (act && r0 + q < m) base[(r0 + q) * ld] = tab[((c >> 2) * 16 + (1 << (c & 3))) * 64 + tword];
-        continue;
-      }
-      const u64 s = readfirst64(sel[q]);
-      if (!s) continue;
-      const unsigned lo = (unsigned)s, hi = (unsigned)(s >> 32);
+      const unsigned lo = __builtin_amdgcn_readlane((unsigned)x, 8 * q), hi = __builtin_amdgcn_readlane((unsigned)(x >> 32), 8 * q);
+      if ((lo | hi) == 0) continue;
       u64 acc = 0;
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         const unsigned idx = ((g < 8 ? lo : hi) >> (4 * (g & 7))) & 15u;
         acc ^= tab[(g * 16 + idx) * 64 + tword];
       }
-      if (act && r0 + q < m) base[(r0 + q) * ld] = old[q] ^ acc;
+      // a pivot of this step becomes its reduced form (the XOR of the raw rows in its b_trk); every other row adds what its word selects
+      const bool piv = fl >= 1 && fl <= 64;
+      if (act && r0 + q < m) base[(r0 + q) * ld] = piv ? acc : old[q] ^ acc;
     }
   }
 }
@@ -551,16 +558,12 @@ extern "C" hipError_t gf2k_elim_step(u64 *A, long long lda, int m, long long c0w
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
   if (!attr_done[dev & 63]) {
-    // 64 KiB of dynamic LDS for the tables that combine the reduced pivot rows, on top of ~37 KiB static
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gf2_elim_pivot_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gf2_elim_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              kUpdLds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gf2_elim_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       kUpdLds);
     if (e != hipSuccess) return e;
     attr_done[dev & 63] = true;
   }
-  hipLaunchKernelGGL(gf2_elim_pivot_kernel, dim3(1), dim3(1024), 65536, s, A, lda, m, c0w, sw, j, colmask, U, ldu, uw, st,
+  hipLaunchKernelGGL(gf2_elim_pivot_kernel, dim3(1), dim3(1024), 0, s, A, lda, m, c0w, sw, j, colmask, U, ldu, uw, st,
                      pivcols, ptab, rowflag, blkpiv);
   // 8 rows per wave and pass, 16 waves per workgroup, one workgroup per CU (128 KiB of LDS tables each)
   int grid = (m + 127) / 128;
