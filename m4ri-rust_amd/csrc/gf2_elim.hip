@@ -48,21 +48,40 @@ __device__ __forceinline__ int rdlane32(int v, int lane) {
   return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(lane));
 }
 
-__global__ __launch_bounds__(1024) void gf2_elim_pivot_kernel(const u64 *__restrict__ A, long long lda, int m, long long c0w,
-                                                              int sw, int j, u64 colmask, const u64 *__restrict__ U,
-                                                              long long ldu, int uw, gf2k_elim_state *st, int *pivcols,
-                                                              u64 *__restrict__ ptab, unsigned char *rowflag,
-                                                              int *__restrict__ blkpiv) {
+// shared state of the pivot search (one workgroup): a member of the calling kernel's LDS
+struct ElimPivotShared {
   // basis vector k: b_word[k] is clear on the pivot column of every other vector (kept fully reduced), b_trk[k] says
   // which of the chosen rows (by insertion index, as originally read) it is the XOR of
-  __shared__ u64 b_word[64], b_trk[64];
-  __shared__ int b_row[64], b_col[64];
-  __shared__ int s_nb;
-  __shared__ int s_nz[16];
-  __shared__ int f_pos[64];
-  __shared__ unsigned char s_chosen[256];  // rows scan0 .. scan0+255 picked by this step
-  __shared__ int s_lead[4];
-  __shared__ int s_col2k[64];
+  u64 b_word[64], b_trk[64];
+  int b_row[64], b_col[64];
+  int s_nb;
+  int s_nz[16];
+  int f_pos[64];
+  unsigned char s_chosen[256];  // rows scan0 .. scan0+255 picked by this step
+  int s_lead[4];
+  int s_col2k[64];
+};
+
+// loads that see what other workgroups of the SAME launch stored with agent scope (the look-ahead search reads the word column the
+// update workgroups have just rewritten; L2 is not coherent across XCDs for plain accesses)
+template <bool COH, typename T>
+__device__ __forceinline__ T elim_ld(const T *p) {
+  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+
+// The pivot step of word column j of the block: SEARCH (reads the column's word of the candidate rows and their flags, keeps the
+// basis in LDS, writes nothing to global memory), then `between()` (the look-ahead form waits there until every update workgroup
+// of the launch has finished), then PUBLISH (flags, state, pivot columns, the raw chosen rows and the selector map).
+template <bool COH, typename Between>
+__device__ __forceinline__ void elim_pivot_step(ElimPivotShared &sm, const u64 *A, long long lda, int m, long long c0w,
+                                                int sw, int j, u64 colmask, const u64 *U, long long ldu, int uw,
+                                                gf2k_elim_state *st, int *pivcols, u64 *__restrict__ ptab, unsigned char *rowflag,
+                                                int *__restrict__ blkpiv, Between between) {
+  u64 (&b_word)[64] = sm.b_word, (&b_trk)[64] = sm.b_trk;
+  int (&b_row)[64] = sm.b_row, (&b_col)[64] = sm.b_col, &s_nb = sm.s_nb, (&s_nz)[16] = sm.s_nz, (&f_pos)[64] = sm.f_pos;
+  unsigned char (&s_chosen)[256] = sm.s_chosen;
+  int (&s_lead)[4] = sm.s_lead, (&s_col2k)[64] = sm.s_col2k;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r_cur = st->r_cur;
   const int jbase = r_cur - st->r0;
@@ -70,7 +89,6 @@ __global__ __launch_bounds__(1024) void gf2_elim_pivot_kernel(const u64 *__restr
   const long long wc = c0w + j;
   if (tid == 0) s_nb = 0;
   if (tid < 256) s_chosen[tid] = 0;
-  if (tid < st->np) rowflag[st->cur_row[tid]] = 255;  // the previous step's pivots become "pivot of this block"
   unsigned char f0 = 1;                                // flag of row scan0 + tid before this step (first pass, tid < 256)
   __syncthreads();
   // the first pass looks at 256 rows only (one wave per SIMD: nearly always enough for 64 pivots, and the waves that
@@ -81,8 +99,8 @@ __global__ __launch_bounds__(1024) void gf2_elim_pivot_kernel(const u64 *__restr
     // w: candidate reduced against the basis; t: which chosen rows were added to it
     // flag and word are requested together (the word of a flagged row is simply discarded): one memory latency, not two
     const bool inr = tid < csz && i < m;
-    const unsigned char fl = inr ? rowflag[i] : 1;  // pivots of this block are no candidates
-    const u64 wraw = inr ? A[(long long)i * lda + wc] : 0;
+    const unsigned char fl = inr ? elim_ld<COH>(rowflag + i) : 1;  // pivots of this block (and of the step being applied) are no candidates
+    const u64 wraw = inr ? elim_ld<COH>(A + (long long)i * lda + wc) : 0;
     if (base == scan0) f0 = fl;
     u64 w = fl == 0 ? (wraw & colmask) : 0, t = 0;
     int done = 0;  // basis vectors already applied to w
@@ -154,6 +172,9 @@ __global__ __launch_bounds__(1024) void gf2_elim_pivot_kernel(const u64 *__restr
   }
   __syncthreads();
   const int np = s_nb;
+  between();  // (contains workgroup barriers; everything below writes global memory)
+  if (tid < st->np) rowflag[st->cur_row[tid]] = 255;  // the previous step's pivots become "pivot of this block"
+  __syncthreads();
 
   // order the pivots by column: vector k is pivot jbase + pos[k] of the block
   if (wave == 0) {
@@ -211,10 +232,10 @@ __global__ __launch_bounds__(1024) void gf2_elim_pivot_kernel(const u64 *__restr
     if (k < np) {
       const long long r = b_row[k];
       if (wd < sw) {
-        v = A[r * lda + c0w + wd];
+        v = elim_ld<COH>(A + r * lda + c0w + wd);
       } else if (wd < sw + uw) {
         const int u = wd - sw, jj = jbase + f_pos[k];
-        v = U[r * ldu + u] ^ ((jj >> 6) == u ? 1ull << (jj & 63) : 0);
+        v = elim_ld<COH>(U + r * ldu + u) ^ ((jj >> 6) == u ? 1ull << (jj & 63) : 0);
       }
     }
     ptab[idx] = v;
@@ -235,24 +256,85 @@ __global__ __launch_bounds__(1024) void gf2_elim_pivot_kernel(const u64 *__restr
   }
 }
 
+__global__ __launch_bounds__(1024) void gf2_elim_pivot_kernel(const u64 *__restrict__ A, long long lda, int m, long long c0w,
+                                                              int sw, int j, u64 colmask, const u64 *__restrict__ U,
+                                                              long long ldu, int uw, gf2k_elim_state *st, int *pivcols,
+                                                              u64 *__restrict__ ptab, unsigned char *rowflag,
+                                                              int *__restrict__ blkpiv) {
+  __shared__ ElimPivotShared sm;
+  elim_pivot_step<false>(sm, A, lda, m, c0w, sw, j, colmask, U, ldu, uw, st, pivcols, ptab, rowflag, blkpiv, [] {});
+}
+
 // every row adds the pivot rows selected by its bits on the pivot columns; the step's own pivot rows (row flag) are
 // overwritten with their reduced form, which is the single-bit table entry of their pivot column.  Four Russians with 4-bit groups: for each nibble of
 // the 64-bit selector word a 16-entry table of XOR combinations, 16 x 16 entries of 512 B (one LDS bank row each:
 // lane = word, conflict-free) = 128 KiB, built once per workgroup; a row then costs 16 lookups.
-constexpr int kUpdLds = 16 * 16 * 64 * 8 + 256 * 8;  // the tables and the selector map
+constexpr int kUpdLds = 16 * 16 * 64 * 8 + 256 * 8 + 256 * 8;  // the tables, the selector map, the next word column's slice of the tables
+
+// Bounded wait of the look-ahead workgroup for a counter the update workgroups of the same launch raise (every one of them raises
+// it, whatever it did, and none of them waits for anything: they are all dispatched before or alongside this workgroup because the
+// grid fits the chip -- at most 256 update workgroups of one per CU -- so the wait ends; the bound turns a scheduling surprise
+// into an error flag instead of a hang).
+__device__ __forceinline__ void elim_wait_count(int *cnt, int want, int *err) {
+  if (threadIdx.x == 0) {
+    int spins = 0;
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {  // (relaxed: an acquire here is an L2 invalidate per turn)
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1 << 22)) {  // ~1 s
+        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  // no acquire fence here (an agent-scope fence invalidates / writes back the whole L2 of the XCD): whatever this workgroup reads
+  // of the launch's own stores it reads with agent-scope atomic loads (elim_ld<true>), and the update workgroups store those words
+  // with agent-scope atomic stores (write-through)
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// LOOK (round 4): the launch has one workgroup more than it has update workgroups.  Every update workgroup first rewrites the NEXT
+// word column (j + 1) of its share of the rows -- one row per lane, a 2-KiB slice of the tables -- and raises st->cnt1; the extra
+// workgroup waits for all of them, runs the pivot SEARCH of step j + 1 on that column while the others update the remaining
+// words, waits for st->cnt2 (everything updated), and PUBLISHES step j + 1 (flags, state, raw pivot rows, selector map).  A step
+// is then one launch, and the one-CU search (~12 us) runs beside the update instead of behind it.
+template <bool LOOK>
 __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__ A, long long lda, int m, int full,
                                                                long long c0w, int sw, int j, u64 *__restrict__ U,
-                                                               long long ldu, int uw, const gf2k_elim_state *st,
-                                                               const u64 *__restrict__ ptab,
-                                                               const unsigned char *__restrict__ rowflag) {
+                                                               long long ldu, int uw, gf2k_elim_state *st,
+                                                               u64 *__restrict__ ptab, unsigned char *__restrict__ rowflag,
+                                                               u64 colmask_next, int *pivcols, int *__restrict__ blkpiv) {
   extern __shared__ __attribute__((aligned(16))) u64 tab[];  // [group 16][entry 16][word 64]
+  __shared__ ElimPivotShared sm;  // (the look-ahead workgroup's search state)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nupd = LOOK ? (int)gridDim.x - 1 : (int)gridDim.x;  // update workgroups
+  if (LOOK && (int)blockIdx.x == nupd) {
+    elim_wait_count(&st->cnt1, nupd, &st->err);
+    elim_pivot_step<true>(sm, A, lda, m, c0w, sw, j + 1, colmask_next, U, ldu, uw, st, pivcols, ptab, rowflag, blkpiv,
+                          [&] { elim_wait_count(&st->cnt2, nupd, &st->err); });
+    __syncthreads();
+    if (tid == 0) {  // every update workgroup is done: ready for the next launch
+      __hip_atomic_store(&st->cnt1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&st->cnt2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
   const int np = st->np, r0s = st->r0;
   const u64 pcmask = st->pcmask;
-  if (np == 0) return;
+  // this workgroup's (write-through, agent-scope) stores so far have completed, then the count goes up.  NOT __threadfence():
+  // its L2 write-back, once per wave and raise, made a step 160 us slower at 65536 rows (measured, round 4).
+  auto raise = [&](int *cnt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  if (np == 0) {
+    if (LOOK) raise(&st->cnt1), raise(&st->cnt2);
+    return;
+  }
   // level 0/1: entry 0 and the single-bit entries: bit i = the step's i-th chosen row as the pivot kernel read it (raw; rows past
   // np are zero).  The selector map (see the pivot kernel) goes into LDS behind the tables.
-  u64 *smap = tab + 16 * 16 * 64;
+  u64 *smap = tab + 16 * 16 * 64, *nxt = smap + 256;
   if (tid < 256) smap[tid] = ptab[64 * 64 + tid];
   for (int it = tid; it < 16 * 5 * 64; it += 1024) {
     const int wd = it & 63, e5 = (it >> 6) % 5, g = (it >> 6) / 5;
@@ -280,7 +362,34 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
   const int tword = isS ? j + lane : (act ? sw + (lane - nS) : 0);
   u64 *const base = isS ? A + wc + lane : U + (lane - nS);
   const long long ld = isS ? lda : ldu;
-  const int gw = blockIdx.x * 16 + wave, nw = gridDim.x * 16;
+  if constexpr (LOOK) {
+    // ---- the next word column first (j + 1 < sw): its slice of the tables, then one row per lane ----
+    if (tid < 256) nxt[tid] = tab[tid * 64 + (j + 1)];
+    __syncthreads();
+    u64 *const col = A + wc + 1;
+    // (the SAME rows as this workgroup's waves take below -- 128-row pieces every 128 * nupd rows -- because word j, the selector,
+    // is rewritten there)
+    for (long long k = tid >> 7;; k += 8) {
+      const long long r = rows_lo + ((long long)blockIdx.x + k * nupd) * 128 + (tid & 127);
+      if (r - (tid & 127) >= m) break;
+      if (r >= m) continue;
+      const int fl = rowflag[r];
+      const bool piv = fl >= 1 && fl <= 64;
+      const u64 sq = piv ? 1ull << (fl - 1) : A[r * lda + wc] & pcmask;
+      if (!sq) continue;
+      u64 x = 0;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) x ^= smap[g * 16 + (int)((sq >> (4 * g)) & 15)];
+      u64 acc = 0;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc ^= nxt[g * 16 + (int)((x >> (4 * g)) & 15)];
+      const u64 v = piv ? acc : col[r * lda] ^ acc;
+      __hip_atomic_store(col + r * lda, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (seen by the look-ahead workgroup's loads)
+    }
+    raise(&st->cnt1);
+  }
+  const bool skip = LOOK && isS && lane == 1;  // word j + 1 is done
+  const int gw = blockIdx.x * 16 + wave, nw = nupd * 16;
   constexpr int RG = 8;
   for (long long r0 = rows_lo + (long long)gw * RG; r0 < m; r0 += (long long)nw * RG) {
     u64 old[RG];
@@ -322,9 +431,14 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
       }
       // a pivot of this step becomes its reduced form (the XOR of the raw rows in its b_trk); every other row adds what its word selects
       const bool piv = fl >= 1 && fl <= 64;
-      if (act && r0 + q < m) base[(r0 + q) * ld] = piv ? acc : old[q] ^ acc;
+      if (act && !skip && r0 + q < m) {
+        const u64 v = piv ? acc : old[q] ^ acc;
+        if constexpr (LOOK) __hip_atomic_store(base + (r0 + q) * ld, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (the look-ahead workgroup reads the rows it chose)
+        else base[(r0 + q) * ld] = v;
+      }
     }
   }
+  if constexpr (LOOK) raise(&st->cnt2);
 }
 
 // ---- end of a block: block pivot j (row blkpiv[j]) goes to row r0 + j; the non-pivot rows that sit inside
@@ -550,7 +664,7 @@ extern "C" hipError_t gf2k_elim_begin_block(gf2k_elim_state *st, hipStream_t s) 
 
 extern "C" hipError_t gf2k_elim_step(u64 *A, long long lda, int m, long long c0w, int sw, int j, u64 colmask, int full,
                                      u64 *U, long long ldu, int uw, gf2k_elim_state *st, int *pivcols, u64 *ptab,
-                                     unsigned char *rowflag, int *blkpiv, hipStream_t s) {
+                                     unsigned char *rowflag, int *blkpiv, u64 colmask_next, int lookahead, hipStream_t s) {
   if (sw + uw > 64 || j >= sw || sw * 64 > GF2K_ELIM_BLOCK_PIVOTS) return hipErrorInvalidValue;
   // dynamic LDS limits are per device: set them once per device, not per step (the call costs host time that a chain
   // of 50 us steps notices)
@@ -558,19 +672,34 @@ extern "C" hipError_t gf2k_elim_step(u64 *A, long long lda, int m, long long c0w
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
   if (!attr_done[dev & 63]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gf2_elim_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gf2_elim_update_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        kUpdLds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gf2_elim_update_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kUpdLds);
     if (e != hipSuccess) return e;
     attr_done[dev & 63] = true;
   }
-  hipLaunchKernelGGL(gf2_elim_pivot_kernel, dim3(1), dim3(1024), 0, s, A, lda, m, c0w, sw, j, colmask, U, ldu, uw, st,
-                     pivcols, ptab, rowflag, blkpiv);
   // 8 rows per wave and pass, 16 waves per workgroup, one workgroup per CU (128 KiB of LDS tables each)
   int grid = (m + 127) / 128;
-  if (grid > 256) grid = 256;
+  if (grid > 255) grid = 255;  // (+ the look-ahead workgroup: the whole grid is resident at once)
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(gf2_elim_update_kernel, dim3(grid), dim3(1024), kUpdLds, s, A, lda, m, full, c0w, sw, j, U, ldu, uw, st,
-                     ptab, rowflag);
+  if (!lookahead) {
+    hipLaunchKernelGGL(gf2_elim_pivot_kernel, dim3(1), dim3(1024), 0, s, A, lda, m, c0w, sw, j, colmask, U, ldu, uw, st, pivcols, ptab,
+                       rowflag, blkpiv);
+    hipLaunchKernelGGL(gf2_elim_update_kernel<false>, dim3(grid), dim3(1024), kUpdLds, s, A, lda, m, full, c0w, sw, j, U, ldu, uw, st,
+                       ptab, rowflag, colmask_next, pivcols, blkpiv);
+    return hipGetLastError();
+  }
+  // look-ahead: the search of step j + 1 runs inside the update launch of step j; the block's first step is searched on its own
+  if (j == 0)
+    hipLaunchKernelGGL(gf2_elim_pivot_kernel, dim3(1), dim3(1024), 0, s, A, lda, m, c0w, sw, j, colmask, U, ldu, uw, st, pivcols, ptab,
+                       rowflag, blkpiv);
+  if (j + 1 < sw)
+    hipLaunchKernelGGL(gf2_elim_update_kernel<true>, dim3(grid + 1), dim3(1024), kUpdLds, s, A, lda, m, full, c0w, sw, j, U, ldu, uw, st,
+                       ptab, rowflag, colmask_next, pivcols, blkpiv);
+  else
+    hipLaunchKernelGGL(gf2_elim_update_kernel<false>, dim3(grid), dim3(1024), kUpdLds, s, A, lda, m, full, c0w, sw, j, U, ldu, uw, st,
+                       ptab, rowflag, colmask_next, pivcols, blkpiv);
   return hipGetLastError();
 }
 

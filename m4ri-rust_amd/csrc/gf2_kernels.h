@@ -46,6 +46,8 @@ struct gf2k_elim_state {
   int lastword;  // after gf2k_elim_end_block: last word index (absolute) in which a pivot row of the block is non-zero
   unsigned long long pcmask;  // pivot columns of the current word
   int cur_row[64];            // rows chosen by the current step (their flag says "pivot of this step" until the next one)
+  int cnt1, cnt2;             // look-ahead launches: update workgroups that have rewritten the next word column / everything
+  int err;                    // set when the look-ahead workgroup's bounded wait ran out (never expected)
 };
 // Row flags (one byte per row) during a block: 0 = ordinary row, 1 + c = pivot of the CURRENT step with pivot column c of
 // the word, 255 = pivot of an earlier step of this block.  Rows are not moved inside a block; gf2k_elim_end_block brings
@@ -56,7 +58,7 @@ extern "C" {
 hipError_t gf2k_elim_begin_block(gf2k_elim_state *st, hipStream_t s);
 hipError_t gf2k_elim_step(uint64_t *A, long long lda, int m, long long c0w, int sw, int j, uint64_t colmask, int full,
                           uint64_t *U, long long ldu, int uw, gf2k_elim_state *st, int *pivcols, uint64_t *ptab,
-                          unsigned char *rowflag, int *blkpiv, hipStream_t s);
+                          unsigned char *rowflag, int *blkpiv, uint64_t colmask_next, int lookahead, hipStream_t s);
 // end of a block: permutation of whole rows (columns [c0w, aw) and the tracking words) through `tmp` (>= 2 *
 // GF2K_ELIM_BLOCK_PIVOTS rows of tld words), flags cleared, U' toggled, st->lastword set over words [w_right, aw);
 // `moves` holds 4 * GF2K_ELIM_BLOCK_PIVOTS ints

@@ -2438,6 +2438,8 @@ int echelonize_dev(gf2_dmat *A, int full, int col_limit, int *rank_out, int *piv
   HIP_TRY(hipMemsetAsync(dst, 0, sizeof(gf2k_elim_state), s));
   HIP_TRY(hipMemsetAsync(flags.p, 0, (size_t)m, s));
 
+  // the pivot search of step j + 1 inside the update launch of step j (gf2_elim.hip, round 4); 0: two launches per step as before
+  static const int lookahead = dev_env_int("M4RI_HIP_ELIM_LOOKAHEAD", 1);
   int r_cur = 0;
   for (long long c0w = 0; c0w < lw && r_cur < m; c0w += KBW) {
     const int sw = (int)(lw - c0w < KBW ? lw - c0w : KBW);
@@ -2446,14 +2448,18 @@ int echelonize_dev(gf2_dmat *A, int full, int col_limit, int *rank_out, int *piv
     for (int j = 0; j < sw; ++j) {
       const bool last = (c0w + j == lw - 1) && (limit & 63);
       const u64 colmask = last ? ((1ull << (limit & 63)) - 1) : ~0ull;
+      const bool last_next = (c0w + j + 1 == lw - 1) && (limit & 63);
+      const u64 colmask_next = last_next ? ((1ull << (limit & 63)) - 1) : ~0ull;
       HIP_TRY(gf2k_elim_step(A->data, lda, m, c0w, sw, j, colmask, full, U.as<u64>(), uw, uw, dst, pv.as<int>(),
-                             ptab.as<u64>(), flags.as<unsigned char>(), blkpiv.as<int>(), s));
+                             ptab.as<u64>(), flags.as<unsigned char>(), blkpiv.as<int>(), colmask_next, lookahead, s));
     }
     HIP_TRY(gf2k_elim_end_block(A->data, lda, aw, c0w, U.as<u64>(), uw, uw, dst, flags.as<unsigned char>(), blkpiv.as<int>(),
                                 moves.as<int>(), tmp.as<u64>(), tld, c0w + sw, s));
-    int head[7] = {0, 0, 0, 0, 0, 0, -1};  // r0, r_cur, np, nmoves, jbase, scan, lastword
-    HIP_TRY(hipMemcpyAsync(head, dst, sizeof(head), hipMemcpyDeviceToHost, s));
+    gf2k_elim_state hst;
+    HIP_TRY(hipMemcpyAsync(&hst, dst, sizeof(hst), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    if (hst.err) return fail_msg("gf2 elimination: the look-ahead workgroup's wait for the update workgroups ran out");
+    const int head[7] = {hst.r0, hst.r_cur, hst.np, hst.nmoves, hst.jbase, hst.scan, hst.lastword};
     const int r0 = head[0], rp = head[1] - head[0];
     r_cur = head[1];
     const long long cR = c0w + sw;
