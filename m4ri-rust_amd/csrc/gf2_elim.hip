@@ -336,6 +336,43 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
   // np are zero).  The selector map (see the pivot kernel) goes into LDS behind the tables.
   u64 *smap = tab + 16 * 16 * 64, *nxt = smap + 256;
   if (tid < 256) smap[tid] = ptab[64 * 64 + tid];
+  const int rows_lo = full ? 0 : r0s;
+  const long long wc = c0w + j;
+  if constexpr (LOOK) {
+    // ---- the next word column first (j + 1 < sw), before the tables: its 2-KiB slice of them straight from the raw rows, then
+    // one row per lane; the look-ahead workgroup starts its search ~5 us into the launch ----
+    if (tid < 256) {
+      const int g = tid >> 4, e = tid & 15;
+      u64 v = 0;
+#pragma unroll
+      for (int b2 = 0; b2 < 4; ++b2)
+        if ((e >> b2) & 1) v ^= ptab[(g * 4 + b2) * 64 + (j + 1)];
+      nxt[tid] = v;
+    }
+    __syncthreads();
+    u64 *const col = A + wc + 1;
+    // (the SAME rows as this workgroup's waves take below -- 128-row pieces every 128 * nupd rows -- because word j, the selector,
+    // is rewritten there)
+    for (long long k = tid >> 7;; k += 8) {
+      const long long r = rows_lo + ((long long)blockIdx.x + k * nupd) * 128 + (tid & 127);
+      if (r - (tid & 127) >= m) break;
+      if (r >= m) continue;
+      const int fl = rowflag[r];  // flag, selector word and old word in one memory latency
+      const u64 wsel = A[r * lda + wc], wold = col[r * lda];
+      const bool piv = fl >= 1 && fl <= 64;
+      const u64 sq = piv ? 1ull << (fl - 1) : wsel & pcmask;
+      if (!sq) continue;
+      u64 x = 0;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) x ^= smap[g * 16 + (int)((sq >> (4 * g)) & 15)];
+      u64 acc = 0;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc ^= nxt[g * 16 + (int)((x >> (4 * g)) & 15)];
+      const u64 v = piv ? acc : wold ^ acc;
+      __hip_atomic_store(col + r * lda, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (seen by the look-ahead workgroup's loads)
+    }
+    raise(&st->cnt1);
+  }
   for (int it = tid; it < 16 * 5 * 64; it += 1024) {
     const int wd = it & 63, e5 = (it >> 6) % 5, g = (it >> 6) / 5;
     u64 v = 0;
@@ -355,39 +392,11 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
     }
     __syncthreads();
   }
-  const int rows_lo = full ? 0 : r0s;
-  const long long wc = c0w + j;
   const int nS = sw - j;
   const bool isS = lane < nS, act = lane < nS + uw;
   const int tword = isS ? j + lane : (act ? sw + (lane - nS) : 0);
   u64 *const base = isS ? A + wc + lane : U + (lane - nS);
   const long long ld = isS ? lda : ldu;
-  if constexpr (LOOK) {
-    // ---- the next word column first (j + 1 < sw): its slice of the tables, then one row per lane ----
-    if (tid < 256) nxt[tid] = tab[tid * 64 + (j + 1)];
-    __syncthreads();
-    u64 *const col = A + wc + 1;
-    // (the SAME rows as this workgroup's waves take below -- 128-row pieces every 128 * nupd rows -- because word j, the selector,
-    // is rewritten there)
-    for (long long k = tid >> 7;; k += 8) {
-      const long long r = rows_lo + ((long long)blockIdx.x + k * nupd) * 128 + (tid & 127);
-      if (r - (tid & 127) >= m) break;
-      if (r >= m) continue;
-      const int fl = rowflag[r];
-      const bool piv = fl >= 1 && fl <= 64;
-      const u64 sq = piv ? 1ull << (fl - 1) : A[r * lda + wc] & pcmask;
-      if (!sq) continue;
-      u64 x = 0;
-#pragma unroll
-      for (int g = 0; g < 16; ++g) x ^= smap[g * 16 + (int)((sq >> (4 * g)) & 15)];
-      u64 acc = 0;
-#pragma unroll
-      for (int g = 0; g < 16; ++g) acc ^= nxt[g * 16 + (int)((x >> (4 * g)) & 15)];
-      const u64 v = piv ? acc : col[r * lda] ^ acc;
-      __hip_atomic_store(col + r * lda, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (seen by the look-ahead workgroup's loads)
-    }
-    raise(&st->cnt1);
-  }
   const bool skip = LOOK && isS && lane == 1;  // word j + 1 is done
   const int gw = blockIdx.x * 16 + wave, nw = nupd * 16;
   constexpr int RG = 8;
