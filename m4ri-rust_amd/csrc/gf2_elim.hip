@@ -338,6 +338,11 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
   if (tid < 256) smap[tid] = ptab[64 * 64 + tid];
   const int rows_lo = full ? 0 : r0s;
   const long long wc = c0w + j;
+  // this workgroup's rows: one contiguous piece, a multiple of the 8 rows a wave takes per pass (65536 rows over 255 workgroups:
+  // 264 rows each, i.e. two passes of the 16 waves and a third of one wave -- 128-row pieces dealt round-robin gave two workgroups
+  // three full passes)
+  const long long per = ((((long long)m - rows_lo + nupd - 1) / nupd) + 7) & ~7ll;
+  const long long row_b = rows_lo + (long long)blockIdx.x * per, row_e = min((long long)m, row_b + per);
   if constexpr (LOOK) {
     // ---- the next word column first (j + 1 < sw), before the tables: its 2-KiB slice of them straight from the raw rows, then
     // one row per lane; the look-ahead workgroup starts its search ~5 us into the launch ----
@@ -351,12 +356,8 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
     }
     __syncthreads();
     u64 *const col = A + wc + 1;
-    // (the SAME rows as this workgroup's waves take below -- 128-row pieces every 128 * nupd rows -- because word j, the selector,
-    // is rewritten there)
-    for (long long k = tid >> 7;; k += 8) {
-      const long long r = rows_lo + ((long long)blockIdx.x + k * nupd) * 128 + (tid & 127);
-      if (r - (tid & 127) >= m) break;
-      if (r >= m) continue;
+    // (the SAME rows as this workgroup's waves take below, because word j, the selector, is rewritten there)
+    for (long long r = row_b + tid; r < row_e; r += 1024) {
       const int fl = rowflag[r];  // flag, selector word and old word in one memory latency
       const u64 wsel = A[r * lda + wc], wold = col[r * lda];
       const bool piv = fl >= 1 && fl <= 64;
@@ -393,14 +394,17 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
     __syncthreads();
   }
   const int nS = sw - j;
-  const bool isS = lane < nS, act = lane < nS + uw;
+  // tracking words past the one that holds this step's last pivot (index jbase + np - 1 of the block) are zero in every row and
+  // in every table entry: those lanes neither load nor store (on average a third of the step's traffic)
+  const int uw_live = min(uw, ((st->jbase + np - 1) >> 6) + 1);
+  const bool isS = lane < nS, act = lane < nS + uw_live;
   const int tword = isS ? j + lane : (act ? sw + (lane - nS) : 0);
   u64 *const base = isS ? A + wc + lane : U + (lane - nS);
   const long long ld = isS ? lda : ldu;
   const bool skip = LOOK && isS && lane == 1;  // word j + 1 is done
-  const int gw = blockIdx.x * 16 + wave, nw = nupd * 16;
   constexpr int RG = 8;
-  for (long long r0 = rows_lo + (long long)gw * RG; r0 < m; r0 += (long long)nw * RG) {
+  for (long long r0 = row_b + wave * RG; r0 < row_e; r0 += 16 * RG) {
+    const long long m = row_e;  // (the bound of this workgroup's piece)
     u64 old[RG];
     const long long rf = r0 + (lane & 7);
     const int flv = rf < m ? rowflag[rf] : 0;  // lanes 0..7: flags of the pass's rows
