@@ -2474,7 +2474,8 @@ int echelonize_dev(gf2_dmat *A, int full, int col_limit, int *rank_out, int *piv
       gf2_dmat Uw{U.as<u64>() + (long long)rows_lo * uw, uw, m - rows_lo, rp};
       gf2_dmat Pw{P.as<u64>(), pld, rp, nright};
       // plain M4RM on purpose: (a) the callers hold g_enqueue_mu, which mul_dispatch takes itself; (b) Strassen levels over
-      // this shape (m x 2048 x n, through mul_strassen directly) were measured neutral: 85.7 against 85.3 ms at 65536^2
+      // this shape (m x 2048 x n, through mul_strassen directly) were measured neutral: 85.7 against 85.3 ms at 65536^2 (round 3);
+      // through the planner (GF2_ALGO_AUTO) again neutral in round 4: 58.58 against 58.56 ms, 16384^2 inverse 10.5 against 8.8
       if (int rc = mul_m4rm_plain(&Cw, &Uw, &Pw, 1, s)) return rc;
     }
   }
