@@ -3625,7 +3625,11 @@ __global__ __launch_bounds__(512, 8) void gf2_transpose512_kernel(u64 *__restric
     for (int k = 0; k < 8; ++k) {
       const long long row = (long long)tY * 512 + 64 * wave + 8 * k + rr;
       const int wc = C0w + w;
+#ifdef GF2K_DEV_VARIANTS  // timing-only ablations (wrong results): 4 = no loads, 8 = no stores, 16 = no butterfly
+      u64 v = (flags & 4) ? (u64)row * 0x9E3779B97F4A7C15ull : (row < rows && wc < sw) ? __builtin_nontemporal_load(S + row * lds_ + wc) : 0;
+#else
       u64 v = (row < rows && wc < sw) ? __builtin_nontemporal_load(S + row * lds_ + wc) : 0;
+#endif
       if (wc == sw - 1) v &= maskS;
       sin[wave][8 * k + rr][w] = v;
     }
@@ -3636,7 +3640,12 @@ __global__ __launch_bounds__(512, 8) void gf2_transpose512_kernel(u64 *__restric
       lo[j] = (u32)x, hi[j] = (u32)(x >> 32);
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) tr_block64(lo[j], hi[j], keep, rot);
+    for (int j = 0; j < 8; ++j) {
+#ifdef GF2K_DEV_VARIANTS
+      if (flags & 16) continue;
+#endif
+      tr_block64(lo[j], hi[j], keep, rot);
+    }
     __syncthreads();  // every wave has taken its staged rows out (and, from the second tile on, stored its output rows)
 #pragma unroll
     for (int j = 0; j < 8; ++j) sout[64 * j + lane][wave] = (u64)lo[j] | ((u64)hi[j] << 32);  // output row 64 j + lane, word = this wave's row block
@@ -3647,6 +3656,9 @@ __global__ __launch_bounds__(512, 8) void gf2_transpose512_kernel(u64 *__restric
       const int ol = 64 * wave + 8 * k + rr;             // output row inside the tile
       const long long orow = 64ll * C0w + ol;            // = source column
       const long long ow = R0 / 64 + w;                  // output word = source row block
+#ifdef GF2K_DEV_VARIANTS
+      if ((flags & 8) && sout[ol][w] != 0x123456789ull) continue;
+#endif
       if (orow < cols && ow < dwn) {
         if (flags & 2) D[orow * ldd + ow] = sout[ol][w];
         else __builtin_nontemporal_store(sout[ol][w], D + orow * ldd + ow);

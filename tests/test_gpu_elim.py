@@ -61,6 +61,24 @@ def test_rref_random(pkg, block_words, m, n):
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("m,n,r", [(300001, 200, 200), (270000, 130, 70), (33000, 193, 193)])
+@pytest.mark.parametrize("full", [True, False])
+def test_rref_tall(pkg, m, n, r, full):
+    """More rows than one turn of the update workgroups covers (255 x 1024 rows in the look-ahead's one-row-per-lane pass of the next
+    word column, 255 x 128 per pass of the waves): every workgroup walks its contiguous piece in several turns; the pivots of a
+    low-rank tall matrix sit far apart, so the search scans past its first 256 rows too."""
+    a = g.random_words(m, n, 31 + m) if r == n else _low_rank(m, n, r, m)
+    a[: m // 2] = 0 if r != n else a[: m // 2]  # (low rank: the upper half is empty, every pivot comes from far down)
+    got, rank = _host_rref(pkg, a, n, full=full)
+    ref, orank, _ = g.o_echelonize(a, m, n, full=True)
+    assert rank == orank <= r
+    if full:
+        assert np.array_equal(got, ref)
+    else:  # upper form: same rank and, reduced on the host, the same reduced form
+        again, rank2, _ = g.o_echelonize(got, m, n, full=True)
+        assert rank2 == rank and np.array_equal(again, ref)
+
+
 @pytest.mark.parametrize("m,n,r", [(200, 300, 17), (1500, 1200, 64), (1500, 1200, 65), (2500, 3000, 700), (4096, 4096, 1)])
 def test_rref_rank_deficient(pkg, block_words, m, n, r):
     a = _low_rank(m, n, r, 7 * r + m)
