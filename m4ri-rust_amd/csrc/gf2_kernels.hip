@@ -3557,11 +3557,20 @@ __device__ __forceinline__ u32 tr_dpp_xor(u32 y, int d) {
 // transposes the 64 x 64 bit block whose row L is {lo, hi} of lane L (lo = columns 0-31)
 __device__ __forceinline__ void tr_block64(u32 &lo, u32 &hi, const u32 (&keep)[4], const u32 (&rot)[4]) {
   // distance 32: columns 32-63 of lanes 0-31 <-> columns 0-31 of lanes 32-63
-  asm("v_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+  // (builtins, not inline asm: the swaps need two wait states after a VALU write of an operand, which the compiler pads only around
+  // instructions it can see -- the asm form of the 16-lane swap right behind the two v_perm_b32 read a stale register: wrong rows
+  // from 16 on in every block, caught by test_dev_transpose_large_tiles)
+  {
+    const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
+    lo = r[0], hi = r[1];
+  }
   // distance 16: split by column bit 4 (p0 = the low halves of both dwords), swap p0 of rows 16-31 / 48-63 with p1 of rows 0-15 / 32-47.
   // The remaining rounds act inside 16-bit groups, so they run on (p0, p1) as they are and the halves are put back at the end.
   u32 p0 = __builtin_amdgcn_perm(hi, lo, 0x05040100u), p1 = __builtin_amdgcn_perm(hi, lo, 0x07060302u);
-  asm("v_permlane16_swap_b32 %0, %1" : "+v"(p0), "+v"(p1));
+  {
+    const auto r = __builtin_amdgcn_permlane16_swap(p0, p1, false, false);
+    p0 = r[0], p1 = r[1];
+  }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int d = 8 >> k;
@@ -3598,18 +3607,30 @@ __global__ __launch_bounds__(512, 8) void gf2_transpose512_kernel(u64 *__restric
     keep[k] = (lane & d) ? ~mask : mask;
     rot[k] = (lane & d) ? (u32)d : (u32)(32 - d);
   }
-  // tiles in super-tiles of 8 x 8 (4096 x 4096 bits), super-tiles row by row.  Workgroups b and b + 8 share an XCD, hence an
-  // L2: they take column-adjacent tiles, whose 64-byte pieces are the two halves of the same 128-byte lines (with neighbours
-  // on different XCDs every line was fetched twice: FETCH_SIZE 1.07 GB for 0.54 GB).
+  // Which tile a workgroup takes decides the rate: the kernel runs at what the memory system gives for 64-byte pieces 8 KiB
+  // apart, and a copy with exactly this access pattern (tools/tilecopy.hip, 65536^2) goes 2.3 TB/s with tiles in plain order,
+  // 2.75 with the order below up to round 4a (flags & 64), 3.8 with the present one:
+  //  * workgroups b, b + 8, b + 16, ... share an XCD, hence an L2, and start together: out of a super-tile of 16 x 8 tiles an
+  //    XCD takes a block of 4 x 4 (2 x 4 until round 4a), so the 64-byte pieces of four neighbours make 256 contiguous bytes on
+  //    the source AND the destination side (with neighbours on different XCDs every 128-byte line was fetched twice);
+  //  * super-tiles are walked diagonally (the ~8 in flight together differ in both coordinates: their destination pieces no
+  //    longer share their low address bits) and an XCD's place inside the super-tile rotates from one super-tile to the next.
   const int tx_n = (((cols + 63) >> 6) + 7) >> 3, ty_n = (rows + 511) >> 9;
-  const int sx_n = (tx_n + 7) >> 3;
+  const int bxs = (flags & 64) ? 2 : 4, slots = bxs * 4;
+  const int sx_n = (tx_n + 4 * bxs - 1) / (4 * bxs), sy_n = (ty_n + 7) >> 3;
   auto tile_of = [&](int b, int &tX, int &tY) -> bool {
-    const int st = b >> 6, in = b & 63;
-    if (flags & 1) {  // the eight tiles an XCD (b mod 8) takes out of a super-tile form a 2 x 4 block: both 64-byte halves of every line meet in one L2, source and destination side
+    const int st = b / (8 * slots), in = b % (8 * slots);
+    int stx = st % sx_n, sty = st / sx_n;
+    if (flags & 1) {
       const int x = in & 7, slot = in >> 3;
-      tX = (st % sx_n) * 8 + 2 * (x & 3) + (slot & 1), tY = (st / sx_n) * 8 + 4 * (x >> 2) + (slot >> 1);
-    } else {
-      tX = (st % sx_n) * 8 + (in >> 3), tY = (st / sx_n) * 8 + (in & 7);
+      int px = x & 3, py = x >> 2;
+      if (!(flags & 64)) {
+        sty = (sty + stx) % sy_n;
+        px = (px + stx + sty) & 3, py = (py + stx + (sty >> 2)) & 1;
+      }
+      tX = stx * 4 * bxs + bxs * px + slot % bxs, tY = sty * 8 + 4 * py + slot / bxs;
+    } else {  // (column-adjacent tiles per XCD, plain order otherwise: A/B)
+      tX = stx * 4 * bxs + in / 8, tY = sty * 8 + (in & 7);
     }
     return tX < tx_n && tY < ty_n;  // (uniform: the tile count is padded to whole super-tiles)
   };
@@ -3674,11 +3695,12 @@ extern "C" hipError_t gf2k_transpose(u64 *D, long long ldd, const u64 *S, long l
   static const int t512 = GF2K_DEV_ENV("M4RI_HIP_TRANSPOSE512", 1);  // (A/B measurements)
   if (t512 && (long long)rows * cols >= (1ll << 29)) {  // from 64 MiB on: below, both operands live in the Infinity Cache and the small blocks win
     const int tx_n = (sw + 7) / 8, ty_n = (rows + 511) / 512;
-    const long long ntp = (long long)((tx_n + 7) / 8) * ((ty_n + 7) / 8) * 64;
+    static const int tflags = GF2K_DEV_ENV("M4RI_HIP_TRANSPOSE_FLAGS", 1);  // (A/B on one box at 65536^2: 0 = column-adjacent tiles per XCD 0.405 ms, 65 = 2 x 4 tile blocks per XCD 0.380, 1 = 4 x 4 blocks, diagonal walk; 2 = plain instead of non-temporal stores: no difference)
+    const int stw = (tflags & 64) ? 8 : 16;  // super-tile: stw x 8 tiles
+    const long long ntp = (long long)((tx_n + stw - 1) / stw) * ((ty_n + 7) / 8) * (stw * 8);
     if (ntp > 0x7fffffffLL) return hipErrorInvalidValue;
     static const int tgrid = GF2K_DEV_ENV("M4RI_HIP_TRANSPOSE_GRID", (1 << 20));  // (A/B: workgroups that walk several tiles)
     dim3 grid((unsigned)std::min<long long>(ntp, tgrid)), block(512);
-    static const int tflags = GF2K_DEV_ENV("M4RI_HIP_TRANSPOSE_FLAGS", 1);  // (A/B on one box at 65536^2: 0 = column-adjacent tiles per XCD 0.405 ms, 1 = 2 x 4 tile blocks per XCD 0.380; 2 = plain instead of non-temporal stores: no difference)
     hipLaunchKernelGGL(gf2_transpose512_kernel, grid, block, 0, stream, D, ldd, S, lds_, rows, cols, (int)ntp, tflags);
     return hipGetLastError();
   }

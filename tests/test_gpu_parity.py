@@ -277,6 +277,21 @@ def test_dev_transpose_vs_oracle(dev):
         assert np.array_equal(dev.transpose(dev.DMat.from_words(w, c)).to_words(), g.o_transpose(w, r, c))
 
 
+@pytest.mark.parametrize("r,c", [(20000, 30001), (32768, 16448), (9000, 61000), (70001, 7700), (512, 1 << 20), (1 << 20, 513)])
+def test_dev_transpose_large_tiles(dev, r, c):
+    """From 2^29 bits on the transposition takes 512 x 512-bit tiles whose order over the workgroups is scrambled on purpose (4 x 4
+    tile blocks per XCD inside 16 x 8 super-tiles, super-tiles walked diagonally, the XCD's place rotating: gf2_transpose512_kernel):
+    ragged edges in both directions, fewer tiles than one super-tile in either direction, strided operands; the oracle's bits."""
+    assert r * c >= 1 << 29
+    w = g.random_words(r, c, 23)
+    S = dev.DMat.from_words(w, c)
+    T = dev.transpose(S)
+    ref = g.o_transpose(w, r, c)
+    assert np.array_equal(T.to_words(), ref)
+    del ref, w
+    assert dev.equal(dev.transpose(T), S)
+
+
 @pytest.mark.parametrize("n,levels", [(8192, 1), (16384, 2)])
 def test_dev_strassen_equals_m4rm_large(dev, n, levels):
     A, B = dev.DMat.random(n, n, 1), dev.DMat.random(n, n, 2)

@@ -530,3 +530,16 @@ def test_integration_lists_every_knob():
     for name, e in k.items():
         assert ("`%s`" % name) in (dev if e["dev"] else shipped), name
     assert sum(1 for e in k.values() if not e["dev"]) <= 16  # the shipped library's surface stays small
+
+
+def test_no_cross_lane_swaps_in_inline_asm():
+    """v_permlane16_swap / v_permlane32_swap need two wait states after a VALU write of an operand (gfx950); the compiler pads
+    only instructions it can see, so in the product sources they are builtins, never inline asm (round 4: the asm form in the
+    transposition read a stale register -- wrong rows from 16 on in every 64 x 64 block)."""
+    import re
+    src = os.path.join(ROOT, "m4ri-rust_amd", "csrc")
+    for fn in sorted(os.listdir(src)):
+        if fn.endswith((".hip", ".inc", ".cpp", ".h")):
+            text = open(os.path.join(src, fn)).read()
+            for m in re.finditer(r'asm\s*(?:volatile)?\s*\(\s*"([^"]*)"', text):
+                assert "permlane" not in m.group(1), (fn, m.group(1))

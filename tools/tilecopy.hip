@@ -18,9 +18,15 @@ __global__ __launch_bounds__(512, 8) void tilecopy(u32x4 *__restrict__ D, const 
   __shared__ u32x4 buf[2048];
   int b = blockIdx.x, tx, ty;
   if (mode) {
-    const int st = b >> 6, in = b & 63, sx_n = tiles_x / 8;
+    // the 8 XCDs (b mod 8) form a 4 x 2 grid inside a super-tile; each takes a block of bx x by tiles of it (mode >> 8 = bx, by in nibbles; 0: 2 x 4)
+    const int bx = (mode >> 8) & 15 ? (mode >> 8) & 15 : 2, by = (mode >> 12) & 15 ? (mode >> 12) & 15 : 4, slots = bx * by;
+    const int st = b / (8 * slots), in = b % (8 * slots), sx_n = tiles_x / (4 * bx), sy_n = tiles_y / (2 * by);
     const int x = in & 7, slot = in >> 3;
-    tx = (st % sx_n) * 8 + 2 * (x & 3) + (slot & 1), ty = (st / sx_n) * 8 + 4 * (x >> 2) + (slot >> 1);
+    int stx = st % sx_n, sty = st / sx_n;
+    if (mode & 2) sty = (sty + stx) % sy_n;  // diagonal order: super-tiles in flight together differ in BOTH coordinates
+    int px = x & 3, py = x >> 2;
+    if (mode & 4) px = (px + stx + sty) & 3, py = (py + stx + (sty >> 2)) & 1;  // an XCD's share of a super-tile rotates from super-tile to super-tile
+    tx = stx * 4 * bx + bx * px + slot % bx, ty = sty * 2 * by + by * py + slot / bx;
   } else {
     tx = b % tiles_x, ty = b / tiles_x;
   }
@@ -47,7 +53,7 @@ template <int P, int Q>
 static void run(u32x4 *D, const u32x4 *S, int n, int mode) {
   const long long ld16 = n / 128;
   const int tiles_x = n / (P * 8), tiles_y = n / (32768 / P);
-  if (mode && (tiles_x % 8 || tiles_y % 8 || tiles_x < 8)) return;  // (super-tiles of 8 x 8: a division by tiles_x / 8 = 0 faulted once, profiles/faults/r04_tilecopy_div0)
+  if (mode && (tiles_x % 32 || tiles_y % 32 || tiles_x < 32)) return;  // (super-tiles of 8 x 8: a division by tiles_x / 8 = 0 faulted once, profiles/faults/r04_tilecopy_div0)
   if ((long long)tiles_x * P * 8 != n || (long long)tiles_y * (32768 / P) != n || n % 1024) { printf("P=%d: n does not divide\n", P); return; }
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -77,11 +83,17 @@ int main(int argc, char **argv) {
     run<256, 256>(D, S, n, mode);
     run<128, 64>(D, S, n, mode);
     run<64, 128>(D, S, n, mode);
-    run<256, 64>(D, S, n, mode);
-    run<64, 256>(D, S, n, mode);
     run<512, 512>(D, S, n, mode);
-    run<1024, 1024>(D, S, n, mode);
     run<8192, 8192>(D, S, n, mode);
   }
+  for (int mode : {3, 5, 7, 1}) {
+    run<64, 64>(D, S, n, mode);
+    run<128, 128>(D, S, n, mode);
+  }
+  for (int shape : {0x42, 0x24, 0x44, 0x82, 0x28, 0x81, 0x18, 0x22, 0x11})  // by, bx
+    for (int mode : {1, 7}) {
+      printf("by=%d bx=%d ", shape >> 4, shape & 15);
+      run<64, 64>(D, S, n, mode | ((shape & 15) << 8) | ((shape >> 4) << 12));
+    }
   return 0;
 }
