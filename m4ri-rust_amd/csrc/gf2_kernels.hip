@@ -3317,7 +3317,7 @@ extern "C" hipError_t gf2k_tallskinny(const u64 *A, long long lda, const u64 *B,
   } while (0)
 #define GF2_LPN_RPT(NWV, MODEV)                                                                                        \
   do {                                                                                                                 \
-    if (rpt == 8) GF2_LPN_GO((gf2_lpn8_kernel<NWV, 512, 8, MODEV, 3>), kLpn8LdsBytes(NWV));                             \
+    if (NWV == 2 && rpt == 8) GF2_LPN_GO((gf2_lpn8_kernel<2, 512, 8, MODEV, 3>), kLpn8LdsBytes(2)); /* (n <= 64 starts at 4) */ \
     else if (rpt == 4) GF2_LPN_GO((gf2_lpn8_kernel<NWV, 512, 4, MODEV, 3>), kLpn8LdsBytes(NWV));                        \
     else if (rpt == 2) GF2_LPN_GO((gf2_lpn8_kernel<NWV, 512, 2, MODEV, 2>), kLpn8LdsBytes(NWV));                        \
     else GF2_LPN_GO((gf2_lpn8_kernel<NWV, 512, 1, MODEV, 1>), kLpn8LdsBytes(NWV));                                      \
@@ -3749,16 +3749,20 @@ extern "C" hipError_t gf2k_strassen_split3(u64 *dst, long long ldd, long long ds
   const dim3 grid(gx, groups, batch);
   // non-temporal stores: the 343 operand streams are not re-read before the leaf launch (measured: -3 % / -6 % pass time)
   static const int nt = GF2K_DEV_ENV("M4RI_HIP_PASS_NT", 1);
-  if (side == 2 && nt)
-    hipLaunchKernelGGL((gf2_strassen_split3_kernel<0, true, true>), grid, dim3(256), 0, stream, dst, ldd, dstStride, srcs, lds_, srcStride, h, w);
-  else if (side == 2)
+#ifdef GF2K_DEV_VARIANTS  // (the plain-store forms exist for A/B runs only: no instantiation the shipped launcher cannot reach)
+  if (!nt && side == 2)
     hipLaunchKernelGGL((gf2_strassen_split3_kernel<0, true>), grid, dim3(256), 0, stream, dst, ldd, dstStride, srcs, lds_, srcStride, h, w);
+  else if (!nt && side == 1)
+    hipLaunchKernelGGL((gf2_strassen_split3_kernel<1, false>), grid, dim3(256), 0, stream, dst, ldd, dstStride, srcs, lds_, srcStride, h, w);
+  else
+#endif
+  if (side == 2)
+    hipLaunchKernelGGL((gf2_strassen_split3_kernel<0, true, true>), grid, dim3(256), 0, stream, dst, ldd, dstStride, srcs, lds_, srcStride, h, w);
   else if (side == 0)
     hipLaunchKernelGGL((gf2_strassen_split3_kernel<0, false>), grid, dim3(256), 0, stream, dst, ldd, dstStride, srcs, lds_, srcStride, h, w);
-  else if (nt)
-    hipLaunchKernelGGL((gf2_strassen_split3_kernel<1, false, true>), grid, dim3(256), 0, stream, dst, ldd, dstStride, srcs, lds_, srcStride, h, w);
   else
-    hipLaunchKernelGGL((gf2_strassen_split3_kernel<1, false>), grid, dim3(256), 0, stream, dst, ldd, dstStride, srcs, lds_, srcStride, h, w);
+    hipLaunchKernelGGL((gf2_strassen_split3_kernel<1, false, true>), grid, dim3(256), 0, stream, dst, ldd, dstStride, srcs, lds_, srcStride, h, w);
+  (void)nt;
   return hipGetLastError();
 }
 
@@ -3771,12 +3775,15 @@ extern "C" hipError_t gf2k_strassen_merge3(u64 *dst, long long ldd, long long ds
   const long long total = (long long)h * w;
   const int gx = grid_for(total, 256, (8192 + batch * groups - 1) / (batch * groups));
   static const int ntl = GF2K_DEV_ENV("M4RI_HIP_PASS_NTL", 1);  // the products are read once: non-temporal loads, -7 % (1.25 -> 1.15 ms)
-  if (ntl)
-    hipLaunchKernelGGL(gf2_strassen_merge3_kernel<true>, dim3(gx, groups, batch), dim3(256), 0, stream, dst, ldd, dstStride, src, lds_,
-                       srcStride, h, w, accumulate);
-  else
+#ifdef GF2K_DEV_VARIANTS
+  if (!ntl)
     hipLaunchKernelGGL(gf2_strassen_merge3_kernel<false>, dim3(gx, groups, batch), dim3(256), 0, stream, dst, ldd, dstStride, src, lds_,
                        srcStride, h, w, accumulate);
+  else
+#endif
+    hipLaunchKernelGGL(gf2_strassen_merge3_kernel<true>, dim3(gx, groups, batch), dim3(256), 0, stream, dst, ldd, dstStride, src, lds_,
+                       srcStride, h, w, accumulate);
+  (void)ntl;
   return hipGetLastError();
 }
 

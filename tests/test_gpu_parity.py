@@ -1087,3 +1087,52 @@ def test_random_shape_fuzz(pkg):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_shapes.py"), "80", "3"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("n", [40, 100, 200])
+@pytest.mark.parametrize("m,mode", [(1048576, 0), (1048576, 1), (600001, 0), (600001, 1), (600001, 2), (300003, 0), (300003, 1), (300003, 2)])
+def test_lpn_kernels_every_instantiation(dev, m, mode, n):
+    """Every (rows per lane, loader) instantiation of the l <= 256 kernels that the launcher can choose (tools/kernel_coverage.py found 20
+    of them never launched by this suite): rows per lane 8 / 4 / 2 / 1 by the row count, loader 2 = contiguous 256-bit rows, 1 = strided
+    16-byte-aligned rows, 0 = any stride / l <= 192."""
+    l = 256 if mode else 190
+    a, b = g.random_words(m, l, 40 + n), g.random_words(l, n, 41 + n)
+    ref = g.o_mul_m4rm(a, b, m, l, n)
+    B = dev.DMat.from_words(b, n)
+    A = dev.DMat.from_words(a, l) if mode != 1 else _strided(dev, a, l, 6)
+    C = dev.mul(A, B, algo="naive")
+    assert np.array_equal(C.to_words(), ref)
+    dev.mul(A, B, C=C, accumulate=True, algo="m4rm")
+    assert not C.to_words().any()
+
+
+@pytest.mark.parametrize("m,l,n", [(524288, 300, 40), (524365, 1000, 64), (524288, 512, 100), (524300, 1024, 200), (524288, 700, 256),
+                                   (600000, 257, 65), (530000, 999, 129)])
+def test_table_kernels_long_inner_dimension_many_rows(dev, m, l, n):
+    """256 < l <= 1024 with at least 2^19 rows: the table kernels that hold all of B's tables in LDS in generations
+    (gf2_tallskinny4_kernel for n <= 64, gf2_tallskinny3_kernel beyond); below 2^19 rows those shapes take the tile kernel, so the
+    suite never reached them after the threshold moved (tools/kernel_coverage.py)."""
+    a, b = g.random_words(m, l, 50 + n), g.random_words(l, n, 51 + n)
+    ref = g.o_mul_m4rm(a, b, m, l, n)
+    A, B = dev.DMat.from_words(a, l), dev.DMat.from_words(b, n)
+    for algo in ("m4rm", "naive"):
+        assert np.array_equal(dev.mul(A, B, algo=algo).to_words(), ref), algo
+    c0 = g.random_words(m, n, 52)
+    C = dev.DMat.from_words(c0, n)
+    dev.mul(A, B, C=C, accumulate=True, algo="m4rm")
+    assert np.array_equal(C.to_words(), ref ^ c0)
+
+
+@pytest.mark.parametrize("l", [1, 50, 64, 65, 128, 200, 256, 500, 512, 513, 1000])
+@pytest.mark.parametrize("n", [1, 64, 65, 200])
+def test_mul_nt_every_row_width(dev, l, n):
+    """_mzd_mul_naive with the pre-transposed operand (mzd.rs:154-168; gf2_mul_nt_dev): the AND / popcount kernel has one
+    instantiation per row width (1, 2, 4, 8 words in registers, longer rows in a loop) -- the one- and two-word ones were never
+    launched by the suite (tools/kernel_coverage.py)."""
+    m = 3001
+    a, b = g.random_words(m, l, 60 + l), g.random_words(l, n, 61 + n)
+    A, Bt = dev.DMat.from_words(a, l), dev.DMat.from_words(g.o_transpose(b, l, n), l)
+    ref = g.o_mul_naive(a, b, m, l, n)
+    assert np.array_equal(dev.mul_nt(A, Bt).to_words(), ref)
+    if l > 64:  # unaligned rows: odd stride
+        assert np.array_equal(dev.mul_nt(_strided(dev, a, l, (l + 63) // 64 | 1, offset_words=1), Bt).to_words(), ref)
