@@ -3388,6 +3388,12 @@ extern "C" hipError_t gf2k_tallskinny(const u64 *A, long long lda, const u64 *B,
   }
 #endif
   if (nw == 1) {  // generation kernel (replicated tables, skew inside a 64-bit word)
+#ifndef GF2K_DEV_VARIANTS
+    // Every shape that used to come here (n <= 64, 256 < l <= 1024, at least 2^19 rows) is taken by the slab table kernel first
+    // (ts_long_shape, m4ri_hip_api.cpp), so the shipped library does not carry an instantiation no call can reach
+    // (tools/kernel_coverage.py, retirement rule of DESIGN 4.1); development builds keep it for A/B runs (M4RI_HIP_TS7=0).
+    return hipErrorInvalidValue;
+#else
     constexpr int RPT4 = 4, NT4 = 1024;
     const unsigned grid4 = (unsigned)(((long long)m + NT4 * RPT4 - 1) / (NT4 * RPT4));
     const size_t lds4 = 128 * 1024 + 8 * 1024;
@@ -3396,6 +3402,7 @@ extern "C" hipError_t gf2k_tallskinny(const u64 *A, long long lda, const u64 *B,
     hipLaunchKernelGGL((gf2_tallskinny4_kernel<1, RPT4, NT4>), dim3(grid4), dim3(NT4), lds4, stream, A, lda, B, ldb, C, ldc, m, l, n,
                        accumulate);
     return hipGetLastError();
+#endif
   }
   constexpr int RPT3 = 4, NT3 = 1024;
   const unsigned grid3 = (unsigned)(((long long)m + NT3 * RPT3 - 1) / (NT3 * RPT3));
