@@ -260,7 +260,7 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v3(const gf2k_mul_
     // gfx950: the sum is not wrapped at 16 bits)
     const u32 kOff = tbase ? (0x10004u - (u32)(EPW * 256)) : 0u;
     const u32 m0v = tbase + (u32)wave * (u32)(EPW * 256) - kOff;
-    asm volatile("s_mov_b32 m0, %0" ::"s"(m0v) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(m0v) : "memory");  // (one wait state before an LDS add-TID instruction reads M0: the compiler cannot see that the asm below does)
   };
   auto build_write = [&cur32](auto itag, auto ttag) __attribute__((always_inline)) {  // entry i (Gray order) <- cur32
     constexpr int i = decltype(itag)::value;
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(WAVES * 64) void gf2_m4rm_kernel_v6(const gf2k_mul_
       if ((wave >> (b - LOWB)) & 1) cur32 ^= rr[b];
     const u32 kOff = tbase ? (0x10004u - (u32)(EPW * 256)) : 0u;  // see gf2_m4rm_kernel_v3
     const u32 m0v = tbase + (u32)wave * (u32)(EPW * 256) - kOff;
-    asm volatile("s_mov_b32 m0, %0" ::"s"(m0v) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(m0v) : "memory");  // (one wait state before an LDS add-TID instruction reads M0: the compiler cannot see that the asm below does)
   };
   auto build_write = [&cur32](auto itag, auto ttag) __attribute__((always_inline)) {
     constexpr int i = decltype(itag)::value;
@@ -940,7 +940,7 @@ __global__ __launch_bounds__(512) void gf2_m4rm_kernel_v8(const gf2k_mul_args p)
         if ((wave >> (b - LOWB)) & 1) cur32 ^= rr[b];
       const u32 kOff = tbase ? (0x10004u - (u32)(EPW * 256)) : 0u;  // see gf2_m4rm_kernel_v3
       const u32 m0v = tbase + (u32)wave * (u32)(EPW * 256) - kOff;
-      asm volatile("s_mov_b32 m0, %0" ::"s"(m0v) : "memory");
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(m0v) : "memory");  // (one wait state before an LDS add-TID instruction reads M0: the compiler cannot see that the asm below does)
     };
     auto build_write = [&cur32](auto itag, auto ttag) __attribute__((always_inline)) {
       constexpr int i = decltype(itag)::value;
@@ -2193,7 +2193,7 @@ __global__ __launch_bounds__(NT) void gf2_tallskinny4_kernel(const u64 *__restri
         {
           constexpr u32 kOff = tbase ? (0x10004u - (u32)(EPW * 256)) : 0u;  // see gf2_m4rm_kernel_v3
           const u32 m0v = tbase + (u32)wave * (u32)(EPW * 256) - kOff;
-          asm volatile("s_mov_b32 m0, %0" ::"s"(m0v) : "memory");
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(m0v) : "memory");  // (one wait state before an LDS add-TID instruction reads M0: the compiler cannot see that the asm below does)
           static_for<EPW>([&](auto itag) __attribute__((always_inline)) {
             constexpr int i = decltype(itag)::value;
             constexpr unsigned e = (unsigned)i ^ ((unsigned)i >> 1);
@@ -3304,11 +3304,43 @@ extern "C" hipError_t gf2k_tallskinny(const u64 *A, long long lda, const u64 *B,
     const bool a16 = (lda & 1) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
     const bool c16 = nw == 1 || ((ldc & 1) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0);
     const int mode = (l > 192 && a16 && c16) ? (lda == 4 ? 2 : 1) : 0;
+    hipError_t e = hipSuccess;
+    // one to four vectors: no tables (gf2_lpnvec_kernel); 256 rows x RPT per workgroup, four workgroups per CU wanted
+    static const int vec_on = GF2K_DEV_ENV("M4RI_HIP_LPNVEC", 1);
+    if (n <= 4 && vec_on) {
+      // (2^20 x 256 x 1 cold on one box: rows per lane 4 / 2 / 1 with >= 1024 workgroups 8.5 / 8.5 / 9.1 us, 8 with 512 or 256
+      // workgroups 8.7 / 8.6; the table kernel 9.0.  Warm, A in the Infinity Cache: 5.7 against 7.5 us.)
+      static const int vrpt = GF2K_DEV_ENV("M4RI_HIP_LPNVEC_RPT", 4);
+      int rpt = vrpt;
+      static const int vwant = GF2K_DEV_ENV("M4RI_HIP_LPNVEC_GRID", 1024);
+      while (rpt > 1 && ((long long)m + 256LL * rpt - 1) / (256LL * rpt) < vwant) rpt >>= 1;
+      const unsigned grid = (unsigned)(((long long)m + 256LL * rpt - 1) / (256LL * rpt));
+#define GF2_LPNVEC_GO(NVV, RPTV, MODEV)                                                                                \
+  hipLaunchKernelGGL((gf2_lpnvec_kernel<NVV, 256, RPTV, MODEV>), dim3(grid), dim3(256), 0, stream, A, lda, B, ldb, C, ldc, m, l, n, accumulate)
+#define GF2_LPNVEC_RPT(NVV, MODEV)                                                                                     \
+  do {                                                                                                                 \
+    if (rpt >= 4) GF2_LPNVEC_GO(NVV, 4, MODEV);                                                                        \
+    else if (rpt == 2) GF2_LPNVEC_GO(NVV, 2, MODEV);                                                                   \
+    else GF2_LPNVEC_GO(NVV, 1, MODEV);                                                                                 \
+  } while (0)
+#define GF2_LPNVEC_MODE(NVV)                                                                                           \
+  do {                                                                                                                 \
+    if (mode == 2) GF2_LPNVEC_RPT(NVV, 2);                                                                             \
+    else if (mode == 1) GF2_LPNVEC_RPT(NVV, 1);                                                                        \
+    else GF2_LPNVEC_RPT(NVV, 0);                                                                                       \
+  } while (0)
+      if (n == 1) GF2_LPNVEC_MODE(1);
+      else if (n == 2) GF2_LPNVEC_MODE(2);
+      else GF2_LPNVEC_MODE(4);
+#undef GF2_LPNVEC_MODE
+#undef GF2_LPNVEC_RPT
+#undef GF2_LPNVEC_GO
+      return hipGetLastError();
+    }
     const int target = nw == 1 ? 512 : 256;  // workgroups wanted
     int rpt = nw == 1 ? 4 : 8;
     while (rpt > 1 && ((long long)m + 512LL * rpt - 1) / (512LL * rpt) < target) rpt >>= 1;
     const unsigned grid = (unsigned)(((long long)m + 512LL * rpt - 1) / (512LL * rpt));
-    hipError_t e = hipSuccess;
 #define GF2_LPN_GO(KERNEL, LDSB)                                                                                       \
   do {                                                                                                                 \
     e = lds_limit_once(reinterpret_cast<const void *>(&KERNEL), (int)(LDSB));                                          \

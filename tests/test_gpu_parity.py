@@ -1089,12 +1089,12 @@ def test_random_shape_fuzz(pkg):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("n", [40, 100, 200])
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 40, 100, 200])
 @pytest.mark.parametrize("m,mode", [(1048576, 0), (1048576, 1), (600001, 0), (600001, 1), (600001, 2), (300003, 0), (300003, 1), (300003, 2)])
 def test_lpn_kernels_every_instantiation(dev, m, mode, n):
     """Every (rows per lane, loader) instantiation of the l <= 256 kernels that the launcher can choose (tools/kernel_coverage.py found 20
     of them never launched by this suite): rows per lane 8 / 4 / 2 / 1 by the row count, loader 2 = contiguous 256-bit rows, 1 = strided
-    16-byte-aligned rows, 0 = any stride / l <= 192."""
+    16-byte-aligned rows, 0 = any stride / l <= 192.  n <= 4: the table-free kernel for one to four vectors (gf2_lpnvec_kernel)."""
     l = 256 if mode else 190
     a, b = g.random_words(m, l, 40 + n), g.random_words(l, n, 41 + n)
     ref = g.o_mul_m4rm(a, b, m, l, n)
