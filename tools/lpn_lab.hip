@@ -292,6 +292,9 @@ int main(int argc, char **argv) {
       vs.push_back(make_k256<512, 8, 2, 3, 0, 5>());
       vs.push_back(make_k256<512, 8, 2, 4, 0, 1>());
       vs.push_back(make_k256<512, 8, 2, 2, 3>());
+      vs.push_back(make_k256<512, 8, 2, 3, 1, 5>());
+      vs.push_back(make_k256<512, 8, 2, 3, 2, 5>());
+      vs.push_back(make_k256<512, 8, 2, 3, 3, 5>());
       vs.push_back(make_k256<1024, 4, 2, 2, 4, 1>());
       vs.push_back(make_k256<512, 8, 2, 3, 4, 1>());
       vs.push_back(make_k256<512, 8, 2, 3, 4, 5>());
