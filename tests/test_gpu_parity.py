@@ -811,6 +811,20 @@ def test_host_transpose_large_uses_device_and_matches(pkg):
         assert t.transposed() == m
 
 
+@pytest.mark.parametrize("r,c", [(32768, 65600), (65536, 32800)])
+def test_host_transpose_pipelined(pkg, r, c):
+    """mzd_transpose on host matrices from 2^31 bits on (at least 32768 rows, a multiple of 512 per block): four (eight from 65536 rows
+    on) row blocks of the source go up, are transposed into their words of every destination row and come down through 2-D copies while
+    the next block goes up.  Ragged column count; the oracle's bits on every row, and the involution (whose source does not qualify:
+    the unpipelined path)."""
+    w = g.random_words(r, c, 43)
+    m = pkg.BinMatrix.from_words(w, c)
+    t = m.transposed()
+    assert t.nrows() == c and t.ncols() == r
+    assert np.array_equal(t.to_words(), g.o_transpose(w, r, c))
+    assert t.transposed() == m
+
+
 @pytest.mark.parametrize("m,l,n", [(2048, 256, 64), (2048, 256, 65), (2500, 256, 128), (3000, 256, 256), (5000, 100, 1),
                                    (4097, 300, 200), (2049, 1000, 129), (9000, 64, 255), (2300, 129, 130), (70000, 256, 37),
                                    (2048, 8, 256), (6000, 513, 64), (5000, 200, 192), (4100, 193, 100), (8197, 256, 255), (65536, 256, 128),
