@@ -16,3 +16,12 @@ for (r, c) in [(65536, 65536), (32768, 65536), (65536, 32768)]:
         L.mzd_transpose(T.mzd, A.mzd)
         best = min(best, time.perf_counter() - t0)
     print("pipeline=%s %d x %d: %.2f ms" % (os.environ.get("M4RI_HIP_TRANSPOSE_PIPELINE", "default"), r, c, best * 1e3), flush=True)
+# the NULL-destination form (what `transposed()` calls): destination from the pinned pool per call
+A = pkg.BinMatrix.random(65536, 65536)
+for name, f in (("mzd_transpose(NULL, A) + mzd_free", lambda: L.mzd_free(L.mzd_transpose(None, A.mzd))),
+                ("mzd_init + mzd_free alone", lambda: L.mzd_free(L.mzd_init(65536, 65536))),
+                ("BinMatrix.transposed()", lambda: A.transposed())):
+    best = 1e9
+    for _ in range(6):
+        t0 = time.perf_counter(); f(); best = min(best, time.perf_counter() - t0)
+    print("pipeline=%s %s: %.2f ms" % (os.environ.get("M4RI_HIP_TRANSPOSE_PIPELINE", "default"), name, best * 1e3), flush=True)
