@@ -210,14 +210,30 @@ def _host_path(torch, sizes=(32768, 65536)):
     h = torch.empty(nb, dtype=torch.uint8).pin_memory()
     d = torch.empty(nb, dtype=torch.uint8, device="cuda")
     rates = {}
-    for name, fn in (("h2d", lambda: d.copy_(h, non_blocking=True)), ("d2h", lambda: h.copy_(d, non_blocking=True))):
-        fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(4):
+
+    def measure():
+        r = {}
+        for name, fn in (("h2d", lambda: d.copy_(h, non_blocking=True)), ("d2h", lambda: h.copy_(d, non_blocking=True))):
             fn()
-        torch.cuda.synchronize()
-        rates[name] = 4 * nb / (time.perf_counter() - t0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(4):
+                fn()
+            torch.cuda.synchronize()
+            r[name] = 4 * nb / (time.perf_counter() - t0)
+        return r
+    # The process has just handed ~20 GiB of device memory back to the driver, which keeps the copy engines busy for a while
+    # (a third of the copy rate, or less, for 2-3 s: tools/ht_probe.py, profiles/r04_host_path.txt): measure until two consecutive
+    # rates agree within 3 % (at most ~10 s), so that neither the floors nor the legs below carry the free.
+    settle = 0
+    for _ in range(40):
+        r = measure()
+        if rates and all(abs(r[k] - rates[k]) <= 0.03 * rates[k] for k in r):
+            rates = {k: max(r[k], rates[k]) for k in r}
+            break
+        rates = r
+        settle += 1
+        time.sleep(0.25)
     del h, d
 
     def floor_ms(up, down):
@@ -285,7 +301,27 @@ def _host_path(torch, sizes=(32768, 65536)):
     out.append({"workload": "the same with gf2_mzd_cache_on_device(A)", "ms": t_c * 1e3, "pcie_floor_ms": floor_ms(64.0, m * 8.0),
                 "bytes_up": 64.0, "bytes_down": m * 8.0,
                 "note": "C of a matrix x vector product is one 64-bit word per row in the M4RI layout: 8 MiB come back for 128 KiB of bits"})
-    return {"pcie_GBps": {k: v / 1e9 for k, v in rates.items()}, "entries": out}
+    return {"pcie_GBps": {k: v / 1e9 for k, v in rates.items()}, "pcie_settle_rounds": settle, "entries": out}
+
+
+def _elimination(device, torch, sizes=(4096, 65536)):
+    """SURVEY.md section 8(f) row 3 in the driver line: reduced echelon form (mzd_echelonize(A, 1), echelonform.rs:16) of a random
+    n x n matrix, device resident (gf2_echelonize_dev), best of three; the blocked Gauss-Jordan of DESIGN.md section 7.1.  A random
+    square matrix has rank n - d with probability ~0.29 / 0.58 / 0.13 for d = 0 / 1 / 2: the rank is reported, the bits are the
+    business of tests/test_gpu_elim.py (oracle, fixtures, E * A = R at full size)."""
+    out = []
+    for n in sizes:
+        ts, rank = [], None
+        for _ in range(3):
+            M = device.DMat.random(n, n, 5)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rank, _ = device.echelonize(M, full=True)
+            ts.append(time.perf_counter() - t0)
+            del M
+        out.append({"workload": "reduced echelon form of a random %d x %d matrix (seed 5), device resident" % (n, n), "n": n, "ms": min(ts) * 1e3,
+                    "rank": int(rank), "n3_per_s": float(n) ** 3 / min(ts)})
+    return out
 
 
 def _sharded_self_check(device, sharded, torch, Bp, Cfull_t, n, world, stream):
@@ -331,6 +367,7 @@ def main():
                     help="how a panel of B reaches the ranks: one broadcast, or scatter from rank 0 + all-gather; left unset together "
                          "with --panels 0 the run times three untimed steps of every candidate first and keeps the fastest")
     ap.add_argument("--no-host-path", action="store_true", help="skip the end-to-end legs on host mzd_t (C ABI incl. PCIe)")
+    ap.add_argument("--no-elim", action="store_true", help="skip the elimination leg (reduced echelon forms, device resident)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--check", action="store_true", help="spot-check rows of C against the oracle after timing")
     ap.add_argument("--no-configs", action="store_true",
@@ -654,14 +691,16 @@ def main():
                 np.array_equal(device.mul(Ad, Bd, algo=args.algo, param=args.levels).to_words(), cpu_sample))
     if world == 1 and not args.no_configs and args.density == "half":
         out["configs"] = _extra_configs(device, torch, stream)
+    if world == 1 and not args.no_elim and args.density == "half":
+        out["elimination"] = _elimination(device, torch)
     if world == 1 and not args.no_host_path and args.density == "half":
         del A, B, C, A_t, B_t, C_t  # the resident operands and (gf2_trim) the 15 GiB arena go back first
         torch.cuda.empty_cache()
         device._lib.lib().gf2_trim()
-        # ... and the driver gets two seconds to finish with the ~17 GiB just freed: for a few hundred milliseconds after such a
-        # hipFree the copies of the host path run a third slower (mzd_transpose 65536^2 16.1 ms against 12.3 in a process that has
-        # freed nothing, or that waits first: tools/ht_probe.py, profiles/r04_host_path.txt) -- a property of freeing, not of the path
-        time.sleep(2.0)
+        # (after such a hipFree the copies of the host path run a third slower for a while -- mzd_transpose 65536^2 16.1 ms against
+        # 12.3 in a process that has freed nothing, or that waits first: tools/ht_probe.py, profiles/r04_host_path.txt -- a property
+        # of freeing, not of the path: _host_path waits until its PCIe rate measurement has settled)
+        time.sleep(1.0)
         out["host_path"] = _host_path(torch)
     print(json.dumps(out))
     if world > 1:

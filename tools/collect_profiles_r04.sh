@@ -29,12 +29,12 @@ python3 tools/host_transpose_bench.py 2>/dev/null | grep "^pipeline" >> $O/host_
 tools/tilecopy 65536 > $O/tilecopy.txt 2>&1
 echo "timings done"
 # density sanity runs (sparse 1/64 and all ones, clock / DVFS)
-for d in sparse ones half; do python3 bench.py --steps 10 --warmup 3 --no-cpu --no-configs --no-host-path --density $d 2>/dev/null | grep "^{" >> $O/density.jsonl; done
+for d in sparse ones half; do python3 bench.py --steps 10 --warmup 3 --no-cpu --no-configs --no-host-path --no-elim --density $d 2>/dev/null | grep "^{" >> $O/density.jsonl; done
 echo "density done"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu --no-configs --no-host-path > $O/prof_bench.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-configs --no-parity --no-host-path > $O/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-configs --no-parity --no-host-path > $O/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu --no-configs --no-host-path --no-elim > $O/prof_bench.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-configs --no-parity --no-host-path --no-elim > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-configs --no-parity --no-host-path --no-elim > $O/pmc_write.log 2>&1
 echo "bench profiles done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_lpn -- python3 $R/tools/lpn_pmc.py > $O/prof_lpn.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_lpn_fetch -- python3 $R/tools/lpn_pmc.py > $O/pmc_lpn_fetch.log 2>&1

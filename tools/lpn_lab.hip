@@ -196,6 +196,19 @@ int main(int argc, char **argv) {
   if (!shipped) fprintf(stderr, "note: shipped library not found (%s)\n", dlerror());
 
   std::vector<u64 *> As(NBUF), Cs(NBUF);
+  const char *delta_env = getenv("LAB_DELTA");  // placement study: everything in one slab, C_i = A_i + 32 MiB (+ pad) + LAB_DELTA bytes
+  if (delta_env) {
+    const long long dl = atoll(delta_env);
+    const size_t delta = dl < 0 ? 0 : (size_t)dl, slot = (size_t)m * 64 + ((size_t)8 << 20);
+    char *slab, *slab2 = nullptr;
+    CK(hipMalloc(&slab, slot * NBUF + ((size_t)64 << 20)));
+    if (dl < 0) CK(hipMalloc(&slab2, (size_t)m * 32 * NBUF));  // -1: the A buffers end to end in one allocation, the C buffers in another
+    for (int i = 0; i < NBUF; ++i) {
+      As[i] = reinterpret_cast<u64 *>(dl < 0 ? slab + (size_t)m * 32 * i : slab + slot * i);
+      Cs[i] = reinterpret_cast<u64 *>(dl < 0 ? slab2 + (size_t)m * 32 * i : slab + slot * i + (size_t)m * 32 + delta);
+      hipLaunchKernelGGL(fill_kernel, dim3((m * 4 + 255) / 256), dim3(256), 0, 0, As[i], (long long)m * 4, 100 + i);
+    }
+  } else
   for (int i = 0; i < NBUF; ++i) {
     CK(hipMalloc(&As[i], (size_t)m * 32));
     CK(hipMalloc(&Cs[i], (size_t)m * 32 + (size_t)(i + 1) * (1 << 20)));  // different distances between A_i and C_i
