@@ -199,9 +199,9 @@ int main(int argc, char **argv) {
   const char *delta_env = getenv("LAB_DELTA");  // placement study: everything in one slab, C_i = A_i + 32 MiB (+ pad) + LAB_DELTA bytes
   if (delta_env) {
     const long long dl = atoll(delta_env);
-    const size_t delta = dl < 0 ? 0 : (size_t)dl, slot = (size_t)m * 64 + ((size_t)8 << 20);
+    const size_t delta = dl < 0 ? 0 : (size_t)dl, slot = (size_t)m * 64 + ((size_t)(getenv("LAB_PAD_MIB") ? atoi(getenv("LAB_PAD_MIB")) : 8) << 20);
     char *slab, *slab2 = nullptr;
-    CK(hipMalloc(&slab, slot * NBUF + ((size_t)64 << 20)));
+    CK(hipMalloc(&slab, slot * NBUF + ((size_t)128 << 20)));
     if (dl < 0) CK(hipMalloc(&slab2, (size_t)m * 32 * NBUF));  // -1: the A buffers end to end in one allocation, the C buffers in another
     for (int i = 0; i < NBUF; ++i) {
       As[i] = reinterpret_cast<u64 *>(dl < 0 ? slab + (size_t)m * 32 * i : slab + slot * i);
