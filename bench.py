@@ -176,14 +176,24 @@ def _extra_configs(device, torch, stream, squares=True, lpn_v=(1, 64, 128, 256))
         entry(name, nn, nn, nn, algo, dt, _sha256_of(C, stream), key, onchip(nn, nn, nn, dt))
         del A, B, C
     m, l, nbuf = 1 << 20, 256, 10
-    As = [device.DMat.random(m, l, 1 if i == 0 else 100 + i, stream) for i in range(nbuf)]
+    # The ten A buffers lie end to end in one allocation, the ten C buffers in another with 3 MiB + 68 KiB more between
+    # neighbours than they need, and A_i is paired with C_(3i+1 mod nbuf): the distance between a product's read and its write
+    # stream decides how the two meet in the memory system (tools/lpn_placement.py, profiles/r04_lpn_placement.txt: V = 128 takes
+    # 11.1-11.5 us at most distances and 12.1-12.8 when the distance is within half a MiB of a multiple of 64 MiB; the round-3
+    # kernel for V = 256 took 18.9-23.0 us depending on it alone).  Separate allocations of equal size have distances that all
+    # fall into ONE residue class -- a lucky or an unlucky one, per process --; ten different residues make the figure typical.
+    MiB = 1 << 20
+    a_slab = torch.empty(nbuf * m * (l // 64), dtype=torch.int64, device="cuda")
+    As = [device.DMat.wrap(a_slab.data_ptr() + i * m * (l // 8), m, l, l // 64, keep=a_slab) for i in range(nbuf)]
+    for i, a in enumerate(As):
+        a.fill_random(1 if i == 0 else 100 + i, stream)
+    c_pitch = m * 32 + 3 * MiB + 68 * 1024
+    c_slab = torch.empty(nbuf * c_pitch // 8, dtype=torch.int64, device="cuda")
     for V in lpn_v:
         X = device.DMat.random(l, V, 2, stream)
-        Cs = [device.DMat(m, V) for _ in range(nbuf)]
-        # A_i is paired with C_(3i+1 mod nbuf): the allocator hands out both sets with the same stride, so pairing equal indices
-        # would give every product the SAME distance between its read and its write stream, and that distance decides whether
-        # the two collide in the HBM channels (tools/lpn_placement.py: V = 256 takes 18.9-23.0 us depending on it alone); ten
-        # different distances make the figure typical instead of lucky or unlucky
+        wv = (V + 63) // 64
+        Cs = [device.DMat.wrap(c_slab.data_ptr() + j * c_pitch, m, V, wv, keep=c_slab) for j in range(nbuf)]
+
         def one(i):
             device.mul(As[i % nbuf], X, C=Cs[(3 * i + 1) % nbuf], algo="naive", stream=stream)
         for i in range(100 * nbuf):  # untimed round-robin passes, 10-25 ms (see above)
@@ -192,7 +202,7 @@ def _extra_configs(device, torch, stream, squares=True, lpn_v=(1, 64, 128, 256))
         entry("config 5: LPN 2^20 x 256 times 256 x %d (mzd_mul_naive entry), cold: %d rotating A buffers" % (V, nbuf),
               m, l, V, "naive", dt, _sha256_of(Cs[1], stream), "lpn_1048576x256x%d" % V)  # Cs[1] = A_0 * X
         del Cs, X
-    del As
+    del As, a_slab, c_slab
     return out
 
 
