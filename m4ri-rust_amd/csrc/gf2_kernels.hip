@@ -97,6 +97,9 @@ typedef __attribute__((address_space(3))) const u64 lds_cu64;
 typedef __attribute__((address_space(3))) u64 lds_u64;
 typedef __attribute__((address_space(3))) u32 lds_u32;
 
+#ifndef GF2_LPNVEC_STRIDED
+#define GF2_LPNVEC_STRIDED 0  // the table-free vector kernel keeps the blocked order: 2^20 x 256 x 1 cold 8.5 us blocked, 8.9 grid-stride (A/B builds: -DGF2_LPNVEC_STRIDED=1)
+#endif
 #include "gf2_lpn.inc"  // gf2_lpn8_kernel / gf2_lpn256_kernel: the l <= 256 tall-skinny products (BASELINE config 5)
 
 // ---------------------------------------------------------------------------------------------
@@ -3296,6 +3299,9 @@ extern "C" hipError_t gf2k_tallskinny(const u64 *A, long long lda, const u64 *B,
   //   n <= 64         gf2_lpn8_kernel<1>    8-bit tables, 8-byte entries, 2 workgroups per CU     8.7-8.9   (4-bit kernel 11.2-13.5)
   //   64 < n <= 128   gf2_lpn8_kernel<2>    8-bit tables, 16-byte entries                         11.3      (14.5-15.1)
   //   128 < n <= 256  gf2_lpn256_kernel     6/6/6/7/7-bit fields, 32-byte entries, ONE phase      17.3-17.7 (two phases: 20.0-21.4)
+  // The RPT row steps of a workgroup are taken in GRID-STRIDE order (step r of workgroup b = rows (r * grid + b) * 512 ...): the launch
+  // then reads one contiguous window of A and writes one of C at any time, like a plain stream (cold, one box: V = 64 8.88 -> 8.60 us,
+  // V = 128 11.26 -> 10.64, V = 256 17.61 -> 17.27; the load / store skeleton of V = 256 alone 13.75 -> 13.06).
   // Rows per workgroup = 512 x RPT with RPT chosen so that the launch has about one workgroup per CU (two for n <= 64): with
   // few rows a batch of 4096 per workgroup leaves most of the chip idle (65536 x 256 x 256: 14.5 us with RPT = 8, 5.4 with 1).
   // M4RI_HIP_LPN=0 restores the round-2/3 kernels (A/B runs).
@@ -3316,7 +3322,7 @@ extern "C" hipError_t gf2k_tallskinny(const u64 *A, long long lda, const u64 *B,
       while (rpt > 1 && ((long long)m + 256LL * rpt - 1) / (256LL * rpt) < vwant) rpt >>= 1;
       const unsigned grid = (unsigned)(((long long)m + 256LL * rpt - 1) / (256LL * rpt));
 #define GF2_LPNVEC_GO(NVV, RPTV, MODEV)                                                                                \
-  hipLaunchKernelGGL((gf2_lpnvec_kernel<NVV, 256, RPTV, MODEV>), dim3(grid), dim3(256), 0, stream, A, lda, B, ldb, C, ldc, m, l, n, accumulate)
+  hipLaunchKernelGGL((gf2_lpnvec_kernel<NVV, 256, RPTV, MODEV, GF2_LPNVEC_STRIDED>), dim3(grid), dim3(256), 0, stream, A, lda, B, ldb, C, ldc, m, l, n, accumulate)
 #define GF2_LPNVEC_RPT(NVV, MODEV)                                                                                     \
   do {                                                                                                                 \
     if (rpt >= 4) GF2_LPNVEC_GO(NVV, 4, MODEV);                                                                        \
@@ -3349,17 +3355,17 @@ extern "C" hipError_t gf2k_tallskinny(const u64 *A, long long lda, const u64 *B,
   } while (0)
 #define GF2_LPN_RPT(NWV, MODEV)                                                                                        \
   do {                                                                                                                 \
-    if (NWV == 2 && rpt == 8) GF2_LPN_GO((gf2_lpn8_kernel<2, 512, 8, MODEV, 3>), kLpn8LdsBytes(2)); /* (n <= 64 starts at 4) */ \
-    else if (rpt == 4) GF2_LPN_GO((gf2_lpn8_kernel<NWV, 512, 4, MODEV, 3>), kLpn8LdsBytes(NWV));                        \
-    else if (rpt == 2) GF2_LPN_GO((gf2_lpn8_kernel<NWV, 512, 2, MODEV, 2>), kLpn8LdsBytes(NWV));                        \
-    else GF2_LPN_GO((gf2_lpn8_kernel<NWV, 512, 1, MODEV, 1>), kLpn8LdsBytes(NWV));                                      \
+    if (NWV == 2 && rpt == 8) GF2_LPN_GO((gf2_lpn8_kernel<2, 512, 8, MODEV, 3, 0, 1>), kLpn8LdsBytes(2)); /* (n <= 64 starts at 4) */ \
+    else if (rpt == 4) GF2_LPN_GO((gf2_lpn8_kernel<NWV, 512, 4, MODEV, 3, 0, 1>), kLpn8LdsBytes(NWV));                        \
+    else if (rpt == 2) GF2_LPN_GO((gf2_lpn8_kernel<NWV, 512, 2, MODEV, 2, 0, 1>), kLpn8LdsBytes(NWV));                        \
+    else GF2_LPN_GO((gf2_lpn8_kernel<NWV, 512, 1, MODEV, 1, 0, 1>), kLpn8LdsBytes(NWV));                                      \
   } while (0)
 #define GF2_LPN256_RPT(MODEV)                                                                                          \
   do {                                                                                                                 \
-    if (rpt == 8) GF2_LPN_GO((gf2_lpn256_kernel<512, 8, MODEV, 3, 0, 5>), kLpn256LdsBytes);                             \
-    else if (rpt == 4) GF2_LPN_GO((gf2_lpn256_kernel<512, 4, MODEV, 3, 0, 5>), kLpn256LdsBytes);                        \
-    else if (rpt == 2) GF2_LPN_GO((gf2_lpn256_kernel<512, 2, MODEV, 2, 0, 5>), kLpn256LdsBytes);                        \
-    else GF2_LPN_GO((gf2_lpn256_kernel<512, 1, MODEV, 1, 0, 5>), kLpn256LdsBytes);                                      \
+    if (rpt == 8) GF2_LPN_GO((gf2_lpn256_kernel<512, 8, MODEV, 3, 0, 13>), kLpn256LdsBytes);                             \
+    else if (rpt == 4) GF2_LPN_GO((gf2_lpn256_kernel<512, 4, MODEV, 3, 0, 13>), kLpn256LdsBytes);                        \
+    else if (rpt == 2) GF2_LPN_GO((gf2_lpn256_kernel<512, 2, MODEV, 2, 0, 13>), kLpn256LdsBytes);                        \
+    else GF2_LPN_GO((gf2_lpn256_kernel<512, 1, MODEV, 1, 0, 13>), kLpn256LdsBytes);                                      \
   } while (0)
     if (nw == 1) {
       if (mode == 2) GF2_LPN_RPT(1, 2);

@@ -156,17 +156,17 @@ static const char *abl_name(int abl) {
   return abl == 0 ? "" : abl == 1 ? " abl:nobuild" : abl == 2 ? " abl:nolookup" : abl == 3 ? " abl:neither" : abl == 4 ? " stamps" : abl == 8 ? " stamps(build)" : " abl:?";
 }
 
-template <int NW, int NT, int RPT, int MODE, int EARLY = 2, int ABL = 0>
+template <int NW, int NT, int RPT, int MODE, int EARLY = 2, int ABL = 0, int STRIDED = 0>
 static Variant make_k8() {
   constexpr int ldsb = kLpn8LdsBytes(NW);
-  set_lds(gf2_lpn8_kernel<NW, NT, RPT, MODE, EARLY, ABL>, ldsb);
+  set_lds(gf2_lpn8_kernel<NW, NT, RPT, MODE, EARLY, ABL, STRIDED>, ldsb);
   char nm[96];
-  snprintf(nm, sizeof nm, "lpn8<w%d,%d,%d,m%d,e%d>%s", NW, NT, RPT, MODE, EARLY, abl_name(ABL));
+  snprintf(nm, sizeof nm, "lpn8<w%d,%d,%d,m%d,e%d%s>%s", NW, NT, RPT, MODE, EARLY, STRIDED ? ",strided" : "", abl_name(ABL));
   return {nm, [](const u64 *A, const u64 *B, u64 *C, int m, int V) {
             unsigned grid = (unsigned)((m + NT * RPT - 1) / (NT * RPT));
             if (g_grid_cap && grid > (unsigned)g_grid_cap) grid = g_grid_cap;
             const int wn = (V + 63) / 64;
-            hipLaunchKernelGGL((gf2_lpn8_kernel<NW, NT, RPT, MODE, EARLY, ABL>), dim3(grid), dim3(NT), ldsb, 0, A, 4, B, wn, C, wn, m, 256, V, 0);
+            hipLaunchKernelGGL((gf2_lpn8_kernel<NW, NT, RPT, MODE, EARLY, ABL, STRIDED>), dim3(grid), dim3(NT), ldsb, 0, A, 4, B, wn, C, wn, m, 256, V, 0);
           }};
 }
 template <int NT, int RPT, int MODE, int EARLY = 2, int ABL = 0, int ORD = 0>
@@ -279,6 +279,7 @@ int main(int argc, char **argv) {
     if (wn == 1) {
       vs.push_back(make_k8<1, 512, 4, 2>());
       vs.push_back(make_k8<1, 512, 4, 2, 3>());
+      vs.push_back(make_k8<1, 512, 4, 2, 3, 0, 1>());
       vs.push_back(make_k8<1, 512, 8, 2>());
       vs.push_back(make_k8<1, 512, 8, 2, 3>());
       vs.push_back(make_k8<1, 512, 8, 2, 4>());
@@ -290,6 +291,7 @@ int main(int argc, char **argv) {
       vs.push_back(make_k8<2, 1024, 4, 2, 4>());
       vs.push_back(make_k8<2, 512, 8, 2>());
       vs.push_back(make_k8<2, 512, 8, 2, 3>());
+      vs.push_back(make_k8<2, 512, 8, 2, 3, 0, 1>());
       vs.push_back(make_k8<2, 512, 8, 2, 4>());
       vs.push_back(make_k8<2, 512, 8, 2, 6>());
       vs.push_back(make_k8<2, 512, 4, 2>());
@@ -305,6 +307,9 @@ int main(int argc, char **argv) {
       vs.push_back(make_k256<512, 8, 2, 3, 0, 5>());
       vs.push_back(make_k256<512, 8, 2, 4, 0, 1>());
       vs.push_back(make_k256<512, 8, 2, 2, 3>());
+      vs.push_back(make_k256<512, 8, 2, 3, 0, 13>());
+      vs.push_back(make_k256<1024, 4, 2, 2, 0, 13>());
+      vs.push_back(make_k256<512, 8, 2, 3, 3, 13>());
       vs.push_back(make_k256<512, 8, 2, 3, 1, 5>());
       vs.push_back(make_k256<512, 8, 2, 3, 2, 5>());
       vs.push_back(make_k256<512, 8, 2, 3, 3, 5>());
