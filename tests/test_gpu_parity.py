@@ -1104,7 +1104,7 @@ def test_random_shape_fuzz(pkg):
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 40, 100, 200])
-@pytest.mark.parametrize("m,mode", [(1048576, 0), (1048576, 1), (600001, 0), (600001, 1), (600001, 2), (300003, 0), (300003, 1), (300003, 2)])
+@pytest.mark.parametrize("m,mode", [(1048576, 0), (1048576, 1), (1048576, 2), (600001, 0), (600001, 1), (600001, 2), (300003, 0), (300003, 1), (300003, 2)])
 def test_lpn_kernels_every_instantiation(dev, m, mode, n):
     """Every (rows per lane, loader) instantiation of the l <= 256 kernels that the launcher can choose (tools/kernel_coverage.py found 20
     of them never launched by this suite): rows per lane 8 / 4 / 2 / 1 by the row count, loader 2 = contiguous 256-bit rows, 1 = strided

@@ -52,7 +52,7 @@ python3 tools/pmc_summary.py FETCH_SIZE=$(ls $O/pmc_fetch/*/*counter_collection.
 python3 tools/pmc_summary.py FETCH_SIZE=$(ls $O/pmc_lpn_fetch/*/*counter_collection.csv | head -1) WRITE_SIZE=$(ls $O/pmc_lpn_write/*/*counter_collection.csv | head -1) > $O/lpn_pmc_summary.json
 rm -rf $O/prof_elim $O/prof_bench $O/pmc_fetch $O/pmc_write $O/prof_lpn $O/pmc_lpn_fetch $O/pmc_lpn_write $O/prof_configs
 # SQ counters of the two LPN kernels (lab variants = the shipped configurations)
-tools/lab_pmc.sh 256 "lpn256<512,8,m2,e3,o5>" > $O/lpn256_sq.txt 2>&1
-tools/lab_pmc.sh 64 "lpn8<w1,512,4,m2,e3>" > $O/lpn8_sq.txt 2>&1
+tools/lab_pmc.sh 256 "lpn256<512,8,m2,e3,o13>" > $O/lpn256_sq.txt 2>&1
+tools/lab_pmc.sh 64 "lpn8<w1,512,4,m2,e3,strided>" > $O/lpn8_sq.txt 2>&1
 python3 bench.py --gpus 2 --backend gloo --check --dim 16384 --no-cpu --steps 3 --warmup 1 2>$O/two_rank_rehearsal.err | grep "^{" > $O/two_rank_rehearsal.json
 ls -la $O
