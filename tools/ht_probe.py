@@ -1,3 +1,5 @@
+"""What in a process slows `BinMatrix.transposed()` of a 65536^2 host matrix down? (development tool; result: freeing ~17 GiB of device
+memory just before -- profiles/r04_host_path.txt).  python tools/ht_probe.py plain|torch|torchpin|streamsN|trim|main[_mul][_hash][_towords][_notrim][_sleep]|benchfn"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
