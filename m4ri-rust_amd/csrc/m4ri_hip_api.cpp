@@ -2493,10 +2493,14 @@ int echelonize_dev(gf2_dmat *A, int full, int col_limit, int *rank_out, int *piv
   static const int spec_on = dev_env_int("M4RI_HIP_ELIM_SPECULATE", 1);
   const bool spec = spec_on && limit == ncols;
   thread_local gf2k_elim_state *hpin = nullptr;
-  thread_local hipEvent_t hev = nullptr;
-  if (spec && !hpin) {
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&hpin), sizeof(gf2k_elim_state), hipHostMallocPortable));
-    HIP_TRY(hipEventCreateWithFlags(&hev, hipEventDisableTiming));
+  thread_local hipEvent_t hevs[16] = {};  // one per device: an event belongs to the device that was current when it was created
+  hipEvent_t hev = nullptr;
+  if (spec) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (!hpin) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&hpin), sizeof(gf2k_elim_state), hipHostMallocPortable));
+    if (!hevs[dev & 15]) HIP_TRY(hipEventCreateWithFlags(&hevs[dev & 15], hipEventDisableTiming));
+    hev = hevs[dev & 15];
   }
   bool prev_empty = false;
   int r_cur = 0;
