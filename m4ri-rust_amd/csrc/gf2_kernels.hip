@@ -1980,8 +1980,23 @@ __global__ __launch_bounds__(256) void gf2_tallskinny6_kernel(const u64 *__restr
 template <int RPT, int NW>  // NW = words per row of C (n <= 64 NW): entries of 8 NW bytes, 16 KiB x NW of tables
 __global__ __launch_bounds__(256) void gf2_tallskinny7_kernel(const u64 *__restrict__ A, long long lda, const u64 *__restrict__ B,
                                                               long long ldb, u64 *__restrict__ C, long long ldc, int m, int l,
-                                                              int n, int accumulate, int slabs_per_split, int atomic, int vec_ok) {
+                                                              int n, int accumulate, int slabs_per_split, int atomic, int vec_ok,
+                                                              int remap_splits, int remap_rblocks) {
   static_assert(NW == 1 || NW == 2, "a 16-entry table must not span more than the 64 banks");
+  // Which (row block, division of the inner dimension) a workgroup takes: a workgroup reads 64-byte pieces a row pitch apart, the
+  // access pattern of the 512-tile transposition, whose rate depends on which pieces are in flight together (gf2_transpose512_kernel,
+  // tools/tilecopy.hip).  remap_splits > 0: a 1-D grid whose workgroups b, b + 8, ... (one XCD, dispatched together) take blocks of
+  // 4 divisions x 4 row blocks out of super-tiles of 16 x 8, super-tiles walked diagonally, the XCD's place rotating -- 256
+  // contiguous bytes per row and XCD, and no two super-tiles in flight with the same low address bits.
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (remap_splits > 0) {
+    const int b = blockIdx.x, sx_n = (remap_splits + 15) >> 4, sy_n = (remap_rblocks + 7) >> 3;
+    const int st = b >> 7, in = b & 127, x = in & 7, slot = in >> 3;
+    const int stx = st % sx_n, sty = (st / sx_n + stx) % sy_n;
+    const int px = ((x & 3) + stx + sty) & 3, py = ((x >> 2) + stx + (sty >> 2)) & 1;
+    by = stx * 16 + 4 * px + (slot & 3), bx = sty * 8 + 4 * py + (slot >> 2);
+    if (by >= remap_splits || bx >= remap_rblocks) return;  // (uniform: the grid is padded to whole super-tiles)
+  }
   extern __shared__ __align__(16) unsigned char lds[];
   constexpr int EB = 8 * NW, TB = 16 * EB;       // bytes per entry / per table
   u64 *bst = reinterpret_cast<u64 *>(lds + 128 * TB);  // the 512 rows of B of the slab (NW words each)
@@ -1989,8 +2004,8 @@ __global__ __launch_bounds__(256) void gf2_tallskinny7_kernel(const u64 *__restr
   const int wl = (l + 63) >> 6, wn = (n + 63) >> 6;
   const u64 maskC = (n & 63) ? ((1ull << (n & 63)) - 1) : ~0ull;
   const int nslabs = (l + 511) >> 9;
-  const int slab0 = blockIdx.y * slabs_per_split, slab1 = min(nslabs, slab0 + slabs_per_split);
-  const long long row0 = (long long)blockIdx.x * (256 * RPT) + tid;
+  const int slab0 = by * slabs_per_split, slab1 = min(nslabs, slab0 + slabs_per_split);
+  const long long row0 = (long long)bx * (256 * RPT) + tid;
   u32 acc[RPT][2 * NW];
 #pragma unroll
   for (int r = 0; r < RPT; ++r)
@@ -3268,12 +3283,17 @@ extern "C" hipError_t gf2k_tallskinny_long(const u64 *A, long long lda, const u6
   }
   const int vec_ok = (lda & 1) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
   const size_t lds7 = (size_t)(128 * 16 * 8 + 512 * 8) * nwC;
+  // many divisions and row blocks: the workgroups take them in the XCD-blocked, diagonal order (see the kernel)
+  static const int remap_on = GF2K_DEV_ENV("M4RI_HIP_TS7_REMAP", 1);
+  const bool remap = remap_on && splits >= 16 && rblocks >= 8 && ((splits + 15) / 16) * ((rblocks + 7) / 8) * 128 < (1ll << 30);
+  const dim3 grid = remap ? dim3((unsigned)(((splits + 15) / 16) * ((rblocks + 7) / 8) * 128)) : dim3((unsigned)rblocks, (unsigned)splits);
+  const int rs = remap ? (int)splits : 0, rb = remap ? (int)rblocks : 0;
   if (nwC == 1)
-    hipLaunchKernelGGL((gf2_tallskinny7_kernel<RPT, 1>), dim3((unsigned)rblocks, (unsigned)splits), dim3(256), lds7, stream, A, lda, B, ldb,
-                       C, ldc, m, l, n, accumulate, sps, atomic, vec_ok);
+    hipLaunchKernelGGL((gf2_tallskinny7_kernel<RPT, 1>), grid, dim3(256), lds7, stream, A, lda, B, ldb, C, ldc, m, l, n, accumulate, sps, atomic,
+                       vec_ok, rs, rb);
   else
-    hipLaunchKernelGGL((gf2_tallskinny7_kernel<RPT, 2>), dim3((unsigned)rblocks, (unsigned)splits), dim3(256), lds7, stream, A, lda, B, ldb,
-                       C, ldc, m, l, n, accumulate, sps, atomic, vec_ok);
+    hipLaunchKernelGGL((gf2_tallskinny7_kernel<RPT, 2>), grid, dim3(256), lds7, stream, A, lda, B, ldb, C, ldc, m, l, n, accumulate, sps, atomic,
+                       vec_ok, rs, rb);
   return hipGetLastError();
 }
 

@@ -894,7 +894,7 @@ def test_lpn_kernels_strides_and_alignment(dev, n, lda, ldc_extra, off):
 @pytest.mark.parametrize("m,l,n", [(300, 5000, 1), (1000, 70001, 1), (4097, 1500, 8), (2500, 3000, 33), (5000, 2049, 64), (64, 100000, 17),
                                    (16, 600, 3), (2100, 513, 5), (3000, 1025, 9), (777, 8192, 32), (4096, 4096, 2), (150, 200000, 40),
                                    (70000, 1100, 1), (33, 1000000, 4), (70000, 600, 7), (66000, 1000, 50), (140000, 300, 64), (20000, 5000, 12),
-                                   (66000, 2049, 10), (1100000, 513, 3)])
+                                   (66000, 2049, 10), (1100000, 513, 3), (9000, 33000, 40), (66000, 9000, 20)])
 def test_wide_matrix_times_few_vectors(pkg, dev, m, l, n):
     """`&A * &v` and blocks of up to 64 vectors on a matrix with LONG rows (mul_slice, binary_matrix.rs:416-431,528-542, on shapes
     the reference's callers reach with a large square A): the wave-per-row kernel (inner dimension in slabs, 32 vectors per pass)

@@ -15,7 +15,9 @@ sys.path.insert(0, ROOT)
 def main():
     import torch
     import m4ri_rust_amd  # noqa: F401
-    from m4ri_rust_amd import device as dev
+    from m4ri_rust_amd import _lib, device as dev
+    if os.environ.get("AB_LIB"):  # A/B of two builds on one box: load this shared object instead
+        _lib.LIB_PATH = os.environ["AB_LIB"]
     dev.require_gpu()
     for spec in sys.argv[1:]:
         f = spec.split(",")
