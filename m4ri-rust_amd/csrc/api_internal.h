@@ -12,3 +12,9 @@ void gf2_cache_forget(mzd_t const *M);
 // size dispatch of the drop-in entry points (gf2_small_host.cpp): M4RI_HIP_HOST_SMALL_WORK word operations, 0 = never
 long long gf2_small_work_limit();
 bool gf2_small_product(long long m, long long l, long long n);
+// pinned scratch blocks from the pool of mzd_host.cpp (null without a device)
+void *gf2_pinned_alloc(size_t bytes);
+void gf2_pinned_free(void *p, size_t bytes);
+// mzd_transpose(DST, A) served from the packed side copy a fresh thin product carries (m4ri_hip_api.cpp, ResultSide): the
+// destination (allocated when DST is NULL), or nullptr when A has no side copy
+mzd_t *gf2_transpose_from_side_copy(mzd_t *DST, mzd_t const *A);

@@ -1889,6 +1889,24 @@ struct CachedOperand {
 std::mutex g_cache_mu;
 std::map<const void *, std::shared_ptr<CachedOperand>> g_cache;
 
+// Result side copies: the PACKED TRANSPOSED form of a fresh thin product, kept on the host next to the product.  The friendly layer
+// turns every `&A * &v` into mzd_mul_naive(NULL, A, v^T) followed by mzd_transpose(NULL, result) (binary_matrix.rs:416-431,
+// :332-361, :528-542): in M4RI's layout the 2^20 x 1 result is one 64-bit word per row, 8 MiB for 128 KiB of bits, and gathering
+// bit 0 of 2^20 words on the host cost 204 us of a 565-us call (profiles/r05_av_breakdown.txt).  The device has those bits in a
+// register file anyway: a product into a library-allocated (NULL) destination with at most M4RI_HIP_RESULT_SIDE_COLS columns also
+// transposes C on the device (one launch) and brings the n x m form down beside C; mzd_transpose of that matrix is then a copy.
+// Keyed like the operand cache by the matrix' block and dropped by the same gf2_cache_forget calls (every library routine that
+// writes a matrix, and mzd_free); stores through rows[] are invisible to the library, as for the operand cache.
+struct ResultSide {
+  word *buf = nullptr;  // pinned; ncols rows of ld words
+  size_t bytes = 0;
+  size_t ld = 0;
+  int nrows = 0, ncols = 0, rowstride = 0;  // of the product
+  const word *row0 = nullptr;
+  ~ResultSide() { gf2_pinned_free(buf, bytes); }
+};
+std::map<const void *, std::shared_ptr<ResultSide>> g_result_side;
+
 struct DMatOwner {
   gf2_dmat d{};
   std::shared_ptr<CachedOperand> borrowed;  // d belongs to the operand cache, kept alive by this reference
@@ -1958,7 +1976,18 @@ void unlease_stream(int dev, hipStream_t s) {
 
 // One device's share of a host product: C[r0:r1, :] (+)= A[r0:r1, :] * B on the CURRENT device, stream s.  Returns when
 // those rows of C are complete in host memory.
-int host_mul_range(mzd_t *C, const mzd_t *A, const mzd_t *B, int r0, int r1, int accumulate, int algo, int param, hipStream_t s) {
+// The side copy of a fresh thin product (see ResultSide): C^T into a device scratch, brought down into `side->buf` on stream s.
+// The caller synchronises s before it looks at the buffer or lets `dT` go.
+// Rows [r0, r0 + c.nrows) of a fresh thin product C (r0 a multiple of 64) into their words of every row of the side copy.  The
+// transposition kernel stores straight into the pinned host buffer (device-visible like every hipHostMalloc block; 128 KiB for
+// 2^20 x 1): no scratch and no second download queued behind C's on the copy engine.  Complete once stream s has been synchronised.
+int result_side_rows(ResultSide *side, const gf2_dmat &c, int r0, hipStream_t s) {
+  const hipError_t e = gf2k_transpose(reinterpret_cast<u64 *>(side->buf) + r0 / 64, (long long)side->ld, c.data, c.ld, c.nrows, c.ncols, s);
+  return e == hipSuccess ? 0 : fail(e, "gf2k_transpose");
+}
+
+int host_mul_range(mzd_t *C, const mzd_t *A, const mzd_t *B, int r0, int r1, int accumulate, int algo, int param, hipStream_t s,
+                   ResultSide *side = nullptr) {
   const int rows = r1 - r0;
   if (rows <= 0) return 0;
   int rc = 0;
@@ -1975,8 +2004,12 @@ int host_mul_range(mzd_t *C, const mzd_t *A, const mzd_t *B, int r0, int r1, int
   // 1.33-1.40 ms -- 49 leaves = 392 tiles = 1.5 rounds, run as a whole round plus a tail launch -- where a quarter of the whole
   // product's time would be 1.1: four of them are 5.5 ms of device work behind the 2.4 ms the first two pieces take to arrive.
   // Not kept: the floor of either decomposition is the rate of its sub-products, profiles/r04_host_path_timeline.txt.)
+  // Thin products (the LPN shape, 2^20 x 256 times a few vectors) are pipelined too: their kernels stream A at HBM rate, so the call
+  // IS the upload of A (32 MiB: 0.56 ms) -- with row blocks the kernel and the download of C (8 MiB in M4RI's layout) hide behind it
+  // instead of following it.
+  const bool thin = B->ncols <= 256 && A->ncols <= 1024 && (size_t)rows * A->rowstride * sizeof(word) >= ((size_t)8 << 20);
   if (pipe_blocks >= 2 && !accumulate && plain_layout && rows >= 16384 && rows % (pipe_blocks * 64) == 0 &&
-      (long long)A->ncols * B->ncols >= (1ll << 28) && !(whole && cache_lookup(A))) {
+      ((long long)A->ncols * B->ncols >= (1ll << 28) || thin) && !(whole && cache_lookup(A))) {
     // Units: row blocks of A and C (contiguous rows) x halves of the inner dimension (contiguous rows of B):
     //   C_i = A_i[:, 0:l/2] * B[0:l/2, :]  ^  A_i[:, l/2:l] * B[l/2:l, :]
     // so that the first product can start after ONE block of A and HALF of B have arrived (7.3 ms of PCIe at n = 65536
@@ -1984,10 +2017,10 @@ int host_mul_range(mzd_t *C, const mzd_t *A, const mzd_t *B, int r0, int r1, int
     const int l = A->ncols;
     const bool bcached = (bool)cache_lookup(B);
     const int K = (!bcached && l >= 8192 && l % 256 == 0 && B->rowstride >= 1 && !(B->flags & mzd_flag_windowed_zerooffset)) ? 2 : 1;
-    SideStream *side = nullptr;
-    rc = side_stream(s, 2 * pipe_blocks + 3, &side, /*want_s3=*/true);
+    SideStream *sd = nullptr;
+    rc = side_stream(s, 2 * pipe_blocks + 3, &sd, /*want_s3=*/true);
     DMatOwner dA, dB, dC;
-    if (!rc) rc = to_device(dB, B, side->s2, K == 1);  // K == 2: allocated here, uploaded in halves below
+    if (!rc) rc = to_device(dB, B, sd->s2, K == 1);  // K == 2: allocated here, uploaded in halves below
     if (!rc) rc = to_device_rows(dA, A, r0, r1, s, false);
     if (!rc) rc = to_device_rows(dC, C, r0, r1, s, false);
     // block boundaries: four equal blocks, or -- when a quarter still has 16384 rows -- a quarter, a half and a quarter: the
@@ -1996,7 +2029,12 @@ int host_mul_range(mzd_t *C, const mzd_t *A, const mzd_t *B, int r0, int r1, int
     std::vector<int> bnd;
     {
       const int q = rows / pipe_blocks;
-      if (pipe_blocks == 4 && q >= 16384) bnd = {0, q, 3 * q, rows};
+      if (pipe_blocks == 4 && q >= 16384 && !thin) bnd = {0, q, 3 * q, rows};
+      // a thin product is nothing but its copies: every block boundary costs ~20 us between two uploads, and what follows the last
+      // upload (~100 us of fixed latencies: event -> kernel 26, kernel -> copy 35, the copies' own ~9 each) is exposed -- so two blocks,
+      // the second short: 3/16 of the rows put the end of the first block's download where the second block's kernel ends
+      // (2^20 x 256 x 1 under the profiler: 793 us with four equal blocks, 763 with these two; unpipelined 800; profiles/r05_av_timeline.txt)
+      else if (thin && pipe_blocks == 4) bnd = {0, (int)((long long)rows * 13 / 16) & ~63, rows};
       else
         for (int i = 0; i <= pipe_blocks; ++i) bnd.push_back(i * q);
     }
@@ -2004,19 +2042,19 @@ int host_mul_range(mzd_t *C, const mzd_t *A, const mzd_t *B, int r0, int r1, int
     auto rows_bytes = [](const mzd_t *M, int nr) { return ((size_t)(nr - 1) * M->rowstride + M->width) * sizeof(word); };
     if (!rc && (dA.d.ld != A->rowstride || dC.d.ld != C->rowstride || (K == 2 && dB.d.ld != B->rowstride)))
       rc = fail_msg("host pipeline: unexpected device stride");
-    hipEvent_t *evA = side ? side->ev.data() : nullptr, *evC = evA + pipe_blocks, *evB = evC + pipe_blocks;
+    hipEvent_t *evA = sd ? sd->ev.data() : nullptr, *evC = evA + pipe_blocks, *evB = evC + pipe_blocks;
     auto upload_a = [&](int i) {
       if (hipMemcpyAsync(dA.d.data + (size_t)bnd[i] * dA.d.ld, A->rows[r0 + bnd[i]], rows_bytes(A, bnd[i + 1] - bnd[i]), hipMemcpyHostToDevice,
-                         side->s2) != hipSuccess ||
-          hipEventRecord(evA[i], side->s2) != hipSuccess)
+                         sd->s2) != hipSuccess ||
+          hipEventRecord(evA[i], sd->s2) != hipSuccess)
         rc = fail(hipGetLastError(), "host pipeline: upload of A");
     };
     if (!rc) upload_a(0);
     for (int k = 0; !rc && k < K; ++k) {  // K == 1: B went up whole above (or lives in the operand cache)
       if (K == 2 && hipMemcpyAsync(dB.d.data + (size_t)k * (l / 2) * dB.d.ld, B->rows[k * (l / 2)], rows_bytes(B, l / 2), hipMemcpyHostToDevice,
-                                   side->s2) != hipSuccess)
+                                   sd->s2) != hipSuccess)
         rc = fail(hipGetLastError(), "host pipeline: upload of B");
-      if (!rc && hipEventRecord(evB[k], side->s2) != hipSuccess) rc = fail(hipGetLastError(), "host pipeline: event");
+      if (!rc && hipEventRecord(evB[k], sd->s2) != hipSuccess) rc = fail(hipGetLastError(), "host pipeline: event");
     }
     for (int i = 1; !rc && i < NBLK; ++i) upload_a(i);
     for (int i = 0; !rc && i < NBLK; ++i) {
@@ -2040,20 +2078,33 @@ int host_mul_range(mzd_t *C, const mzd_t *A, const mzd_t *B, int r0, int r1, int
           if (hipStreamWaitEvent(s, evB[kk], 0) != hipSuccess) rc = fail(hipGetLastError(), "host pipeline: wait");
         if (!rc) rc = mul_dispatch(&c, &a, &b, k > 0, algo, param, s, /*sync_free=*/false);
       }
-      if (!rc && (hipEventRecord(evC[i], s) != hipSuccess || hipStreamWaitEvent(side->s3, evC[i], 0) != hipSuccess ||
-                  hipMemcpyAsync(C->rows[r0 + bnd[i]], c.data, rows_bytes(C, R), hipMemcpyDeviceToHost, side->s3) != hipSuccess))
+      if (!rc && (hipEventRecord(evC[i], s) != hipSuccess || hipStreamWaitEvent(sd->s3, evC[i], 0) != hipSuccess ||
+                  hipMemcpyAsync(C->rows[r0 + bnd[i]], c.data, rows_bytes(C, R), hipMemcpyDeviceToHost, sd->s3) != hipSuccess))
         rc = fail(hipGetLastError(), "host pipeline: download");
+      if (!rc && side) rc = result_side_rows(side, c, bnd[i], s);  // beside the block's download
     }
-    if (side && hipStreamSynchronize(side->s2) != hipSuccess && !rc) rc = fail(hipGetLastError(), "host pipeline: upload stream");
-    if (side && side->s3 && hipStreamSynchronize(side->s3) != hipSuccess && !rc) rc = fail(hipGetLastError(), "host pipeline: download stream");
+    if (sd && hipStreamSynchronize(sd->s2) != hipSuccess && !rc) rc = fail(hipGetLastError(), "host pipeline: upload stream");
+    if (sd && sd->s3 && hipStreamSynchronize(sd->s3) != hipSuccess && !rc) rc = fail(hipGetLastError(), "host pipeline: download stream");
     if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = fail(hipGetLastError(), "host pipeline: compute stream");
   } else {
     DMatOwner dA, dB, dC;
     rc = to_device_rows(dA, A, r0, r1, s, true);
     if (!rc) rc = to_device(dB, B, s, true);
     if (!rc) rc = to_device_rows(dC, C, r0, r1, s, accumulate != 0);
-    if (!rc) rc = mul_dispatch(&dC.d, &dA.d, &dB.d, accumulate, algo, param, s, /*sync_free=*/true);
-    if (!rc) rc = download_rows(C, r0, &dC.d, s);
+    // (thin products: no wait between the kernel and the download -- the download's own launch latency would be exposed behind it)
+    if (!rc) rc = mul_dispatch(&dC.d, &dA.d, &dB.d, accumulate, algo, param, s, /*sync_free=*/!(side || B->ncols <= 64));
+    if (!rc && side) {
+      // C comes down on the download stream while the compute stream transposes it and brings the small form down
+      SideStream *sd = nullptr;
+      rc = side_stream(s, 1, &sd, /*want_s3=*/true);
+      if (!rc && (hipEventRecord(sd->ev[0], s) != hipSuccess || hipStreamWaitEvent(sd->s3, sd->ev[0], 0) != hipSuccess ||
+                  hipMemcpyAsync(C->rows[r0], dC.d.data, ((size_t)(rows - 1) * C->rowstride + C->width) * sizeof(word), hipMemcpyDeviceToHost,
+                                 sd->s3) != hipSuccess))
+        rc = fail(hipGetLastError(), "thin product: download");
+      if (!rc) rc = result_side_rows(side, dC.d, 0, s);
+      if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = fail(hipGetLastError(), "thin product: compute stream");
+      if (sd && sd->s3 && hipStreamSynchronize(sd->s3) != hipSuccess && !rc) rc = fail(hipGetLastError(), "thin product: download stream");
+    } else if (!rc) rc = download_rows(C, r0, &dC.d, s);
     if (rc) (void)hipStreamSynchronize(s);
   }
   return rc;
@@ -2212,8 +2263,26 @@ mzd_t *host_mul_on(mzd_t *C, const mzd_t *A, const mzd_t *B, int accumulate, int
       if (allocated) mzd_free(C);
       return bail("stream");
     }
-    rc = host_mul_range(C, A, B, 0, A->nrows, accumulate, algo, param, s);
+    // a fresh thin product also comes back in its packed transposed form (see ResultSide)
+    static const int side_cols = env_int("M4RI_HIP_RESULT_SIDE_COLS", 8);
+    std::shared_ptr<ResultSide> side;
+    if (allocated && !windows && C->ncols <= side_cols && C->blocks && C->blocks[0].size >= ((size_t)1 << 20)) {
+      side = std::make_shared<ResultSide>();
+      side->ld = ((size_t)C->nrows + 63) / 64;
+      side->bytes = (size_t)C->ncols * side->ld * sizeof(word);
+      side->buf = static_cast<word *>(gf2_pinned_alloc(side->bytes));
+      if (!side->buf) side.reset();  // pinning failed: the product does not depend on it
+    }
+    rc = host_mul_range(C, A, B, 0, A->nrows, accumulate, algo, param, s, side.get());
     if (want >= 0) (void)hipSetDevice(cur);
+    if (!rc && side) {
+      side->nrows = C->nrows;
+      side->ncols = C->ncols;
+      side->rowstride = C->rowstride;
+      side->row0 = C->rows[0];
+      std::lock_guard<std::mutex> lk(g_cache_mu);
+      g_result_side[cache_key(C)] = std::move(side);
+    }
   }
   if (rc) {
     if (allocated) mzd_free(C);
@@ -2240,8 +2309,16 @@ extern "C" mzd_t *gf2_mul_multi(mzd_t *C, mzd_t const *A, mzd_t const *B, int al
 
 void gf2_cache_forget(mzd_t const *M) {
   std::shared_ptr<CachedOperand> c;
+  std::shared_ptr<ResultSide> sd;
   {
     std::lock_guard<std::mutex> lk(g_cache_mu);
+    if (!g_result_side.empty()) {
+      auto it = g_result_side.find(cache_key(M));
+      if (it != g_result_side.end()) {
+        sd = std::move(it->second);
+        g_result_side.erase(it);
+      }
+    }
     if (g_cache.empty()) return;
     auto it = g_cache.find(cache_key(M));
     if (it == g_cache.end()) return;
@@ -2276,6 +2353,32 @@ extern "C" int gf2_mzd_cache_on_device(mzd_t const *M) {
 }
 
 extern "C" void gf2_mzd_uncache(mzd_t const *M) { gf2_cache_forget(M); }
+
+// mzd_transpose(DST, A) from the side copy of A, if A is a fresh thin product that still has one: DST (allocated when NULL) or nullptr.
+mzd_t *gf2_transpose_from_side_copy(mzd_t *DST, mzd_t const *A) {
+  std::shared_ptr<ResultSide> sd;
+  {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    if (g_result_side.empty()) return nullptr;
+    auto it = g_result_side.find(cache_key(A));
+    if (it == g_result_side.end()) return nullptr;
+    sd = it->second;
+  }
+  // the same view of the block (a window of the product is a different matrix)
+  if (sd->nrows != A->nrows || sd->ncols != A->ncols || sd->rowstride != A->rowstride || sd->row0 != A->rows[0] ||
+      (A->flags & mzd_flag_windowed_zerooffset))
+    return nullptr;
+  const bool fresh = DST == nullptr;
+  if (fresh) DST = gf2_mzd_init_uncleared(A->ncols, A->nrows);
+  const wi_t w = DST->width;
+  for (rci_t i = 0; i < DST->nrows; ++i) {
+    word *d = DST->rows[i];
+    const word *t = sd->buf + (size_t)i * sd->ld;
+    if (w > 1) std::memcpy(d, t, (size_t)(w - 1) * sizeof(word));
+    d[w - 1] = fresh ? (t[w - 1] & DST->high_bitmask) : ((d[w - 1] & ~DST->high_bitmask) | (t[w - 1] & DST->high_bitmask));
+  }
+  return DST;
+}
 
 int gf2_host_transpose_gpu(mzd_t *dst, mzd_t const *src) {
   if (require_device()) return -1;

@@ -42,9 +42,19 @@ static size_t pin_threshold() {
 
 // Pinned blocks are expensive to create (hipHostMalloc pins pages: ~100 ms for 512 MiB), so freed ones are kept in a
 // small size-keyed pool and handed out again (M4RI keeps a similar cache of its own blocks, m4ri_mmc).
+// A pooled block keeps its ROW-POINTER ARRAY: rows[i] = begin + i * rowstride is a function of the block's address and the
+// shape alone, and for a tall thin matrix the array is as large as the data (2^20 x 1, the result of every `&A * &v` of an
+// LPN solver, binary_matrix.rs:416-431: 8 MiB of pointers beside 8 MiB of words -- allocating and filling it took 226 us of a
+// 565-us call, profiles/r05_av_breakdown.txt).  The next matrix of the same shape takes block and array as they are.
 namespace {
+struct PinEntry {
+  void *p;
+  word **rows;  // may be null (blocks that never carried a matrix: gf2_pinned_alloc)
+  rci_t nrows;
+  wi_t rowstride;
+};
 std::mutex g_pin_mu;
-std::multimap<size_t, void *> g_pin_free;
+std::multimap<size_t, PinEntry> g_pin_free;
 size_t g_pin_cached = 0;
 size_t pin_cache_limit() {
   static size_t t = [] {
@@ -53,21 +63,54 @@ size_t pin_cache_limit() {
   }();
   return t;
 }
+
+word **make_rows(word *begin, rci_t r, wi_t rowstride) {
+  word **rows = static_cast<word **>(std::malloc(((size_t)r + 1) * sizeof(word *)));
+  if (!rows) gf2_die("out of memory");
+  for (rci_t i = 0; i < r; ++i) rows[i] = begin + (size_t)i * rowstride;
+  rows[r] = nullptr;
+  return rows;
+}
+
+// a pooled pinned block of exactly `bytes`, preferring one whose row-pointer array fits (r, rowstride); *rows is that array or null
+void *pin_pool_take(size_t bytes, rci_t r, wi_t rowstride, word ***rows) {
+  PinEntry e{nullptr, nullptr, 0, 0};
+  {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    auto range = g_pin_free.equal_range(bytes);
+    auto pick = range.first;
+    for (auto it = range.first; it != range.second; ++it)
+      if (it->second.rows && it->second.nrows == r && it->second.rowstride == rowstride) {
+        pick = it;
+        break;
+      }
+    if (pick == range.second) return nullptr;
+    e = pick->second;
+    g_pin_cached -= bytes;
+    g_pin_free.erase(pick);
+  }
+  if (e.rows && (e.nrows != r || e.rowstride != rowstride || !rows)) {
+    std::free(e.rows);
+    e.rows = nullptr;
+  }
+  if (rows) *rows = e.rows;
+  return e.p;
+}
+
+bool pin_pool_give(void *p, size_t bytes, word **rows, rci_t r, wi_t rowstride) {
+  std::lock_guard<std::mutex> lk(g_pin_mu);
+  if (g_pin_cached + bytes > pin_cache_limit()) return false;
+  g_pin_free.emplace(bytes, PinEntry{p, rows, r, rowstride});
+  g_pin_cached += bytes;
+  return true;
+}
 }  // namespace
 
-static void *block_alloc(size_t bytes, uint8_t *kind, bool zero) {
+// *rows: in = null; out = a row-pointer array for (r, rowstride) that came with a pooled block, or still null
+static void *block_alloc(size_t bytes, uint8_t *kind, bool zero, rci_t r = 0, wi_t rowstride = 0, word ***rows = nullptr) {
   *kind = kAllocMalloc;
   if (bytes >= pin_threshold() && gf2_device_count() > 0) {
-    void *p = nullptr;
-    {
-      std::lock_guard<std::mutex> lk(g_pin_mu);
-      auto it = g_pin_free.find(bytes);
-      if (it != g_pin_free.end()) {
-        p = it->second;
-        g_pin_cached -= bytes;
-        g_pin_free.erase(it);
-      }
-    }
+    void *p = pin_pool_take(bytes, r, rowstride, rows);
     if (!p && hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
       (void)hipGetLastError();
       p = nullptr;
@@ -84,21 +127,30 @@ static void *block_alloc(size_t bytes, uint8_t *kind, bool zero) {
   return p;
 }
 
-static void block_free(void *p, uint8_t kind, size_t bytes) {
-  if (!p) return;
-  if (kind == kAllocPinned) {
-    {
-      std::lock_guard<std::mutex> lk(g_pin_mu);
-      if (g_pin_cached + bytes <= pin_cache_limit()) {
-        g_pin_free.emplace(bytes, p);
-        g_pin_cached += bytes;
-        return;
-      }
-    }
+// `rows` (may be null) is the block's row-pointer array: it stays with a pooled block and is freed otherwise
+static void block_free(void *p, uint8_t kind, size_t bytes, word **rows = nullptr, rci_t r = 0, wi_t rowstride = 0) {
+  if (p && kind == kAllocPinned) {
+    if (pin_pool_give(p, bytes, rows, r, rowstride)) return;
     (void)hipHostFree(p);
-  } else {
+  } else if (p) {
     std::free(p);
   }
+  std::free(rows);
+}
+
+// Small pinned scratch blocks for the rest of the library (the packed side copy of a thin product, m4ri_hip_api.cpp): same pool,
+// whatever the size; null without a device or when pinning fails.
+void *gf2_pinned_alloc(size_t bytes) {
+  if (!bytes || gf2_device_count() <= 0) return nullptr;
+  void *p = pin_pool_take(bytes, 0, 0, nullptr);
+  if (!p && hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
+    (void)hipGetLastError();
+    p = nullptr;
+  }
+  return p;
+}
+void gf2_pinned_free(void *p, size_t bytes) {
+  if (p && !pin_pool_give(p, bytes, nullptr, 0, 0)) (void)hipHostFree(p);
 }
 
 // Pre-creates `count` pinned blocks of the size an r x c matrix takes and puts them into the pool: the first mzd_init /
@@ -122,9 +174,12 @@ extern "C" int gf2_mzd_prewarm(rci_t r, rci_t c, int count) {
       (void)hipGetLastError();
       break;
     }
-    std::lock_guard<std::mutex> lk(g_pin_mu);
-    g_pin_free.emplace(bytes, p);
-    g_pin_cached += bytes;
+    word **rows = make_rows(static_cast<word *>(p), r, rowstride);  // the block arrives with its row pointers
+    if (!pin_pool_give(p, bytes, rows, r, rowstride)) {
+      std::free(rows);
+      (void)hipHostFree(p);
+      break;
+    }
     ++added;
   }
   return added;
@@ -173,16 +228,18 @@ static mzd_t *mzd_init_impl(rci_t r, rci_t c, bool zero) {
     } else {
       blocks = static_cast<mzd_block_t *>(std::calloc(2, sizeof(mzd_block_t)));  // [1] = terminator
       if (!blocks) gf2_die("out of memory");
-      blocks[0].begin = static_cast<word *>(block_alloc(bytes, &kind, zero));
-      A->rows = static_cast<word **>(std::malloc(((size_t)r + 1) * sizeof(word *)));
-      if (!A->rows) gf2_die("out of memory");
+      word **pooled_rows = nullptr;
+      blocks[0].begin = static_cast<word *>(block_alloc(bytes, &kind, zero, r, rowstride, &pooled_rows));
+      A->rows = pooled_rows ? pooled_rows : make_rows(blocks[0].begin, r, rowstride);
     }
     blocks[0].size = bytes;
     blocks[0].end = blocks[0].begin + (size_t)r * A->rowstride;
     A->padding[0] = kind;
     A->blocks = blocks;
-    for (rci_t i = 0; i < r; ++i) A->rows[i] = blocks[0].begin + (size_t)i * A->rowstride;
-    A->rows[r] = nullptr;
+    if (inl) {
+      for (rci_t i = 0; i < r; ++i) A->rows[i] = blocks[0].begin + (size_t)i * A->rowstride;
+      A->rows[r] = nullptr;
+    }
   }
   return A;
 }
@@ -201,10 +258,11 @@ extern "C" void mzd_free(mzd_t *A) {
     std::free(A);
     return;
   }
-  std::free(A->rows);
   if (owns_blocks(A)) {
-    block_free(A->blocks[0].begin, A->padding[0], A->blocks[0].size);
+    block_free(A->blocks[0].begin, A->padding[0], A->blocks[0].size, A->rows, A->nrows, A->rowstride);  // takes the row pointers along
     std::free(A->blocks);
+  } else {
+    std::free(A->rows);
   }
   std::free(A);
 }
@@ -326,6 +384,9 @@ static inline void transpose64(word x[64]) {
 extern "C" mzd_t *mzd_transpose(mzd_t *DST, mzd_t const *A) {
   if (DST) gf2_cache_forget(DST);  // written below: a device copy kept for it is stale
   if (DST && (DST->nrows != A->ncols || DST->ncols != A->nrows)) gf2_die("mzd_transpose: Wrong size for return matrix.");
+  // a fresh thin product carries its transposed form already (as_vector of every `&A * &v`, binary_matrix.rs:332-361)
+  if (A->ncols <= 64 && A->nrows >= 64 && DST != A)
+    if (mzd_t *D = gf2_transpose_from_side_copy(DST, A)) return D;
   // large matrices: PCIe both ways plus the device kernel is ~100x faster than the host loop below
   static const long long gpu_min_bits = [] {
     const char *e = std::getenv("M4RI_HIP_TRANSPOSE_GPU_MIN_BITS");

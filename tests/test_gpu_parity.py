@@ -1093,6 +1093,85 @@ def test_operand_cache(pkg):
         del T
 
 
+@pytest.mark.parametrize("m,n", [(1 << 20, 1), (1 << 18, 3), (300032, 1), (1 << 17, 8), (200001, 2)])
+def test_result_side_copy(pkg, m, n):
+    """A thin product into a NULL destination comes back with its packed transposed form beside it (m4ri_hip_api.cpp, ResultSide):
+    mzd_transpose of that product is served from it and must equal the transposition of the bits the product holds -- for the
+    pipelined (A uploaded in row blocks) and the plain (A cached) schedule, ragged row counts included -- and every library call
+    that writes the product (mzd_add, mzd_row_swap, a product through a window of it, mzd_copy into it) drops the side copy.
+    Stores through rows[] are invisible to the library: INTEGRATION.md 4d says gf2_mzd_uncache after them, checked here too."""
+    L = pkg._lib.lib()
+    l = 256
+    a, x = g.random_words(m, l, 3), g.random_words(l, n, 4)
+    A, X = pkg.BinMatrix.from_words(a, l), pkg.BinMatrix.from_words(x, n)
+    ref = g.o_mul_naive(a, x, m, l, n)
+    reft = g.o_transpose(ref, m, n)
+    for cached in (False, True):
+        if cached:
+            A.cache_on_device()
+        R = pkg.BinMatrix(L.mzd_mul_naive(None, A.mzd, X.mzd))
+        assert np.array_equal(R.to_words(), ref)
+        T = R.transposed()  # from the side copy
+        assert T.nrows() == n and T.ncols() == m and np.array_equal(T.to_words(), reft)
+        T2 = pkg.BinMatrix.zero(n, m)  # a preallocated destination as well
+        assert L.mzd_transpose(T2.mzd, R.mzd) and np.array_equal(T2.to_words(), reft)
+        # a library write to the product drops the side copy: add another matrix into it
+        y = g.random_words(m, n, 9)
+        Y = pkg.BinMatrix.from_words(y, n)
+        assert L.mzd_add(R.mzd, R.mzd, Y.mzd)
+        now = ref ^ y
+        assert np.array_equal(R.transposed().to_words(), g.o_transpose(now, m, n))
+        # a fresh product again, then a row swap
+        R = pkg.BinMatrix(L.mzd_mul_naive(None, A.mzd, X.mzd))
+        i, j = 5, m - 7
+        L.mzd_row_swap(R.mzd, i, j)
+        sw = ref.copy()
+        sw[[i, j]] = sw[[j, i]]
+        assert np.array_equal(R.transposed().to_words(), g.o_transpose(sw, m, n))
+        # a product THROUGH A WINDOW of a fresh product (rows 64.. of it overwritten)
+        R = pkg.BinMatrix(L.mzd_mul_naive(None, A.mzd, X.mzd))
+        rows_w = 4096
+        W = L.mzd_init_window(R.mzd, 64, 0, 64 + rows_w, n)
+        Aw = pkg.BinMatrix.from_words(a[1000:1000 + rows_w], l)
+        assert L.mzd_mul_naive(W, Aw.mzd, X.mzd)
+        L.mzd_free(W)
+        win = ref.copy()
+        win[64:64 + rows_w] = ref[1000:1000 + rows_w]
+        assert np.array_equal(R.transposed().to_words(), g.o_transpose(win, m, n))
+        # a store through rows[] + gf2_mzd_uncache (what INTEGRATION.md 4d asks of the caller)
+        R = pkg.BinMatrix(L.mzd_mul_naive(None, A.mzd, X.mzd))
+        view = R._words_view()
+        view[11, 0] ^= np.uint64(1)
+        L.gf2_mzd_uncache(R.mzd)
+        st = ref.copy()
+        st[11, 0] ^= np.uint64(1)
+        assert np.array_equal(R.transposed().to_words(), g.o_transpose(st, m, n))
+    A.uncache()
+    # the reference's operator end to end (binary_matrix.rs:528-542) on the first column
+    if n == 1:
+        v = pkg.BinVector(g.random_words(1, l, 4)[0], l)
+        xv = g.o_transpose(g.random_words(1, l, 4), 1, l)
+        got = A * v
+        want = g.o_transpose(g.o_mul_naive(a, xv, m, l, 1), m, 1)[0]
+        assert len(got) == m and np.array_equal(np.asarray(got.get_storage(), dtype=np.uint64), want)
+
+
+def test_pinned_pool_keeps_row_pointers(pkg):
+    """A pooled pinned block keeps its row-pointer array (mzd_host.cpp): the next matrix of the same shape takes both, a matrix of
+    another shape with the same byte count gets a fresh array -- rows[i] must be right either way."""
+    L = pkg._lib.lib()
+    import ctypes
+    for (r, c) in [(1 << 18, 1), (1 << 17, 100), (1 << 18, 64), (1 << 16, 256), (1 << 18, 1)]:
+        M = L.mzd_init(r, c)
+        mz = M.contents
+        stride = mz.rowstride
+        base = ctypes.cast(mz.rows[0], ctypes.c_void_p).value
+        for i in (0, 1, r // 2, r - 1):
+            assert ctypes.cast(mz.rows[i], ctypes.c_void_p).value == base + 8 * stride * i, (r, c, i)
+        assert not mz.rows[r]
+        L.mzd_free(M)
+
+
 def test_random_shape_fuzz(pkg):
     """tools/fuzz_shapes.py: log-uniform random shapes (incl. tall-skinny ones) through three algorithms and the
     elimination, all against the oracle."""

@@ -27,6 +27,9 @@ DESCRIPTIONS = {
     "M4RI_HIP_HOST_PIPELINE_BLOCKS": "row blocks of the host upload / multiply / download pipeline (default 4; < 2 switches it off)",
     "M4RI_HIP_APACK": "0: Strassen leaves of A stay row-major (no row-group-packed layout)",
     "M4RI_HIP_PLAIN_APACK": "0: plain products never pack A first",
+    "M4RI_HIP_RESULT_SIDE_COLS": "a product into a NULL destination with at most this many columns (default 8) and >= 1 MiB of rows also comes back in its packed transposed form, from which mzd_transpose of that product is served (INTEGRATION 4b, 4d); 0 = never",
+    "M4RI_HIP_ELIM_LOOKAHEAD": "0: the pivot search of an elimination step runs as its own launch instead of on an extra workgroup of the previous step's update launch (DESIGN 7.1)",
+    "M4RI_HIP_ELIM_SPECULATE": "0: the trailing product of an elimination block waits for the block's record instead of being enqueued ahead of it",
     "M4RI_HIP_M4RM_CFG": "force one tile-kernel variant (7, 8, 9-12, 20, 81, 82) for A/B runs; anything else is ignored with a message",
 }
 
@@ -66,7 +69,28 @@ def knobs():
     return found
 
 
+def render():
+    import io
+    import contextlib
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        _print_table()
+    return buf.getvalue()
+
+
 def main():
+    if "--write" in sys.argv:  # splice the table into INTEGRATION.md between its markers
+        path = os.path.join(ROOT, "INTEGRATION.md")
+        doc = open(path).read()
+        a = doc.index("<!-- knob table: begin")
+        a = doc.index("\n", a) + 1
+        b = doc.index("<!-- knob table: end")
+        open(path, "w").write(doc[:a] + render() + doc[b:])
+        return
+    _print_table()
+
+
+def _print_table():
     k = knobs()
     for dev in (False, True):
         print("**%s**\n" % ("Read by the shipped library (`libm4ri_hip.so`)" if not dev else

@@ -3,6 +3,7 @@
 import csv, glob, sys
 d = sys.argv[1]
 span = float(sys.argv[2]) if len(sys.argv) > 2 else 12.0
+min_ns = float(sys.argv[3]) if len(sys.argv) > 3 else 20000.0  # shortest event shown
 ev = []
 for f in glob.glob(d + "/*/*kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
@@ -14,5 +15,5 @@ ev.sort()
 end = max(e[1] for e in ev)
 t0 = end - span * 1e6
 for s, e, nm in ev:
-    if e >= t0 and (e - s) > 20000:
+    if e >= t0 and (e - s) > min_ns:
         print("%8.3f -> %8.3f ms (%7.3f)  %s" % ((s - t0) / 1e6, (e - t0) / 1e6, (e - s) / 1e6, nm))
