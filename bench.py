@@ -27,6 +27,7 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
 HBM_PEAK_GBS = 8000.0      # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s is the measured copy rate
 HBM_COPY_GBS = 6290.0
 LDS_PEAK_TBS = 150.0       # aggregate ds_read_b128 rate, all CUs (MI355X_MICROARCH.md, LDS)
+LDS_BYTES_PER_CLK = 256 * 256  # 256 B per clock and CU (64 dwords wide), 256 CUs (MI355X_MICROARCH.md, LDS)
 
 
 def _cpu_model():
@@ -609,6 +610,21 @@ def main():
                                  "command in a builder run, %s); not measured in this run" % tj.get("source", "see profiles/INDEX.md")
         except Exception:
             traffic = None
+    # the clock the chip holds under the tile kernel: measured with in-kernel stamps in a development build
+    # (tools/clock_probe.py), replayed here like `traffic`; the LDS delivers 256 B per clock and CU whatever the clock is
+    clock_ghz, clock_source = None, "not measured in this run (needs the development build of the kernel: tools/clock_probe.py)"
+    cfile = os.path.join(ROOT, "profiles", "clock_latest.json")
+    if os.path.exists(cfile):
+        try:
+            with open(cfile) as f:
+                cj = json.load(f)
+            key = {"half": "half", "sparse": "sparse", "ones": "ones"}[args.density]
+            if cj.get("n") == n and cj.get("clock_GHz", {}).get(key):
+                clock_ghz = float(cj["clock_GHz"][key])
+                clock_source = "replayed: profiles/clock_latest.json (%s); not measured in this run" % cj.get("method", "tools/clock_probe.py")
+        except Exception:
+            clock_ghz = None
+    lds_tbps = lds_bytes_launch / (avg_kernel_ms * 1e-3) / 1e12 if launches else 0.0
     out = {
         "metric": "gf2_matmul_bit_ops_per_sec_n%d" % n,
         "value": bitops / dt,
@@ -646,9 +662,15 @@ def main():
             "algorithmic_bytes_per_launch": alg_bytes_launch,
             "note": "this kernel is LDS-bound, not HBM-bound (see onchip); HBM fraction is small by construction",
             "onchip": {
-                "bound": "lds", "achieved": lds_bytes_launch / (avg_kernel_ms * 1e-3) / 1e12 if launches else 0.0,
+                "bound": "lds", "achieved": lds_tbps,
                 "peak": LDS_PEAK_TBS, "unit": "TB/s",
-                "frac": (lds_bytes_launch / (avg_kernel_ms * 1e-3) / 1e12 / LDS_PEAK_TBS) if launches else 0.0,
+                "frac": lds_tbps / LDS_PEAK_TBS,
+                # the same bytes against what the LDS can deliver at the clock the chip actually holds under this kernel
+                # (256 B per clock and CU x 256 CUs): random operands run at ~2.2 GHz, sparse / constant ones at ~2.37
+                "clock_GHz": clock_ghz,
+                "peak_at_measured_clock": (LDS_BYTES_PER_CLK * clock_ghz * 1e9 / 1e12) if clock_ghz else None,
+                "frac_at_measured_clock": (lds_tbps / (LDS_BYTES_PER_CLK * clock_ghz * 1e9 / 1e12)) if clock_ghz else None,
+                "clock_source": clock_source,
             },
         },
         "hbm_equiv_GBps_whole_step": 3.0 * n * n / 8.0 / (ms_per_step * 1e-3) / 1e9,

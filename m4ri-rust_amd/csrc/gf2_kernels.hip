@@ -50,6 +50,14 @@ typedef uint32_t u32;
 // library uses the default
 #ifdef GF2K_DEV_VARIANTS
 #define GF2K_DEV_ENV(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+// Which clock does the tile kernel hold?  (tools/clock_probe.py, development builds only: in the shipped kernel no stamp executes.)
+// When set, every workgroup of gf2_m4rm_kernel_v8 stores {s_memrealtime, s_memtime} at its start and {s_memtime, s_memrealtime} at its
+// end: 4 u64 per workgroup, the tall packed instantiation <8, *, 1> from entry 0 on, every other instantiation from entry 2^20 on.
+// clock = d(s_memtime) / d(s_memrealtime) x 100 MHz inside one workgroup (s_memtime counts per XCD; MI355X_MICROARCH.md, DVFS item 6).
+__device__ unsigned long long *gf2k_clock_stamps;
+extern "C" hipError_t gf2k_dev_set_clock_stamps(unsigned long long *p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(gf2k_clock_stamps), &p, sizeof(p));
+}
 #else
 #define GF2K_DEV_ENV(name, dflt) (dflt)
 #endif
@@ -866,6 +874,9 @@ __global__ __launch_bounds__(512) void gf2_m4rm_kernel_v8(const gf2k_mul_args p)
   }
   const int nparts = rest > 0 ? 2 : 1;
 #ifdef GF2K_DEV_VARIANTS
+  unsigned long long *const clk_stamps = gf2k_clock_stamps;
+  unsigned long long clk_rt0 = 0, clk_c0 = 0;
+  if (clk_stamps) clk_rt0 = __builtin_amdgcn_s_memrealtime(), clk_c0 = __builtin_amdgcn_s_memtime();
   if ((p.kwords & 1) && wave >= 4) __builtin_amdgcn_s_setprio(1);  // static priority for the later-dispatched half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
   if ((p.kwords & 2) && wave < 4) __builtin_amdgcn_s_setprio(1);
 #endif
@@ -1128,6 +1139,13 @@ __global__ __launch_bounds__(512) void gf2_m4rm_kernel_v8(const gf2k_mul_args p)
       }
     }
   }
+#ifdef GF2K_DEV_VARIANTS
+  if (clk_stamps && tid == 0) {
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long *o = clk_stamps + ((RG == 8 && APACK == 1) ? 0 : (1 << 20)) + 4ll * (blockIdx.x & 0x3ffff);
+    o[0] = clk_rt0, o[1] = clk_c0, o[2] = c1, o[3] = rt1;
+  }
+#endif
 }
 
 // C (+)= the partial tiles of a stream-K launch (gf2_m4rm_kernel_v8): one 256-thread block per (remainder tile, 64 rows), thread =

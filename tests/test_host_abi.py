@@ -32,6 +32,8 @@ def test_header_symbols_are_exported(pkg):
     exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
     assert declared <= exported, sorted(declared - exported)
     assert declared == set(pkg._lib.DECLARED_SYMBOLS), sorted(declared ^ set(pkg._lib.DECLARED_SYMBOLS))
+    # development hooks (in-kernel clock stamps, tools/clock_probe.py) exist in tools/libm4ri_hip_dev.so only
+    assert not any("dev_set" in e or "clock_stamps" in e for e in exported)
 
 
 def test_header_compiles_as_c_and_struct_is_64_bytes(tmp_path):
