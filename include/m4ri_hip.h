@@ -270,6 +270,12 @@ void gf2_prof_enable(int on);
 /* sums since the last reset: *launches, *ms = total event-measured duration of those launches */
 int gf2_prof_read(int *launches, double *ms, int reset);
 
+/* Launch census: "<count> <mangled kernel name>\n" for every kernel of the library this process has launched so far, written to buf
+ * (at most cap - 1 bytes and a terminator); returns the length of the whole text.  With M4RI_HIP_KERNEL_CENSUS_FILE=<path> in the
+ * environment the counts are also appended to that file when the library is unloaded (child processes of a test suite).  The GPU
+ * suite ends with a test that every kernel the shared object contains has been launched (tests/test_zz_kernel_census.py). */
+size_t gf2_kernel_census(char *buf, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

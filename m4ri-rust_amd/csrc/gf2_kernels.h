@@ -123,3 +123,14 @@ hipError_t gf2k_strassen_merge2(uint64_t *dst, long long ldd, long long dstStrid
 hipError_t gf2k_strassen_merge(uint64_t *dst, long long ldd, long long dstStride, const uint64_t *src, long long lds_,
                                long long srcStride, int h, int w, int accumulate, int batch, hipStream_t stream);
 }
+
+// Launch census (include/m4ri_hip.h, gf2_kernel_census): every kernel launch of the library goes through this macro, which counts
+// it by the kernel's host-side handle before handing it to HIP's own form.  tests/test_zz_kernel_census.py compares the kernels that
+// were LAUNCHED by the GPU suite with the kernels the shared object CONTAINS (round 4: a kernel nobody launched ran wrong for half a round).
+void gf2k_note_launch(const void *kernel);
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, ...)                        \
+  do {                                                             \
+    gf2k_note_launch(reinterpret_cast<const void *>(kernelName));  \
+    hipLaunchKernelGGLInternal((kernelName), __VA_ARGS__);         \
+  } while (0)

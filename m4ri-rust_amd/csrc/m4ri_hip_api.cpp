@@ -18,6 +18,7 @@
 #include <map>
 #include <memory>
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <thread>
 #include <string>
@@ -71,6 +72,74 @@ static int require_device() {
   if (gf2_device_count() <= 0)
     return fail_msg("no usable HIP device: libm4ri_hip has no CPU fallback for the multiply path");
   return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch census: how often each kernel of the library has been launched by this process
+// ---------------------------------------------------------------------------------------------
+
+namespace {
+// open-addressing table keyed by the kernel's host-side handle; lock-free (a launch pays a hash and one atomic increment)
+struct CensusSlot {
+  std::atomic<const void *> key{nullptr};
+  std::atomic<unsigned long long> count{0};
+};
+constexpr unsigned kCensusSlots = 1024;  // the library has ~130 kernels
+CensusSlot g_census[kCensusSlots];
+
+std::string census_text() {
+  std::string out;
+  for (unsigned i = 0; i < kCensusSlots; ++i) {
+    const void *k = g_census[i].key.load(std::memory_order_acquire);
+    if (!k) continue;
+    const char *nm = hipKernelNameRefByPtr(k, nullptr);
+    out += std::to_string(g_census[i].count.load(std::memory_order_relaxed));
+    out += ' ';
+    out += nm ? nm : "?";
+    out += '\n';
+  }
+  return out;
+}
+
+// M4RI_HIP_KERNEL_CENSUS_FILE=<path>: the counts of this process are APPENDED to the file when the library is unloaded (test suites
+// that launch kernels from child processes: tests/conftest.py sets it for the whole session)
+struct CensusDump {
+  ~CensusDump() {
+    const char *path = std::getenv("M4RI_HIP_KERNEL_CENSUS_FILE");
+    if (!path || !*path) return;
+    const std::string t = census_text();
+    if (t.empty()) return;
+    if (FILE *f = std::fopen(path, "a")) {
+      std::fwrite(t.data(), 1, t.size(), f);
+      std::fclose(f);
+    }
+  }
+} g_census_dump;
+}  // namespace
+
+void gf2k_note_launch(const void *kernel) {
+  unsigned i = (unsigned)((reinterpret_cast<uintptr_t>(kernel) >> 3) * 2654435761u) % kCensusSlots;
+  for (unsigned probe = 0; probe < kCensusSlots; ++probe, i = (i + 1) % kCensusSlots) {
+    const void *k = g_census[i].key.load(std::memory_order_acquire);
+    if (k == kernel) break;
+    if (!k) {
+      const void *expect = nullptr;
+      if (g_census[i].key.compare_exchange_strong(expect, kernel, std::memory_order_acq_rel) || expect == kernel) break;
+    }
+  }
+  g_census[i].count.fetch_add(1, std::memory_order_relaxed);
+}
+
+// "<count> <mangled kernel name>\n" for every kernel launched so far; returns the length of the whole text (without the
+// terminator), of which at most cap - 1 bytes are written to buf
+extern "C" size_t gf2_kernel_census(char *buf, size_t cap) {
+  const std::string t = census_text();
+  if (buf && cap) {
+    const size_t n = t.size() < cap - 1 ? t.size() : cap - 1;
+    std::memcpy(buf, t.data(), n);
+    buf[n] = 0;
+  }
+  return t.size();
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -30,6 +30,7 @@ DESCRIPTIONS = {
     "M4RI_HIP_RESULT_SIDE_COLS": "a product into a NULL destination with at most this many columns (default 8) and >= 1 MiB of rows also comes back in its packed transposed form, from which mzd_transpose of that product is served (INTEGRATION 4b, 4d); 0 = never",
     "M4RI_HIP_ELIM_LOOKAHEAD": "0: the pivot search of an elimination step runs as its own launch instead of on an extra workgroup of the previous step's update launch (DESIGN 7.1)",
     "M4RI_HIP_ELIM_SPECULATE": "0: the trailing product of an elimination block waits for the block's record instead of being enqueued ahead of it",
+    "M4RI_HIP_KERNEL_CENSUS_FILE": "path: the launch counts of the process (gf2_kernel_census) are appended to this file when the library is unloaded; the GPU test suite sets it so that kernels launched by its child processes count (tests/test_zz_kernel_census.py)",
     "M4RI_HIP_M4RM_CFG": "force one tile-kernel variant (7, 8, 9-12, 20, 81, 82) for A/B runs; anything else is ignored with a message",
 }
 
