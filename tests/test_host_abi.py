@@ -545,3 +545,61 @@ def test_no_cross_lane_swaps_in_inline_asm():
             text = open(os.path.join(src, fn)).read()
             for m in re.finditer(r'asm\s*(?:volatile)?\s*\(\s*"([^"]*)"', text):
                 assert "permlane" not in m.group(1), (fn, m.group(1))
+
+
+def _hazard_tool():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("asm_hazards", os.path.join(ROOT, "tools", "asm_hazards.py"))
+    ah = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ah)
+    return ah
+
+
+def test_hazard_checker_sees_known_bad_and_known_good_sequences():
+    """tools/asm_hazards.py on hand-written assembly: every rule fires on the unpadded pair and is quiet on the padded one -- among
+    them the exact shape of round 4's transposition bug (two v_perm_b32 writing the operands of an inline-asm v_permlane16_swap)."""
+    ah = _hazard_tool()
+
+    def findings(body):
+        text = "kern:\n" + body + "\n.Lfunc_end0:\n"
+        (name, ins), = ah.parse_functions(text).items()
+        return [f[1] for f in ah.check_function(name, ins)]
+
+    A, E = "\t;;#ASMSTART\n", "\t;;#ASMEND\n"
+    bad_swap = "\tv_perm_b32 v1, v3, v4, v5\n\tv_perm_b32 v2, v3, v4, v6\n" + A + "\tv_permlane16_swap_b32 v1, v2\n" + E
+    assert findings(bad_swap) == ["VALU write -> v_permlane*_swap operand"] * 2
+    assert not findings("\tv_perm_b32 v1, v3, v4, v5\n\tv_perm_b32 v2, v3, v4, v6\n" + A + "\ts_nop 1\n\tv_permlane16_swap_b32 v1, v2\n" + E)
+    assert findings("\tv_perm_b32 v1, v3, v4, v5\n" + A + "\ts_nop 0\n\tv_permlane32_swap_b32 v1, v2\n" + E)  # one state is not two
+    # both sides visible to the compiler: its own business (it pads what it sees)
+    assert not findings("\tv_perm_b32 v1, v3, v4, v5\n\tv_permlane16_swap_b32 v1, v2\n")
+    # M0 -> add-TID LDS write / LDS-DMA
+    assert findings(A + "\ts_mov_b32 m0, s4\n\tds_write_addtid_b32 v1 offset:256\n" + E) == ["SALU writes M0 -> add-TID LDS / LDS-DMA / s_sendmsg"]
+    assert not findings(A + "\ts_mov_b32 m0, s4\n\ts_nop 0\n\tds_write_addtid_b32 v1 offset:256\n" + E)
+    assert findings(A + "\ts_mov_b32 m0, s4\n\tglobal_load_lds_dwordx4 v[2:3], off\n" + E)
+    assert findings("\ts_mov_b32 m0, s4\n" + A + "\tbuffer_load_dword v1, s[8:11], 0 offen lds\n" + E)
+    # DPP
+    assert findings(A + "\tv_xor_b32 v1, v2, v3\n\tv_mov_b32_dpp v4, v1 row_shr:1 row_mask:0xf bank_mask:0xf\n" + E) == ["VALU write -> DPP src0"]
+    assert not findings(A + "\tv_xor_b32 v1, v2, v3\n\ts_nop 1\n\tv_mov_b32_dpp v4, v1 row_shr:1 row_mask:0xf bank_mask:0xf\n" + E)
+    assert findings(A + "\tv_cmpx_eq_u32_e32 v1, v2\n\tv_nop\n\tv_mov_b32_dpp v4, v7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n" + E) == ["VALU writes EXEC -> DPP"]
+    # readlane / readfirstlane
+    assert findings("\tv_add_u32_e32 v1, v2, v3\n" + A + "\tv_readfirstlane_b32 s4, v1\n" + E) == ["VALU write -> v_readlane / v_readfirstlane source"]
+    assert not findings("\tv_add_u32_e32 v1, v2, v3\n" + A + "\ts_nop 0\n\tv_readfirstlane_b32 s4, v1\n" + E)
+    assert findings(A + "\tv_readfirstlane_b32 s5, v9\n\ts_nop 2\n\tv_readlane_b32 s4, v1, s5\n" + E) == ["VALU writes SGPR -> lane select of v_readlane / v_writelane"]
+    # a VALU-written SGPR as a VMEM address operand
+    assert findings(A + "\tv_readfirstlane_b32 s8, v1\n\ts_nop 3\n\tbuffer_load_dword v2, v3, s[8:11], 0 offen\n" + E) == ["VALU writes SGPR -> VMEM reads it"]
+    assert not findings(A + "\tv_readfirstlane_b32 s8, v1\n\ts_nop 4\n\tbuffer_load_dword v2, v3, s[8:11], 0 offen\n" + E)
+    assert findings(A + "\tv_cmp_eq_u32_e64 s[2:3], v1, v2\n\tglobal_load_dword v4, v5, s[2:3]\n" + E)
+    # a wide store's data registers rewritten right behind it
+    assert findings(A + "\tglobal_store_dwordx4 v[10:11], v[4:7], off\n" + E + "\tv_mov_b32_e32 v5, 0\n") == ["VMEM store of > 64 bits -> VALU rewrites its data"]
+    assert not findings(A + "\tglobal_store_dwordx4 v[10:11], v[4:7], off\n\ts_nop 1\n" + E + "\tv_mov_b32_e32 v5, 0\n")
+    assert not findings(A + "\tglobal_store_dwordx2 v[10:11], v[4:5], off\n" + E + "\tv_mov_b32_e32 v5, 0\n")  # 64 bits: no hazard
+
+
+def test_no_unpadded_hazard_around_inline_asm_in_the_device_code():
+    """The audit itself: csrc/*.hip compiled to gfx950 assembly with the Makefile's flags, every hazard pair with an
+    instruction between ;;#ASMSTART and ;;#ASMEND on either side checked for its wait states.  ~45 s (hipcc -S of the two kernel files)."""
+    ah = _hazard_tool()
+    findings, stats = ah.audit()
+    assert stats["asm_instructions"] > 10000 and stats["functions"] > 100, stats  # the audit saw the library, not an empty file
+    assert stats["examined"].get("SALU writes M0 -> add-TID LDS / LDS-DMA / s_sendmsg", 0) > 1000, stats["examined"]
+    assert not findings, "\n".join("%s %s line %d: %s (%d of %d states)\n   %s\n   %s" % f for f in findings[:20])
