@@ -25,6 +25,8 @@
 // All per-step decisions live in a device-side state record, so a block is enqueued without host round trips.
 #include "gf2_kernels.h"
 
+#include <atomic>
+
 typedef uint64_t u64;
 
 __device__ __forceinline__ u64 shfl64(u64 v, int src) {
@@ -74,7 +76,7 @@ __device__ __forceinline__ T elim_ld(const T *p) {
 // basis in LDS, writes nothing to global memory), then `between()` (the look-ahead form waits there until every update workgroup
 // of the launch has finished), then PUBLISH (flags, state, pivot columns, the raw chosen rows and the selector map).
 template <bool COH, typename Between>
-__device__ __forceinline__ void elim_pivot_step(ElimPivotShared &sm, const u64 *A, long long lda, int m, long long c0w,
+__device__ __forceinline__ bool elim_pivot_step(ElimPivotShared &sm, const u64 *A, long long lda, int m, long long c0w,
                                                 int sw, int j, u64 colmask, const u64 *U, long long ldu, int uw,
                                                 gf2k_elim_state *st, int *pivcols, u64 *__restrict__ ptab, unsigned char *rowflag,
                                                 int *__restrict__ blkpiv, Between between) {
@@ -172,7 +174,7 @@ __device__ __forceinline__ void elim_pivot_step(ElimPivotShared &sm, const u64 *
   }
   __syncthreads();
   const int np = s_nb;
-  between();  // (contains workgroup barriers; everything below writes global memory)
+  if (!between()) return false;  // (contains workgroup barriers; everything below writes global memory.  false: the look-ahead wait ran out -- nothing is published)
   if (tid < st->np) rowflag[st->cur_row[tid]] = 255;  // the previous step's pivots become "pivot of this block"
   __syncthreads();
 
@@ -254,6 +256,7 @@ __device__ __forceinline__ void elim_pivot_step(ElimPivotShared &sm, const u64 *
     }
     ptab[64 * 64 + tid] = x;
   }
+  return true;
 }
 
 __global__ __launch_bounds__(1024) void gf2_elim_pivot_kernel(const u64 *__restrict__ A, long long lda, int m, long long c0w,
@@ -262,7 +265,8 @@ __global__ __launch_bounds__(1024) void gf2_elim_pivot_kernel(const u64 *__restr
                                                               u64 *__restrict__ ptab, unsigned char *rowflag,
                                                               int *__restrict__ blkpiv) {
   __shared__ ElimPivotShared sm;
-  elim_pivot_step<false>(sm, A, lda, m, c0w, sw, j, colmask, U, ldu, uw, st, pivcols, ptab, rowflag, blkpiv, [] {});
+  if (__hip_atomic_load(&st->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // an earlier launch of the chain failed: touch nothing
+  (void)elim_pivot_step<false>(sm, A, lda, m, c0w, sw, j, colmask, U, ldu, uw, st, pivcols, ptab, rowflag, blkpiv, [] { return true; });
 }
 
 // every row adds the pivot rows selected by its bits on the pivot columns; the step's own pivot rows (row flag) are
@@ -275,22 +279,34 @@ constexpr int kUpdLds = 16 * 16 * 64 * 8 + 256 * 8 + 256 * 8;  // the tables, th
 // it, whatever it did, and none of them waits for anything: they are all dispatched before or alongside this workgroup because the
 // grid fits the chip -- at most 256 update workgroups of one per CU -- so the wait ends; the bound turns a scheduling surprise
 // into an error flag instead of a hang).
-__device__ __forceinline__ void elim_wait_count(int *cnt, int want, int *err) {
+// Returns false when the bound ran out (st->err is set then): the caller must neither search on, publish nor reset the counters --
+// the update workgroups may still be running and raising them; every later launch of the chain sees err and does nothing,
+// and the host reports the failure at the end of the block.
+__device__ __forceinline__ bool elim_wait_count(int *cnt, int want, int *err) {
+  __shared__ int wait_ok;
   if (threadIdx.x == 0) {
-    int spins = 0;
+    int ok = 1, spins = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz, the same on every part and at every shader clock
     while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {  // (relaxed: an acquire here is an L2 invalidate per turn)
       __builtin_amdgcn_s_sleep(8);
-      if (++spins > (1 << 22)) {  // ~1 s
+      if ((++spins & 255) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > 100000000ull) {  // 1 s
         __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
         break;
       }
     }
+    wait_ok = ok;
   }
   __syncthreads();
   // no acquire fence here (an agent-scope fence invalidates / writes back the whole L2 of the XCD): whatever this workgroup reads
-  // of the launch's own stores it reads with agent-scope atomic loads (elim_ld<true>), and the update workgroups store those words
-  // with agent-scope atomic stores (write-through)
+  // of the launch's own stores it reads with agent-scope atomic loads (elim_ld<true>: sc1 loads, served by the memory-side of the
+  // L2 hierarchy), and the update workgroups store those words with agent-scope atomic stores (sc1: write-through) and wait for
+  // them with s_waitcnt vmcnt(0) BEFORE they raise the counter (`raise` below) -- the ordering the hand-off rests on; the 112 cases
+  // of tests/test_gpu_elim.py run it at every size against the oracle, and the fault-injection case shows the bound's way out.
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  const bool ok = wait_ok != 0;
+  __syncthreads();  // (wait_ok is rewritten by the next wait)
+  return ok;
 }
 
 // LOOK (round 4): the launch has one workgroup more than it has update workgroups.  Every update workgroup first rewrites the NEXT
@@ -299,7 +315,7 @@ __device__ __forceinline__ void elim_wait_count(int *cnt, int want, int *err) {
 // words, waits for st->cnt2 (everything updated), and PUBLISHES step j + 1 (flags, state, raw pivot rows, selector map).  A step
 // is then one launch, and the one-CU search (~12 us) runs beside the update instead of behind it.
 template <bool LOOK>
-__global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__ A, long long lda, int m, int full,
+__global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__ A, long long lda, int m, int full_and_flags,
                                                                long long c0w, int sw, int j, u64 *__restrict__ U,
                                                                long long ldu, int uw, gf2k_elim_state *st,
                                                                u64 *__restrict__ ptab, unsigned char *__restrict__ rowflag,
@@ -308,10 +324,14 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
   __shared__ ElimPivotShared sm;  // (the look-ahead workgroup's search state)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nupd = LOOK ? (int)gridDim.x - 1 : (int)gridDim.x;  // update workgroups
+  if (__hip_atomic_load(&st->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // an earlier launch of the chain failed: touch nothing
+  const int fault = full_and_flags >> 8;  // (test hook, M4RI_HIP_ELIM_FAULT: 1 = update workgroup 0 never raises its counters)
+  const int full = full_and_flags & 1;
   if (LOOK && (int)blockIdx.x == nupd) {
-    elim_wait_count(&st->cnt1, nupd, &st->err);
-    elim_pivot_step<true>(sm, A, lda, m, c0w, sw, j + 1, colmask_next, U, ldu, uw, st, pivcols, ptab, rowflag, blkpiv,
-                          [&] { elim_wait_count(&st->cnt2, nupd, &st->err); });
+    if (!elim_wait_count(&st->cnt1, nupd, &st->err)) return;
+    if (!elim_pivot_step<true>(sm, A, lda, m, c0w, sw, j + 1, colmask_next, U, ldu, uw, st, pivcols, ptab, rowflag, blkpiv,
+                               [&] { return elim_wait_count(&st->cnt2, nupd, &st->err); }))
+      return;
     __syncthreads();
     if (tid == 0) {  // every update workgroup is done: ready for the next launch
       __hip_atomic_store(&st->cnt1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -326,7 +346,7 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
   auto raise = [&](int *cnt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && !(fault == 1 && blockIdx.x == 0)) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   if (np == 0) {
     if (LOOK) raise(&st->cnt1), raise(&st->cnt2);
@@ -681,20 +701,29 @@ extern "C" hipError_t gf2k_elim_step(u64 *A, long long lda, int m, long long c0w
   if (sw + uw > 64 || j >= sw || sw * 64 > GF2K_ELIM_BLOCK_PIVOTS) return hipErrorInvalidValue;
   // dynamic LDS limits are per device: set them once per device, not per step (the call costs host time that a chain
   // of 50 us steps notices)
-  static bool attr_done[64] = {false};
+  // (concurrent host threads: the flags are atomics, setting the attribute twice is harmless; keyed by the real device ordinal)
+  constexpr int kMaxDev = 1024;
+  static std::atomic<int> cu_of[kMaxDev];  // 0 = not set up yet, else the device's compute-unit count
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-  if (!attr_done[dev & 63]) {
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return hipErrorInvalidDevice;
+  int cus = cu_of[dev].load(std::memory_order_acquire);
+  if (!cus) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gf2_elim_update_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        kUpdLds);
     if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gf2_elim_update_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kUpdLds);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (e != hipSuccess) return e;
-    attr_done[dev & 63] = true;
+    if (cus < 1) cus = 1;
+    cu_of[dev].store(cus, std::memory_order_release);
   }
-  // 8 rows per wave and pass, 16 waves per workgroup, one workgroup per CU (128 KiB of LDS tables each)
+  // 8 rows per wave and pass, 16 waves per workgroup, one workgroup per CU (128 KiB of LDS tables each).  The look-ahead form needs
+  // its WHOLE grid resident at once (the extra workgroup waits for the others): update workgroups <= CUs - 1 -- 255 on an MI355X,
+  // fewer on a partition -- and the two-launch form on a device with fewer than two CUs
+  if (lookahead && cus < 2) lookahead = 0;
+  const int cap = lookahead ? cus - 1 : cus;
   int grid = (m + 127) / 128;
-  if (grid > 255) grid = 255;  // (+ the look-ahead workgroup: the whole grid is resident at once)
+  if (grid > cap) grid = cap;
   if (grid < 1) grid = 1;
   if (!lookahead) {
     hipLaunchKernelGGL(gf2_elim_pivot_kernel, dim3(1), dim3(1024), 0, s, A, lda, m, c0w, sw, j, colmask, U, ldu, uw, st, pivcols, ptab,

@@ -1111,7 +1111,16 @@ static PlainPath plain_path(int m, int l, int n) {
   // the table kernels for 256 < l <= 1024 give a workgroup 4096 rows: below 2^19 rows they leave most of the chip idle
   // (65536 x 1000 x 64: 44 us whatever the row count, against 15-45 us through the tile kernel; tools/ab_ts_long.sh)
   static const int ts_long_min_rows = dev_env_int("M4RI_HIP_TS_LONG_MIN_ROWS", 524288);
-  if (n <= 256 && m >= (l > 256 ? ts_long_min_rows : 2048) && (n > 64 || l > 64) && l <= 1024) return kPathTallSkinny;
+#ifdef GF2K_DEV_VARIANTS
+  constexpr bool has_generation_kernel = true;
+#else
+  // the shipped gf2k_tallskinny has no kernel for n <= 64 with 256 < l <= 1024 (the slab kernel above takes those shapes under its
+  // present thresholds; gf2_tallskinny4_kernel lives in development builds only): should a retuned threshold ever let one through,
+  // it goes to the tile kernel instead of failing
+  constexpr bool has_generation_kernel = false;
+#endif
+  if (n <= 256 && m >= (l > 256 ? ts_long_min_rows : 2048) && (n > 64 || l > 64) && l <= 1024 && (has_generation_kernel || n > 64 || l <= 256))
+    return kPathTallSkinny;
   if (m <= 8) return kPathFewRows;
   if (few_rows_t_shape(m, l, n)) return kPathFewRowsT;
   return kPathTiles;
@@ -2654,7 +2663,13 @@ int echelonize_dev(gf2_dmat *A, int full, int col_limit, int *rank_out, int *piv
   HIP_TRY(hipMemsetAsync(flags.p, 0, (size_t)m, s));
 
   // the pivot search of step j + 1 inside the update launch of step j (gf2_elim.hip, round 4); 0: two launches per step as before
-  static const int lookahead = dev_env_int("M4RI_HIP_ELIM_LOOKAHEAD", 1);
+  // (both switches are read by the shipped library too: a part or a partition on which the look-ahead launch cannot be resident as
+  // a whole must be able to turn it off)
+  static const int lookahead = env_int("M4RI_HIP_ELIM_LOOKAHEAD", 1);
+  // test hook: 1 = update workgroup 0 of every look-ahead launch never raises its counters, so the look-ahead workgroup's bounded
+  // wait runs out (tests/test_gpu_elim.py::test_lookahead_failure_is_reported_not_hung)
+  static const int fault = env_int("M4RI_HIP_ELIM_FAULT", 0);
+  const int full_and_flags = (full ? 1 : 0) | (fault << 8);
   // Without augmented columns (limit == ncols) the trailing product of a block does not wait for the block's result: it is
   // enqueued with what the host knows BEFORE the block -- the rank so far = the block's first pivot row r0 -- and with the largest
   // pivot count the block can have (the tracking columns of pivots that were not found are zero, so the rows of P they meet do
@@ -2662,18 +2677,28 @@ int echelonize_dev(gf2_dmat *A, int full, int col_limit, int *rank_out, int *piv
   // device used to idle between the block's last kernel and the product's first (copy back, wake-up, a dozen launches) are gone:
   // 65536^2 59.1 -> 57.5 ms, 16384^2 8.2 -> 7.8, 4096^2 1.87 -> 1.81 (same box).  A block without pivots costs one wasted product, after which the next block
   // takes the waiting form; augmented systems (inverse, solve) keep it always: their product is cut at the last non-zero word.
-  static const int spec_on = dev_env_int("M4RI_HIP_ELIM_SPECULATE", 1);
+  static const int spec_on = env_int("M4RI_HIP_ELIM_SPECULATE", 1);
   const bool spec = spec_on && limit == ncols;
   thread_local gf2k_elim_state *hpin = nullptr;
-  thread_local hipEvent_t hevs[16] = {};  // one per device: an event belongs to the device that was current when it was created
+  thread_local std::map<int, hipEvent_t> hevs;  // one per device ORDINAL: an event belongs to the device that was current when it was created
   hipEvent_t hev = nullptr;
   if (spec) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (!hpin) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&hpin), sizeof(gf2k_elim_state), hipHostMallocPortable));
-    if (!hevs[dev & 15]) HIP_TRY(hipEventCreateWithFlags(&hevs[dev & 15], hipEventDisableTiming));
-    hev = hevs[dev & 15];
+    hipEvent_t &slot = hevs[dev];
+    if (!slot) HIP_TRY(hipEventCreateWithFlags(&slot, hipEventDisableTiming));
+    hev = slot;
   }
+  // Whatever way this function is left, the stream has drained before the scratch buffers above are handed back to the pool: an
+  // error return behind an enqueued trailing product must not free U / P / tmp under it.  Declared after the buffers,
+  // so destroyed before them.
+  struct DrainOnExit {
+    hipStream_t s;
+    ~DrainOnExit() {
+      if (hipStreamSynchronize(s) != hipSuccess) (void)hipGetLastError();
+    }
+  } drain{s};
   bool prev_empty = false;
   int r_cur = 0;
   for (long long c0w = 0; c0w < lw && r_cur < m; c0w += KBW) {
@@ -2686,7 +2711,7 @@ int echelonize_dev(gf2_dmat *A, int full, int col_limit, int *rank_out, int *piv
       const u64 colmask = last ? ((1ull << (limit & 63)) - 1) : ~0ull;
       const bool last_next = (c0w + j + 1 == lw - 1) && (limit & 63);
       const u64 colmask_next = last_next ? ((1ull << (limit & 63)) - 1) : ~0ull;
-      HIP_TRY(gf2k_elim_step(A->data, lda, m, c0w, sw, j, colmask, full, U.as<u64>(), uw, uw, dst, pv.as<int>(),
+      HIP_TRY(gf2k_elim_step(A->data, lda, m, c0w, sw, j, colmask, full_and_flags, U.as<u64>(), uw, uw, dst, pv.as<int>(),
                              ptab.as<u64>(), flags.as<unsigned char>(), blkpiv.as<int>(), colmask_next, lookahead, s));
     }
     HIP_TRY(gf2k_elim_end_block(A->data, lda, aw, c0w, U.as<u64>(), uw, uw, dst, flags.as<unsigned char>(), blkpiv.as<int>(),

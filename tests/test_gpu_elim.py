@@ -436,3 +436,65 @@ def test_invert_naive(pkg, monkeypatch, small_work):
         low = g.o_mul_naive(g.random_words(n, n - 1, 70 + n), g.random_words(n - 1, n, 71 + n), n, n - 1, n)
         assert g.o_inverse(low, n) is None
         assert not L.mzd_invert_naive(None, pkg.BinMatrix.from_words(low, n).mzd, None)
+
+
+_FAULT_SCRIPT = r"""
+import sys, time
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import numpy as np
+import m4ri_rust_amd as pkg
+from m4ri_rust_amd import device, _lib
+n = 4096
+M = device.DMat.random(n, n, 5)
+t0 = time.time()
+try:
+    device.echelonize(M, full=True)
+except _lib.HipError as e:
+    print("FAILED-AS-DOCUMENTED %%.1f s: %%s" %% (time.time() - t0, e))
+    # the library is usable afterwards: a product on the same stream still matches the oracle
+    import gf2util as g
+    a, b = g.random_words(300, 200, 1), g.random_words(200, 100, 2)
+    c = device.mul(device.DMat.from_words(a, 200), device.DMat.from_words(b, 100)).to_words()
+    assert np.array_equal(c, g.o_mul_m4rm(a, b, 300, 200, 100))
+    print("STILL-USABLE")
+    sys.exit(0)
+print("NO-ERROR after %%.1f s" %% (time.time() - t0))
+sys.exit(3)
+"""
+
+
+def test_lookahead_failure_is_reported_not_hung(pkg):
+    """The in-launch look-ahead (gf2_elim.hip) has one workgroup wait for counters the update workgroups of the SAME launch raise.  If
+    they never arrive -- M4RI_HIP_ELIM_FAULT=1 makes update workgroup 0 skip its raises -- the wait is bounded (1 s of s_memrealtime),
+    the look-ahead workgroup leaves WITHOUT searching on, publishing or resetting the counters, every later launch of the chain sees
+    the error flag and touches nothing, and the host reports the failure: an error return, not a hang and not a corrupted matrix
+    handed back as a result.  In a child process: the library reads the hook once."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, M4RI_HIP_ELIM_FAULT="1")
+    r = subprocess.run([sys.executable, "-c", _FAULT_SCRIPT % {"root": root}], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "FAILED-AS-DOCUMENTED" in r.stdout and "look-ahead" in r.stdout and "STILL-USABLE" in r.stdout, r.stdout
+
+
+@pytest.mark.parametrize("knobs", [{"M4RI_HIP_ELIM_LOOKAHEAD": "0"}, {"M4RI_HIP_ELIM_SPECULATE": "0"},
+                                   {"M4RI_HIP_ELIM_LOOKAHEAD": "0", "M4RI_HIP_ELIM_SPECULATE": "0"}],
+                         ids=["two-launch steps", "waiting products", "both"])
+def test_elimination_switches_of_the_shipped_library(pkg, knobs):
+    """M4RI_HIP_ELIM_LOOKAHEAD=0 / M4RI_HIP_ELIM_SPECULATE=0 are read by the shipped library (a part on which the look-ahead launch
+    cannot be resident as a whole must be able to turn it off): same reduced echelon form either way, checked in a child process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')\n"
+              "import numpy as np, gf2util as g, m4ri_rust_amd as pkg\n"
+              "for (m, n, r) in ((3000, 2500, 1800), (5000, 4200, 4200), (2048, 4096, 2048)):\n"
+              "    a = g.o_mul_naive(g.random_words(m, r, 7), g.random_words(r, n, 8), m, r, n)\n"
+              "    M = pkg.BinMatrix.from_words(a, n)\n"
+              "    rank = M.echelonize(full=True)\n"
+              "    ref, orank, _ = g.o_echelonize(a, m, n, full=True)\n"
+              "    assert rank == orank and np.array_equal(M.to_words(), ref), (m, n, r)\n"
+              "print('OK')\n") % (root, root)
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=dict(os.environ, **knobs), timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]

@@ -1202,9 +1202,10 @@ def test_lpn_kernels_every_instantiation(dev, m, mode, n):
 @pytest.mark.parametrize("m,l,n", [(524288, 300, 40), (524365, 1000, 64), (524288, 512, 100), (524300, 1024, 200), (524288, 700, 256),
                                    (600000, 257, 65), (530000, 999, 129)])
 def test_table_kernels_long_inner_dimension_many_rows(dev, m, l, n):
-    """256 < l <= 1024 with at least 2^19 rows: the table kernels that hold all of B's tables in LDS in generations
-    (gf2_tallskinny4_kernel for n <= 64, gf2_tallskinny3_kernel beyond); below 2^19 rows those shapes take the tile kernel, so the
-    suite never reached them after the threshold moved (tools/kernel_coverage.py)."""
+    """256 < l <= 1024 with at least 2^19 rows: gf2_tallskinny3_kernel (all of B's tables in LDS, 16- and 32-byte entries) for more
+    than 64 columns, the slab table kernel (gf2_tallskinny7_kernel) for up to 64 -- the shipped library no longer carries the
+    generation kernel gf2_tallskinny4_kernel those used to take; below 2^19 rows these shapes take the tile kernel, so the suite
+    never reached them after the threshold moved (tools/kernel_coverage.py)."""
     a, b = g.random_words(m, l, 50 + n), g.random_words(l, n, 51 + n)
     ref = g.o_mul_m4rm(a, b, m, l, n)
     A, B = dev.DMat.from_words(a, l), dev.DMat.from_words(b, n)

@@ -31,6 +31,7 @@ DESCRIPTIONS = {
     "M4RI_HIP_ELIM_LOOKAHEAD": "0: the pivot search of an elimination step runs as its own launch instead of on an extra workgroup of the previous step's update launch (DESIGN 7.1)",
     "M4RI_HIP_ELIM_SPECULATE": "0: the trailing product of an elimination block waits for the block's record instead of being enqueued ahead of it",
     "M4RI_HIP_KERNEL_CENSUS_FILE": "path: the launch counts of the process (gf2_kernel_census) are appended to this file when the library is unloaded; the GPU test suite sets it so that kernels launched by its child processes count (tests/test_zz_kernel_census.py)",
+    "M4RI_HIP_ELIM_FAULT": "test hook: 1 = update workgroup 0 of every look-ahead launch never raises its counters, so that the look-ahead workgroup's bounded wait runs out and the elimination reports the failure (tests/test_gpu_elim.py::test_lookahead_failure_is_reported_not_hung)",
     "M4RI_HIP_M4RM_CFG": "force one tile-kernel variant (7, 8, 9-12, 20, 81, 82) for A/B runs; anything else is ignored with a message",
 }
 
