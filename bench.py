@@ -335,16 +335,16 @@ def _elimination(device, torch, sizes=(4096, 65536)):
     return out
 
 
-def _sharded_self_check(device, sharded, torch, Bp, Cfull_t, n, world, stream):
-    """Cheap default check of a multi-GPU step (rank 0): eight consecutive rows out of every rank's row block (at least 32
-    rows in all, offsets from a fixed seed) are re-multiplied by rank 0 alone from the seeded generator and compared with the
-    rows of C the ranks produced and RCCL gathered."""
+def _sharded_self_check(device, sharded, torch, Bp, Cfull_t, n, nblocks, stream):
+    """Cheap default check of a multi-GPU step (rank 0): eight consecutive rows out of every ROW BLOCK of the grid (at least 32
+    rows in all, offsets from a fixed seed) are re-multiplied by rank 0 alone from the seeded generator, against every (sub-)panel
+    of B, and compared with the rows of C the ranks produced and RCCL gathered -- so every rank's block of C is sampled."""
     import random
     rng = random.Random(20261004)
-    rows = n // world
-    grp = max(8, -(-32 // world))
-    starts = [r * rows + rng.randrange(0, rows - grp + 1) for r in range(world)]
-    As_t = torch.empty((grp * world, n // 64), dtype=torch.int64, device="cuda")
+    rows = n // nblocks
+    grp = max(8, -(-32 // nblocks))
+    starts = [r * rows + rng.randrange(0, rows - grp + 1) for r in range(nblocks)]
+    As_t = torch.empty((grp * nblocks, n // 64), dtype=torch.int64, device="cuda")
     for k, r0 in enumerate(starts):
         sharded.fill_row_block(device.DMat.from_torch(As_t[k * grp:(k + 1) * grp], n), seed=1, row0=r0, stream=stream)
     idx = torch.tensor([r0 + j for r0 in starts for j in range(grp)], device="cuda")
@@ -355,7 +355,7 @@ def _sharded_self_check(device, sharded, torch, Bp, Cfull_t, n, world, stream):
         ref = device.mul(As, Bp[pnl], algo="m4rm", stream=stream).to_words(stream)
         got = Cfull_t[pnl][idx].cpu().numpy().view(np.uint64)
         ok = ok and bool(np.array_equal(got, ref))
-    return {"rows_checked": int(idx.numel()), "row_starts": starts, "ok": bool(ok)}
+    return {"rows_checked": int(idx.numel()), "panels_checked": len(Bp), "row_starts": starts, "ok": bool(ok)}
 
 
 def main():
@@ -374,6 +374,10 @@ def main():
                     help="column panels of B per step when N > 1 (RCCL/compute overlap); 0 = 2 panels on 2 GPUs, 4 above "
                          "(measured per-rank products: thin panels cost Strassen efficiency, 32768x65536x32768 takes 13.0 ms "
                          "but 4 x 32768x65536x16384 take 31 ms; from 4 GPUs on the transfer is the longer leg)")
+    ap.add_argument("--grid", default=None,
+                    help="N > 1: RxQ grid of ranks (R * Q = N): rank i * Q + j keeps row block i of A (n / R rows) and receives only column "
+                         "panel j of B (n / Q columns); Nx1 is the plain row-block scheme.  Unset: every factorisation is a tuning candidate "
+                         "(priors from one-GPU timings of the per-rank shapes at n = 65536, N = 8: 8x1 4.65 ms, 4x2 4.18, 2x4 4.00 per rank)")
     ap.add_argument("--bcast", default=None, choices=["broadcast", "allgather"],
                     help="how a panel of B reaches the ranks: one broadcast, or scatter from rank 0 + all-gather; left unset together "
                          "with --panels 0 the run times three untimed steps of every candidate first and keeps the fastest")
@@ -421,8 +425,14 @@ def main():
 
     n = args.n
     assert n % (64 * world) == 0
-    rows = n // world
     ldw = n // 64
+
+    def parse_grid(text):
+        r_, q_ = (int(x) for x in text.lower().split("x"))
+        assert r_ >= 1 and q_ >= 1 and r_ * q_ == world, "--grid %s does not cover %d ranks" % (text, world)
+        return r_, q_
+    R, Q = parse_grid(args.grid) if (args.grid and world > 1) else (world, 1)
+    rows = n // R
     # all work (kernels and RCCL collectives) is issued under one explicit torch stream: torch orders its
     # collectives against the current stream, and the library launches on the very same hipStream_t
     comp = torch.cuda.Stream()
@@ -432,57 +442,94 @@ def main():
     # resident operands (torch owns the memory; the library sees raw device pointers).
     # synthetic data: seeded splitmix64 bits (same stream as the oracle generator); rank r holds rows
     # [r*rows, (r+1)*rows) of the global A (seed 1), B has seed 2.
-    A_t = torch.empty((rows, ldw), dtype=torch.int64, device="cuda")
-    A = device.DMat.from_torch(A_t, n)
-    sharded.fill_row_block(A, seed=1, row0=rank * rows, stream=stream)
-    def make_panels(P_):
-        """B and C as P_ column panels ("tiles"), each contiguous, so that a panel can be broadcast / gathered by RCCL while the
-        previous one is being multiplied; B's panels filled on rank 0."""
-        wp_, ncp_ = ldw // P_, n // P_
-        Bp_t_ = [torch.empty((n, wp_), dtype=torch.int64, device="cuda") for _ in range(P_)]
-        Cp_t_ = [torch.empty((rows, wp_), dtype=torch.int64, device="cuda") for _ in range(P_)]
-        Bp_ = [device.DMat.from_torch(t, ncp_) for t in Bp_t_]
-        Cp_ = [device.DMat.from_torch(t, ncp_) for t in Cp_t_]
-        Cfull_t_ = [torch.empty((n, wp_), dtype=torch.int64, device="cuda") for _ in range(P_)] if rank == 0 else None
+    def make_a(R_, Q_):
+        """Row block i = rank // Q_ of the seeded global A (n / R_ rows)."""
+        rows_ = n // R_
+        a_t = torch.empty((rows_, ldw), dtype=torch.int64, device="cuda")
+        a = device.DMat.from_torch(a_t, n)
+        sharded.fill_row_block(a, seed=1, row0=(rank // Q_) * rows_, stream=stream)
+        return a_t, a
+
+    grids = {}
+
+    def grid_of(R_, Q_):
+        """The process groups of an R_ x Q_ grid (created once, by every rank, in the same order)."""
+        if (R_, Q_) not in grids:
+            grids[(R_, Q_)] = sharded.Grid(R_, Q_)
+        return grids[(R_, Q_)]
+
+    def make_panels(R_, Q_, P_):
+        """Buffers of an R_ x Q_ grid with P_ sub-panels per column panel ("tiles" of B, each contiguous, so that one can travel by RCCL
+        while the previous one is being multiplied): this rank's sub-panels of ITS column panel of B and of its block of C; on rank 0
+        also all of B (b_src[j][p], filled from the seeded generator) and all of C (Cfull[j][p])."""
+        rows_, ws_, ncs_ = n // R_, ldw // (Q_ * P_), n // (Q_ * P_)
+        b_src_ = None
         if rank == 0:
-            for pnl in range(P_):
-                sharded.fill_block(Bp_[pnl], 2, 0, pnl * wp_, n, stream)
-        return Bp_t_, Cp_t_, Bp_, Cp_, Cfull_t_
+            b_src_ = [[torch.empty((n, ws_), dtype=torch.int64, device="cuda") for _ in range(P_)] for _ in range(Q_)]
+            for j_ in range(Q_):
+                for p_ in range(P_):
+                    sharded.fill_block(device.DMat.from_torch(b_src_[j_][p_], ncs_), 2, 0, (j_ * P_ + p_) * ws_, n, stream)
+        Bp_t_ = b_src_[0] if rank == 0 else [torch.empty((n, ws_), dtype=torch.int64, device="cuda") for _ in range(P_)]
+        Cp_t_ = [torch.empty((rows_, ws_), dtype=torch.int64, device="cuda") for _ in range(P_)]
+        Bp_ = [device.DMat.from_torch(t, ncs_) for t in Bp_t_]
+        Cp_ = [device.DMat.from_torch(t, ncs_) for t in Cp_t_]
+        Cfull_t_ = [[torch.empty((n, ws_), dtype=torch.int64, device="cuda") for _ in range(P_)] for _ in range(Q_)] if rank == 0 else None
+        return b_src_, Bp_t_, Cp_t_, Bp_, Cp_, Cfull_t_
+
+    def panel_ok(Q_, P_):
+        return ldw % (2 * Q_ * P_) == 0 and (n // (Q_ * P_)) % 128 == 0
+
+    A_t, A = make_a(R, Q)
 
     panel_tuning = None
-    if world > 1 and args.panels <= 0 and args.bcast is None:
+    if world > 1 and (args.panels <= 0 or args.grid is None) and args.bcast is None:
         # No multi-GPU run of this repository exists yet, so the first one tunes itself: three untimed steps of every candidate
-        # (panel count x how a panel travels), barrier + synchronize around them, the slowest rank's time decides on every rank
-        # alike.  Priors from one-GPU timings of the per-rank panel shapes: DESIGN.md section 6.
+        # (grid of ranks x sub-panels per column panel x how a panel travels), barrier + synchronize around them, the slowest rank's
+        # time decides on every rank alike.  Priors from one-GPU timings of the per-rank shapes: DESIGN.md section 6.
         panel_tuning = []
-        for P_ in (1, 2, 4):
-            if ldw % (2 * P_) or (n // P_) % 128:
-                continue
-            bufs = make_panels(P_)
-            for mode in ("broadcast", "allgather"):
-                if mode == "allgather" and n % world:
+        grid_cands = [(R, Q)] if args.grid else [(world // q_, q_) for q_ in (1, 2, 4, 8) if world % q_ == 0 and n % (64 * (world // q_)) == 0]
+        panel_cands = (args.panels,) if args.panels > 0 else (1, 2, 4)
+        for (R_, Q_) in grid_cands:
+            g_ = grid_of(R_, Q_)
+            a_t_, a_ = (A_t, A) if (R_, Q_) == (R, Q) else make_a(R_, Q_)
+            for P_ in panel_cands:
+                if not panel_ok(Q_, P_) or (Q_ > 1 and Q_ * P_ > 8):
                     continue
-                for it in range(4):  # the first one untimed (arenas, communicators)
-                    if it == 1:
-                        torch.cuda.synchronize()
-                        dist.barrier()
-                        t0_ = time.perf_counter()
-                    sharded.step_pipelined(A, bufs[0], bufs[1], bufs[4], bufs[2], bufs[3], algo=args.algo, levels=args.levels,
-                                           stream=stream, bcast=mode)
-                torch.cuda.synchronize()
-                dist.barrier()
-                tm = torch.tensor([(time.perf_counter() - t0_) / 3.0], dtype=torch.float64, device="cuda")
-                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-                panel_tuning.append({"panels": P_, "bcast": mode, "ms_per_step": float(tm.item()) * 1e3})
-            del bufs
-            torch.cuda.empty_cache()
+                bufs = make_panels(R_, Q_, P_)
+                for mode in ("broadcast", "allgather"):
+                    if mode == "allgather" and n % R_:
+                        continue
+                    for it in range(4):  # the first one untimed (arenas, communicators)
+                        if it == 1:
+                            torch.cuda.synchronize()
+                            dist.barrier()
+                            t0_ = time.perf_counter()
+                        sharded.step_grid(g_, a_, bufs[0], bufs[1], bufs[2], bufs[5], bufs[3], bufs[4], algo=args.algo,
+                                          levels=args.levels, stream=stream, bcast=mode)
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    tm = torch.tensor([(time.perf_counter() - t0_) / 3.0], dtype=torch.float64, device="cuda")
+                    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                    panel_tuning.append({"grid": "%dx%d" % (R_, Q_), "panels": P_, "bcast": mode, "ms_per_step": float(tm.item()) * 1e3})
+                del bufs
+                torch.cuda.empty_cache()
+            del a_t_, a_
         bestc = min(panel_tuning, key=lambda c: c["ms_per_step"])
         args.panels, args.bcast = bestc["panels"], bestc["bcast"]
+        if parse_grid(bestc["grid"]) != (R, Q):
+            R, Q = parse_grid(bestc["grid"])
+            rows = n // R
+            del A_t, A
+            torch.cuda.empty_cache()
+            A_t, A = make_a(R, Q)
     if args.bcast is None:
         args.bcast = "broadcast"
     P = (args.panels if args.panels > 0 else (2 if world == 2 else 4)) if world > 1 else 1
-    assert ldw % (2 * P) == 0
-    wp, ncp = ldw // P, n // P
+    while world > 1 and P > 1 and not panel_ok(Q, P):
+        P //= 2
+    assert ldw % (2 * Q * P) == 0
+    wp, ncp = ldw // (Q * P), n // (Q * P)  # words / columns of one sub-panel
+    grid = grid_of(R, Q) if world > 1 else None
     if world == 1:
         B_t = torch.empty((n, ldw), dtype=torch.int64, device="cuda")
         C_t = torch.empty((rows, ldw), dtype=torch.int64, device="cuda")
@@ -503,7 +550,7 @@ def main():
                             t_.bitwise_and_(tmp_t)
                     del tmp, tmp_t
     else:
-        Bp_t, Cp_t, Bp, Cp, Cfull_t = make_panels(P)
+        b_src_t, Bp_t, Cp_t, Bp, Cp, Cfull_t = make_panels(R, Q, P)
     torch.cuda.synchronize()
 
     step_events = []  # filled during the timed steps only
@@ -511,8 +558,8 @@ def main():
     def step(record=False):
         if world > 1:
             ev = [] if record else None
-            sharded.step_pipelined(A, Bp_t, Cp_t, Cfull_t, Bp, Cp, algo=args.algo, levels=args.levels, stream=stream,
-                                   bcast=args.bcast, events=ev)
+            sharded.step_grid(grid, A, b_src_t, Bp_t, Cp_t, Cfull_t, Bp, Cp, algo=args.algo, levels=args.levels, stream=stream,
+                              bcast=args.bcast, events=ev)
             if record:
                 step_events.append(ev)
         else:
@@ -571,14 +618,16 @@ def main():
         # rank 0 recomputes every C panel from the full seeded A on its own GPU and compares with what was gathered
         A_full = device.DMat.random(n, n, 1, stream)
         sharded_ok = True
-        for pnl in range(P):
-            ref = device.mul(A_full, Bp[pnl], algo=args.algo, param=args.levels, stream=stream)
-            sharded_ok = sharded_ok and device.equal(ref, device.DMat.from_torch(Cfull_t[pnl], ncp), stream)
+        for j_ in range(Q):
+            for pnl in range(P):
+                ref = device.mul(A_full, device.DMat.from_torch(b_src_t[j_][pnl], ncp), algo=args.algo, param=args.levels, stream=stream)
+                sharded_ok = sharded_ok and device.equal(ref, device.DMat.from_torch(Cfull_t[j_][pnl], ncp), stream)
         del A_full
 
     self_check = None
     if world > 1 and not args.no_parity:
-        self_check = _sharded_self_check(device, sharded, torch, Bp, Cfull_t, n, world, stream)
+        self_check = _sharded_self_check(device, sharded, torch, [device.DMat.from_torch(b_src_t[j_][p_], ncp) for j_ in range(Q) for p_ in range(P)],
+                                         [Cfull_t[j_][p_] for j_ in range(Q) for p_ in range(P)], n, R, stream)
     parity = None
     if world == 1 and not args.no_parity and args.density == "half":
         want = _golden_digests().get("sq_%d" % n, {}).get("sha256_c")
@@ -587,7 +636,7 @@ def main():
 
     # dominant kernel: the (batched) M4RM tile kernel. Algorithmic bytes of ONE launch = what that
     # launch's products read and write once: batch * (m*l + l*n + m*n)/8 with the leaf dims.
-    ncols_launch = n // P  # columns of B one launch sees (a column panel when N > 1)
+    ncols_launch = n // (Q * P)  # columns of B one launch sees (a sub-panel of the rank's column panel when N > 1)
     levels = sharded.levels_used(rows, n, ncols_launch, args.algo, args.levels)
     # the library may cut the batch of 7^levels leaf products into several launches (chunks that overlap the Strassen passes)
     products = (args.steps * P) or 1
@@ -641,13 +690,16 @@ def main():
         "config": {
             "workload": "GF(2) %dx%dx%d matmul, inputs resident in HBM, %s%s" % (
                 n, n, n, "Strassen(%d levels)-over-M4RM" % levels if levels else "M4RM only",
-                "; per step: B (resident on rank 0) reaches the %d ranks in %d column panels, every rank multiplies its %d-row block "
-                "of A by each panel, the %d x %d blocks of C are gathered on rank 0" % (world, P, rows, rows, ncp) if world > 1 else ""),
+                "; per step on a %d x %d grid of ranks: B (resident on rank 0) travels in %d column panels of %d sub-panels, rank (i, j) "
+                "multiplies its %d-row block i of A by the sub-panels of column panel j, the %d x %d blocks of C are gathered on rank 0"
+                % (R, Q, Q, P, rows, rows, ncp) if world > 1 else ""),
             "n": n, "algo": args.algo, "strassen_levels": levels,
             "parallelism": "row-block shard of A over %d GPU(s)%s" % (
-                world, ", B in %d column panels: RCCL %s(panel p+1) / gather(C panel p-1) overlap the product of panel p" % (
-                    P, "broadcast" if args.bcast == "broadcast" else "scatter+all_gather")
+                world, " as a %d x %d grid (%d row blocks of A x %d column panels of B; the inner dimension is never split), %d sub-panels "
+                       "per column panel: RCCL %s(sub-panel p+1) / gather(C sub-panel p-1) overlap the product of sub-panel p" % (
+                    R, Q, R, Q, P, "broadcast" if args.bcast == "broadcast" else "scatter+all_gather")
                 if world > 1 else ""),
+            "grid": "%dx%d" % (R, Q) if world > 1 else None,
         },
         "roofline": {
             "bound": "hbm",
@@ -696,8 +748,8 @@ def main():
                 "step_ms": max(b["step_ms"] for b in bds),
                 "note": "per-rank maxima; marks recorded on the compute stream inside the timed steps"}
         if panel_tuning is not None:
-            out["panel_tuning"] = {"candidates": panel_tuning, "chosen": {"panels": P, "bcast": args.bcast},
-                                   "note": "three untimed steps per candidate before the timed loop; --panels / --bcast pin a choice"}
+            out["panel_tuning"] = {"candidates": panel_tuning, "chosen": {"grid": "%dx%d" % (R, Q), "panels": P, "bcast": args.bcast},
+                                   "note": "three untimed steps per candidate before the timed loop; --grid / --panels / --bcast pin a choice"}
         if self_check is not None:
             out["self_check"] = self_check
             out["parity_rows_ok"] = self_check["ok"]

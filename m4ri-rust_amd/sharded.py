@@ -134,6 +134,165 @@ def mul_row_sharded_pipelined(a_block, b_panels, c_panels, c_full_panels, ncols_
         w.wait()
 
 
+# ---------------------------------------------------------------------------------------------
+# Two-dimensional grids of ranks (round 5): R row blocks of A x Q column panels of B, R * Q = world.
+#
+# Rank r = i * Q + j keeps row block i of A resident (rows / R rows), receives ONLY column panel j of B (cols / Q columns, in P
+# sub-panels for the overlap of transfer and product), multiplies once per sub-panel, and the blocks of C are gathered on rank 0.
+# Still north_star's decomposition -- rows of A sharded, tiles of B by RCCL, gather of C, the inner dimension never split, no
+# reduction -- but a rank's product is squarer (one-GPU timings at n = 65536, profiles/r04_size_sweep.txt: 8192 x 65536 x 65536
+# 4.65 ms, 16384 x 65536 x 32768 4.18, 32768 x 65536 x 16384 4.00) and it needs 1 / Q of B: 128 MiB instead of 512 per rank and step
+# on a 2 x 4 grid.  Q = 1 is the row-block scheme above.
+# ---------------------------------------------------------------------------------------------
+
+class Grid:
+    """The process groups of an R x Q grid.  Collective: EVERY rank of the world constructs it with the same (R, Q), in the same order
+    relative to other group creations."""
+
+    def __init__(self, R, Q, world=None, rank=None):
+        import torch.distributed as dist
+        self.world = dist.get_world_size() if world is None else world
+        self.rank = dist.get_rank() if rank is None else rank
+        assert R >= 1 and Q >= 1 and R * Q == self.world, "grid %d x %d does not cover %d ranks" % (R, Q, self.world)
+        self.R, self.Q = R, Q
+        self.i, self.j = self.rank // Q, self.rank % Q
+        # column group j: the R ranks that share column panel j of B; bgroup j: rank 0 (where B lives) + column group j
+        self.col_ranks = [[i * Q + j for i in range(R)] for j in range(Q)]
+        self.col_groups, self.bgroups = [], []
+        for j in range(Q):
+            if Q == 1:
+                self.col_groups.append(None)  # the default group: exactly the row-block scheme
+                self.bgroups.append(None)
+                continue
+            cg = dist.new_group(ranks=self.col_ranks[j])
+            self.col_groups.append(cg)
+            self.bgroups.append(cg if j == 0 else dist.new_group(ranks=[0] + self.col_ranks[j]))
+        self._side = None
+
+    def block_of(self, r):
+        return r // self.Q, r % self.Q
+
+    def side_stream(self, like):
+        """A second stream for chains of collectives on DIFFERENT communicators (each orders itself against the stream that is
+        current when it is issued, not against the other communicator): GPUs only."""
+        import torch
+        if not like.is_cuda:
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        return self._side
+
+
+def distribute_grid_panel(grid, b_panel, b_src_p, mode="broadcast"):
+    """Start moving sub-panel p of every column panel of B from rank 0 to the ranks that multiply with it; returns a handle with
+    .wait().  b_panel: this rank's (l, w) buffer (on rank 0: b_src_p[0] itself); b_src_p: on rank 0 the Q source tensors
+    [column panel j], None elsewhere.
+
+    "broadcast": for every column panel j one broadcast from rank 0 inside {rank 0} + column group j.
+    "allgather": ONE scatter from rank 0 over all ranks -- rank (i, j) receives rows [i l / R, (i + 1) l / R) of panel j: 1 / world of
+    B leaves rank 0 towards every peer, all of its links in parallel -- then an all-gather inside every column group."""
+    import torch
+    import torch.distributed as dist
+    R, Q, rank = grid.R, grid.Q, grid.rank
+    if mode == "broadcast":
+        works = []
+        for j in range(Q):
+            if rank == 0:
+                works.append(dist.broadcast(b_src_p[j], src=0, group=grid.bgroups[j], async_op=True))
+            elif j == grid.j:
+                works.append(dist.broadcast(b_panel, src=0, group=grid.bgroups[j], async_op=True))
+        return _Chain(works)
+    assert b_panel.shape[0] % R == 0, "panel rows must divide by the number of row blocks"
+    shards = list(b_panel.chunk(R, dim=0))
+    mine = shards[grid.i]
+    slist = None
+    if rank == 0:
+        slist = [list(b_src_p[grid.block_of(r)[1]].chunk(R, dim=0))[grid.block_of(r)[0]] for r in range(grid.world)]
+    gloo = dist.get_backend() != "nccl"
+    w1 = dist.scatter(mine, scatter_list=slist, src=0, async_op=True)
+    if R == 1:
+        return w1
+    side = grid.side_stream(b_panel)
+    if side is not None and Q > 1:
+        # the all-gather runs on the column group's communicator: chained behind the scatter through a side stream, so that the
+        # compute stream waits for neither until the consumer asks (handle.wait())
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            w1.wait()
+            w2 = dist.all_gather(shards, mine, group=grid.col_groups[grid.j], async_op=True)
+        return _Chain([w2])
+    src = mine
+    if gloo:  # gloo runs asynchronous operations in no particular order, and dislikes aliased buffers
+        w1.wait()
+        src = mine.clone()
+    w2 = dist.all_gather(shards, src, group=grid.col_groups[grid.j], async_op=True)
+    return _Chain([w1, w2])
+
+
+def gather_grid_panel(grid, c_panel, c_full_p):
+    """Start gathering sub-panel p of C on rank 0: c_panel = this rank's (rows / R, w) block; c_full_p = on rank 0 the Q tensors
+    (rows, w) [column panel j] that receive it, None elsewhere.  One gather over all ranks."""
+    import torch.distributed as dist
+    glist = None
+    if grid.rank == 0:
+        glist = [list(c_full_p[grid.block_of(r)[1]].chunk(grid.R, dim=0))[grid.block_of(r)[0]] for r in range(grid.world)]
+    return dist.gather(c_panel, gather_list=glist, dst=0, async_op=True)
+
+
+def mul_grid_pipelined(grid, a_block, b_src, b_panels, c_panels, c_full, ncols_inner, ncols_sub, local_mul=None,
+                       bcast="broadcast", **kw):
+    """C = A * B on an R x Q grid of ranks, B in Q column panels of P sub-panels each.
+
+    a_block        : (rows / R, ceil(l / 64)) int64, row block i of A
+    b_src[j][p]    : rank 0 only -- (l, ceil(ncols_sub / 64)) int64, sub-panel p of column panel j of B; None elsewhere
+    b_panels[p]    : this rank's sub-panels of ITS column panel j (rank 0: b_src[0][p])
+    c_panels[p]    : (rows / R, ceil(ncols_sub / 64)), this rank's block of C for sub-panel p
+    c_full[j][p]   : rank 0 only -- (rows, ceil(ncols_sub / 64)) receiving sub-panel p of column panel j of C; None elsewhere
+    """
+    local_mul = local_mul or _hip_local_mul
+    P = len(b_panels)
+    if grid.world == 1:
+        for p in range(P):
+            local_mul(a_block, b_panels[p], c_panels[p], ncols_inner, ncols_sub, **kw)
+            if c_full is not None:
+                c_full[0][p].copy_(c_panels[p])
+        return
+    bcasts = [distribute_grid_panel(grid, b_panels[p], [b_src[j][p] for j in range(grid.Q)] if grid.rank == 0 else None, bcast)
+              for p in range(P)]
+    gathers = []
+    for p in range(P):
+        bcasts[p].wait()
+        local_mul(a_block, b_panels[p], c_panels[p], ncols_inner, ncols_sub, **kw)
+        gathers.append(gather_grid_panel(grid, c_panels[p], [c_full[j][p] for j in range(grid.Q)] if grid.rank == 0 else None))
+    for w in gathers:
+        w.wait()
+
+
+def step_grid(grid, A, b_src_t, Bp_t, Cp_t, Cfull_t, Bp, Cp, algo="auto", levels=0, stream=None, bcast="broadcast", events=None):
+    """bench.py's timed step for N > 1 ranks on an R x Q grid (DMat wrappers pre-built); `events` as in step_pipelined."""
+    import torch
+    P = len(Bp_t)
+
+    def mark():
+        if events is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            events.append(e)
+    mark()
+    bcasts = [distribute_grid_panel(grid, Bp_t[p], [b_src_t[j][p] for j in range(grid.Q)] if grid.rank == 0 else None, bcast)
+              for p in range(P)]
+    gathers = []
+    for p in range(P):
+        bcasts[p].wait()
+        mark()
+        device.mul(A, Bp[p], C=Cp[p], algo=algo, param=levels, stream=stream)
+        mark()
+        gathers.append(gather_grid_panel(grid, Cp_t[p], [Cfull_t[j][p] for j in range(grid.Q)] if grid.rank == 0 else None))
+    for w in gathers:
+        w.wait()
+    mark()
+
+
 def step_pipelined(A, Bp_t, Cp_t, Cfull_t, Bp, Cp, algo="auto", levels=0, stream=None, bcast="broadcast", events=None):
     """bench.py's timed step for N > 1 ranks, B in column panels (DMat wrappers pre-built).
 

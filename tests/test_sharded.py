@@ -89,6 +89,71 @@ def _worker_panels(rank, world, port, m, l, n, P, out_path, bcast="broadcast"):
     dist.destroy_process_group()
 
 
+def _worker_grid(rank, world, port, m, l, n, R, Q, P, out_path, bcast):
+    """One rank of an R x Q grid (sharded.mul_grid_pipelined): row block i = rank // Q of A, column panel j = rank % Q of B."""
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    import gf2util as gg
+    import m4ri_rust_amd  # noqa: F401
+    from m4ri_rust_amd import sharded
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    grid = sharded.Grid(R, Q)
+    i = rank // Q
+    rows, ws, ncs = m // R, gg.width(n) // (Q * P), n // (Q * P)
+    a_block = torch.from_numpy(gg.random_words(m, l, 1)[i * rows:(i + 1) * rows].copy().view(np.int64))
+    b_full = gg.random_words(l, n, 2)
+    b_src = None
+    if rank == 0:
+        b_src = [[torch.from_numpy(b_full[:, (j * P + p) * ws:(j * P + p + 1) * ws].copy().view(np.int64)) for p in range(P)] for j in range(Q)]
+    b_panels = b_src[0] if rank == 0 else [torch.zeros((l, ws), dtype=torch.int64) for _ in range(P)]
+    c_panels = [torch.zeros((rows, ws), dtype=torch.int64) for _ in range(P)]
+    c_full = [[torch.zeros((m, ws), dtype=torch.int64) for _ in range(P)] for _ in range(Q)] if rank == 0 else None
+
+    def oracle_local_mul(a_t, b_t, c_t, ncols_inner, ncols_out, **_kw):
+        a = np.ascontiguousarray(a_t.numpy().view(np.uint64))
+        bb = np.ascontiguousarray(b_t.numpy().view(np.uint64))
+        c_t.copy_(torch.from_numpy(gg.o_mul_m4rm(a, bb, a.shape[0], ncols_inner, ncols_out).view(np.int64)))
+
+    for _ in range(2):  # two steps back to back: the panels travel into the same buffers again
+        sharded.mul_grid_pipelined(grid, a_block, b_src, b_panels, c_panels, c_full, l, ncs, local_mul=oracle_local_mul, bcast=bcast)
+    if rank == 0:
+        np.save(out_path, np.concatenate([c_full[j][p].numpy().view(np.uint64) for j in range(Q) for p in range(P)], axis=1))
+        # rank 0's copy of B must have survived the all-gathers into its own panel buffers
+        assert all(np.array_equal(b_src[j][p].numpy().view(np.uint64), b_full[:, (j * P + p) * ws:(j * P + p + 1) * ws])
+                   for j in range(Q) for p in range(P))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bcast", ["broadcast", "allgather"])
+@pytest.mark.parametrize("R,Q,P", [(4, 1, 1), (2, 2, 1), (2, 2, 2), (1, 4, 1), (4, 1, 2)], ids=lambda v: str(v))
+def test_grid_world4_gloo(tmp_path, built, R, Q, P, bcast):
+    """R x Q grids of four ranks (round 5): rank (i, j) multiplies row block i of A with column panel j of B only; 4 x 1 (the
+    row-block scheme), 2 x 2 and 1 x 4 must all deliver the same C on rank 0 -- the oracle's -- for both ways B travels."""
+    import torch.multiprocessing as mp
+    m, l, n = 256, 192, 512
+    out = str(tmp_path / "c.npy")
+    mp.spawn(_worker_grid, args=(4, _free_port(), m, l, n, R, Q, P, out, bcast), nprocs=4, join=True)
+    ref = g.o_mul_m4rm(g.random_words(m, l, 1), g.random_words(l, n, 2), m, l, n)
+    assert np.array_equal(np.load(out), ref)
+
+
+@pytest.mark.parametrize("R,Q", [(2, 1), (1, 2)], ids=["2x1", "1x2"])
+def test_grid_world2_gloo(tmp_path, built, R, Q):
+    import torch.multiprocessing as mp
+    m, l, n = 128, 200, 256
+    out = str(tmp_path / "c.npy")
+    mp.spawn(_worker_grid, args=(2, _free_port(), m, l, n, R, Q, 2, out, "allgather"), nprocs=2, join=True)
+    ref = g.o_mul_m4rm(g.random_words(m, l, 1), g.random_words(l, n, 2), m, l, n)
+    assert np.array_equal(np.load(out), ref)
+
+
 @pytest.mark.parametrize("bcast", ["broadcast", "allgather"])
 @pytest.mark.parametrize("P,n", [(2, 256), (4, 512)], ids=["2panels", "4panels"])
 def test_pipelined_column_panels_world2_gloo(tmp_path, built, P, n, bcast):
@@ -138,34 +203,39 @@ def test_row_block_generator_matches_full_matrix():
 # ---- the driver's own invocation, rehearsed on the GPU box ---------------------------------------------
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("bcast", ["broadcast", "allgather", None])
-def test_bench_two_ranks_from_a_bare_shell(bcast):
+@pytest.mark.parametrize("bcast,grid", [("broadcast", None), ("allgather", None), (None, None), ("broadcast", "1x2"), ("allgather", "1x2"),
+                                        ("allgather", "2x1")])
+def test_bench_two_ranks_from_a_bare_shell(bcast, grid):
     """`python bench.py --gpus 2 ...` with WORLD_SIZE unset -- exactly how the driver starts the scaling runs -- must launch
-    its own two ranks (torch.distributed.run children; the parent never touches the GPU), run the row-sharded step
-    (broadcast of B panels, HIP product of the row block, gather of C) and print ONE JSON line whose sharded result equals
+    its own two ranks (torch.distributed.run children; the parent never touches the GPU), run the sharded step (RCCL / gloo
+    movement of B's panels, HIP product of every rank's block, gather of C) and print ONE JSON line whose sharded result equals
     the single-GPU product.  On the one-GPU test box the two ranks share device 0 and talk over gloo; on a multi-GPU node
-    the same command with --backend nccl is the real thing."""
+    the same command with --backend nccl is the real thing.  Grids (round 5): 2x1 = two row blocks of A against all of B (the
+    row-block scheme), 1x2 = all of A against two column panels of B; unset, both are tuning candidates."""
     import json
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--check", "--dim", "8192",
-           "--no-cpu", "--steps", "2", "--warmup", "1"] + (["--bcast", bcast] if bcast else [])
+           "--no-cpu", "--steps", "2", "--warmup", "1"] + (["--bcast", bcast] if bcast else []) + (["--grid", grid] if grid else [])
     r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["sharded_result_matches_single_gpu"] is True
+    assert out["self_check"]["ok"] is True and out["parity_rows_ok"] is True
     assert out["scaling"] == "strong" and out["value"] > 0 and out["config"]["n"] == 8192
+    assert out["config"]["grid"] == (grid or "2x1") or bcast is None
     # the line says where a step's time went (marks on the compute stream, per-rank maxima) ...
     bd = out["step_breakdown"]
     assert len(bd["wait_b_ms"]) == len(bd["product_ms"]) >= 1 and bd["step_ms"] > 0 and bd["gather_tail_ms"] >= 0
     assert all(r["step_breakdown"] for r in out["ranks"])
-    if bcast is None:  # ... and, with --panels / --bcast left alone, the run chose its panel plan from its own timings
+    if bcast is None:  # ... and, with --grid / --panels / --bcast left alone, the run chose its plan from its own timings
         tune = out["panel_tuning"]
-        assert {(c["panels"], c["bcast"]) for c in tune["candidates"]} == {(p, b) for p in (1, 2, 4) for b in ("broadcast", "allgather")}
-        assert tune["chosen"] in [{"panels": c["panels"], "bcast": c["bcast"]} for c in tune["candidates"]]
+        assert {(c["grid"], c["panels"], c["bcast"]) for c in tune["candidates"]} == {(gr, p, b) for gr in ("2x1", "1x2") for p in (1, 2, 4)
+                                                                                      for b in ("broadcast", "allgather")}
         best = min(tune["candidates"], key=lambda c: c["ms_per_step"])
-        assert tune["chosen"] == {"panels": best["panels"], "bcast": best["bcast"]}
+        assert tune["chosen"] == {"grid": best["grid"], "panels": best["panels"], "bcast": best["bcast"]}
+        assert out["config"]["grid"] == best["grid"]
     else:
         assert "panel_tuning" not in out
