@@ -124,6 +124,7 @@ _PROTOS = {
     "gf2_prof_enable": (None, [_I]),
     "gf2_prof_read": (_I, [ctypes.POINTER(_I), ctypes.POINTER(ctypes.c_double), _I]),
     "gf2_kernel_census": (ctypes.c_size_t, [ctypes.c_char_p, ctypes.c_size_t]),
+    "gf2_host_plan_model": (_I, [_I, _I, _I, _I, _I, ctypes.POINTER(ctypes.c_double)]),
 }
 
 # every symbol include/m4ri_hip.h declares; tests check the library exports all of them

@@ -2056,6 +2056,121 @@ void unlease_stream(int dev, hipStream_t s) {
 // those rows of C are complete in host memory.
 // The side copy of a fresh thin product (see ResultSide): C^T into a device scratch, brought down into `side->buf` on stream s.
 // The caller synchronises s before it looks at the buffer or lets `dT` go.
+// ---- schedules of a large host product (round 5) ----
+// Modelled device time of one (sub-)product as the host path would run it.
+double host_product_model(int m, int l, int n, int algo, int param) {
+  if (algo == GF2_ALGO_M4RM || algo == GF2_ALGO_NAIVE) return plain_time_model(m, l, n);
+  static const int leaf_min = env_int("M4RI_HIP_STRASSEN_LEAF_MIN", 2048);
+  double t = 0;
+  (void)pick_levels(m, l, n, param, leaf_min, &t);
+  return t > 0 ? t : plain_time_model(m, l, n);
+}
+// A host product is three queues -- uploads, products, downloads -- and a plan is the order and size of their pieces.  Two families:
+//   row blocks   C_i = A_i B: blocks of A and C (the first one against the two halves of B, so that it can start early); every
+//                block's rows of C leave as soon as they exist, but a block product runs below the whole product's efficiency
+//                (8192-row blocks of 32768^3: 1.45 ms against 1.0 for a quarter of the whole);
+//   slabs        C ^= A[:, K] B[K, :] over slabs K of the INNER dimension: every product keeps all rows (65536 x 16384 x 65536
+//                accumulate: 8.4 ms, a quarter of the whole product is 7.2), only the first slab's upload is exposed -- A's
+//                slab is a 2-D copy of 1-2 KiB pieces, which runs at the linear rate --; the last slab is multiplied in row
+//                blocks so that C does not leave all at once behind it.
+// Which one ends first depends on how compute and PCIe compare, so each candidate is played through with the planner's own time
+// model and the copy rate of the link (profiles/r05_slab_prices.txt has the measured sub-products).
+struct HostPlan {
+  std::vector<int> slabs;  // sizes of the slabs of the inner dimension in bits; empty: the row-block plan
+  int row_groups = 1;      // slab plans: the rows of A and C in this many groups, one group after the other through all slabs (a
+                           // finished group's rows of C leave while the next group is multiplied; sub-products of rows / 2 x l / 4
+                           // are no less efficient than all rows x l / 4: 32768^3 16384 x 8192 x 32768 0.64 ms against 1.24 for twice the rows)
+  double t_end = 0;
+};
+HostPlan plan_host_product(int rows, int l, int n, int algo, int param, bool b_resident, size_t a_row_bytes, size_t b_row_bytes, size_t c_row_bytes,
+                           double *all_t_end = nullptr, int *chosen = nullptr) {
+  static const double rate = (double)dev_env_int("M4RI_HIP_PCIE_GBS", 55) * 1e9;
+  // read per call (tests and A/B runs): 1 row blocks, 2 four equal slabs, 3 growing slabs, 4 two slabs, 5 / 6 two row groups x four / two slabs; 0 = by the model
+  const int forced = env_int("M4RI_HIP_HOST_PLAN", 0);
+  auto T = [&](int m_, int l_) { return host_product_model(m_, l_, n, algo, param); };
+  const int NB = 4;
+  // row blocks: quarter, half, quarter when a quarter keeps 16384 rows (see host_mul_range), B in two halves for the first block
+  HostPlan rb;
+  {
+    const int q = rows / 4;
+    std::vector<int> bnd = q >= 16384 ? std::vector<int>{0, q, 3 * q, rows} : std::vector<int>{0, q, 2 * q, 3 * q, rows};
+    const bool halves = !b_resident && l >= 8192 && l % 256 == 0;
+    double up = 0, tc = 0, td = 0;
+    std::vector<double> arrA;
+    up += (double)bnd[1] * a_row_bytes / rate;
+    arrA.push_back(up);
+    double bt = up, bb = up;
+    if (!b_resident) {
+      up += (double)l / 2 * b_row_bytes / rate;
+      bt = up;
+      up += (double)l / 2 * b_row_bytes / rate;
+      bb = up;
+    }
+    for (size_t i = 1; i + 1 < bnd.size(); ++i) {
+      up += (double)(bnd[i + 1] - bnd[i]) * a_row_bytes / rate;
+      arrA.push_back(up);
+    }
+    for (size_t i = 0; i + 1 < bnd.size(); ++i) {
+      const int R = bnd[i + 1] - bnd[i];
+      if (i == 0 && halves) {
+        tc = std::max(tc, std::max(arrA[0], bt)) + T(R, l / 2);
+        tc = std::max(tc, bb) + T(R, l / 2);
+      } else {
+        tc = std::max(tc, std::max(arrA[i], bb)) + T(R, l);
+      }
+      td = std::max(td, tc) + (double)R * c_row_bytes / rate;
+    }
+    rb.t_end = td;
+  }
+  auto slab_plan = [&](const std::vector<int> &ks, int NR) {
+    HostPlan hp;
+    hp.slabs = ks;
+    hp.row_groups = NR;
+    const int rg = rows / NR;
+    double up = 0, tc = 0, td = 0;
+    for (int g = 0; g < NR; ++g)
+      for (size_t si = 0; si < ks.size(); ++si) {
+        up += ((double)rg * ks[si] / 8.0 + ((b_resident || g > 0) ? 0.0 : (double)ks[si] * b_row_bytes)) / rate;
+        if (si + 1 < ks.size()) {
+          tc = std::max(tc, up) + T(rg, ks[si]);
+        } else if (g + 1 < NR) {
+          tc = std::max(tc, up) + T(rg, ks[si]);
+          td = std::max(td, tc) + (double)rg * c_row_bytes / rate;
+        } else {
+          for (int b = 0; b < NB; ++b) {
+            tc = std::max(tc, up) + T(rg / NB, ks[si]);
+            td = std::max(td, tc) + (double)(rg / NB) * c_row_bytes / rate;
+          }
+        }
+      }
+    hp.t_end = td;
+    return hp;
+  };
+  std::vector<HostPlan> cands{rb};
+  const bool slabs_ok = l % (8 * 1024) == 0 && l >= 16384 && rows % (NB * 64) == 0;
+  if (slabs_ok) {
+    cands.push_back(slab_plan({l / 4, l / 4, l / 4, l / 4}, 1));
+    cands.push_back(slab_plan({l / 8, l / 8, l / 4, l / 2}, 1));
+    cands.push_back(slab_plan({l / 2, l / 2}, 1));
+    if (rows % (2 * NB * 64) == 0 && rows / 2 >= 8192) {
+      cands.push_back(slab_plan({l / 4, l / 4, l / 4, l / 4}, 2));
+      cands.push_back(slab_plan({l / 2, l / 2}, 2));
+    }
+  }
+  if (all_t_end)
+    for (size_t i = 0; i < 6; ++i) all_t_end[i] = i < cands.size() ? cands[i].t_end : -1.0;
+  // the fastest slab plan by the model -- within half a percent the LATER candidate wins: two row groups measured 0.2-0.3 ms ahead
+  // of their one-group twins where the model has them level (32768^3 7.9 against 8.2 ms, 65536^3 41.0 against 41.4; profiles/
+  // r05_host_plan_ab.txt) --, taken if it promises 3 % over the row blocks
+  size_t best = 0, bs = 0;
+  for (size_t i = 1; i < cands.size(); ++i)
+    if (!bs || cands[i].t_end <= 1.005 * cands[bs].t_end) bs = i;
+  if (bs && cands[bs].t_end < 0.97 * cands[0].t_end) best = bs;
+  if (forced >= 1 && forced <= (int)cands.size()) best = (size_t)forced - 1;
+  if (chosen) *chosen = (int)best + 1;
+  return cands[best];
+}
+
 // Rows [r0, r0 + c.nrows) of a fresh thin product C (r0 a multiple of 64) into their words of every row of the side copy.  The
 // transposition kernel stores straight into the pinned host buffer (device-visible like every hipHostMalloc block; 128 KiB for
 // 2^20 x 1): no scratch and no second download queued behind C's on the copy engine.  Complete once stream s has been synchronised.
@@ -2086,6 +2201,83 @@ int host_mul_range(mzd_t *C, const mzd_t *A, const mzd_t *B, int r0, int r1, int
   // IS the upload of A (32 MiB: 0.56 ms) -- with row blocks the kernel and the download of C (8 MiB in M4RI's layout) hide behind it
   // instead of following it.
   const bool thin = B->ncols <= 256 && A->ncols <= 1024 && (size_t)rows * A->rowstride * sizeof(word) >= ((size_t)8 << 20);
+  const bool big_pipelined = pipe_blocks >= 2 && !accumulate && plain_layout && rows >= 16384 && rows % (pipe_blocks * 64) == 0 &&
+                             (long long)A->ncols * B->ncols >= (1ll << 28) && !(whole && cache_lookup(A));
+  HostPlan hplan;
+  if (big_pipelined && pipe_blocks == 4 && B->rowstride >= 1 && !(B->flags & mzd_flag_windowed_zerooffset))
+    hplan = plan_host_product(rows, A->ncols, B->ncols, algo, param, (bool)cache_lookup(B), (size_t)A->rowstride * sizeof(word),
+                              (size_t)B->rowstride * sizeof(word), (size_t)C->rowstride * sizeof(word));
+  if (!hplan.slabs.empty()) {
+    // ---- slabs of the inner dimension: C (+)= A[G, K_s] B[K_s, :] for every row group G in turn; a finished group's rows of C leave
+    // while the next group is multiplied, the LAST group's last slab runs in four row blocks whose rows leave one by one ----
+    const int S = (int)hplan.slabs.size(), NR = hplan.row_groups, NBL = 4, RGr = rows / NR;
+    SideStream *sd = nullptr;
+    rc = side_stream(s, NR * S + NR + NBL, &sd, /*want_s3=*/true);
+    DMatOwner dA, dB, dC;
+    const bool bcached = (bool)cache_lookup(B);
+    if (!rc) rc = to_device(dB, B, sd->s2, bcached);  // a cached B is borrowed (nothing is copied); otherwise allocated here, uploaded by slabs
+    if (!rc) rc = to_device_rows(dA, A, r0, r1, s, false);
+    if (!rc) rc = to_device_rows(dC, C, r0, r1, s, false);
+    if (!rc && (dA.d.ld != A->rowstride || dC.d.ld != C->rowstride || (!bcached && dB.d.ld != B->rowstride)))
+      rc = fail_msg("host pipeline: unexpected device stride");
+    hipEvent_t *evU = sd ? sd->ev.data() : nullptr, *evC = evU + NR * S;
+    auto rows_bytes = [](const mzd_t *M, int nr) { return ((size_t)(nr - 1) * M->rowstride + M->width) * sizeof(word); };
+    for (int g = 0; !rc && g < NR; ++g) {  // every upload is queued at once: the next piece travels while this one is multiplied
+      int k0 = 0;
+      for (int si = 0; !rc && si < S; ++si) {
+        const int ks = hplan.slabs[si];
+        if (hipMemcpy2DAsync(dA.d.data + (size_t)g * RGr * dA.d.ld + k0 / 64, (size_t)dA.d.ld * sizeof(u64), A->rows[r0 + g * RGr] + k0 / 64,
+                             (size_t)A->rowstride * sizeof(word), (size_t)ks / 8, (size_t)RGr, hipMemcpyHostToDevice, sd->s2) != hipSuccess ||
+            (!bcached && g == 0 &&
+             hipMemcpyAsync(dB.d.data + (size_t)k0 * dB.d.ld, B->rows[k0], rows_bytes(B, ks), hipMemcpyHostToDevice, sd->s2) != hipSuccess) ||
+            hipEventRecord(evU[g * S + si], sd->s2) != hipSuccess)
+          rc = fail(hipGetLastError(), "host pipeline: upload of a slab");
+        k0 += ks;
+      }
+    }
+    int nev_c = 0;
+    auto download = [&](int row0, int nr, const gf2_dmat &c) {
+      if (hipEventRecord(evC[nev_c], s) != hipSuccess || hipStreamWaitEvent(sd->s3, evC[nev_c], 0) != hipSuccess ||
+          hipMemcpyAsync(C->rows[r0 + row0], c.data, rows_bytes(C, nr), hipMemcpyDeviceToHost, sd->s3) != hipSuccess)
+        rc = fail(hipGetLastError(), "host pipeline: download");
+      ++nev_c;
+    };
+    for (int g = 0; !rc && g < NR; ++g) {
+      int k0 = 0;
+      for (int si = 0; !rc && si < S; ++si) {
+        const int ks = hplan.slabs[si];
+        if (hipStreamWaitEvent(s, evU[g * S + si], 0) != hipSuccess) rc = fail(hipGetLastError(), "host pipeline: wait");
+        gf2_dmat a = dA.d, b = dB.d, c = dC.d;
+        a.data += (size_t)g * RGr * a.ld + k0 / 64;
+        a.nrows = RGr;
+        a.ncols = ks;
+        b.data += (size_t)k0 * b.ld;
+        b.nrows = ks;
+        c.data += (size_t)g * RGr * c.ld;
+        c.nrows = RGr;
+        if (si + 1 < S || g + 1 < NR) {
+          if (!rc) rc = mul_dispatch(&c, &a, &b, si > 0, algo, param, s, /*sync_free=*/false);
+          if (!rc && si + 1 == S) download(g * RGr, RGr, c);
+        } else {
+          for (int bl = 0; !rc && bl < NBL; ++bl) {
+            const int R = RGr / NBL;
+            gf2_dmat ab = a, cb = c;
+            ab.data += (size_t)bl * R * ab.ld;
+            ab.nrows = R;
+            cb.data += (size_t)bl * R * cb.ld;
+            cb.nrows = R;
+            rc = mul_dispatch(&cb, &ab, &b, si > 0, algo, param, s, /*sync_free=*/false);
+            if (!rc) download(g * RGr + bl * R, R, cb);
+          }
+        }
+        k0 += ks;
+      }
+    }
+    if (sd && hipStreamSynchronize(sd->s2) != hipSuccess && !rc) rc = fail(hipGetLastError(), "host pipeline: upload stream");
+    if (sd && sd->s3 && hipStreamSynchronize(sd->s3) != hipSuccess && !rc) rc = fail(hipGetLastError(), "host pipeline: download stream");
+    if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = fail(hipGetLastError(), "host pipeline: compute stream");
+    return rc;
+  }
   if (pipe_blocks >= 2 && !accumulate && plain_layout && rows >= 16384 && rows % (pipe_blocks * 64) == 0 &&
       ((long long)A->ncols * B->ncols >= (1ll << 28) || thin) && !(whole && cache_lookup(A))) {
     // Units: row blocks of A and C (contiguous rows) x halves of the inner dimension (contiguous rows of B):
@@ -2431,6 +2623,18 @@ extern "C" int gf2_mzd_cache_on_device(mzd_t const *M) {
 }
 
 extern "C" void gf2_mzd_uncache(mzd_t const *M) { gf2_cache_forget(M); }
+
+// The schedules a large product on HOST matrices can take, as the library's time model plays them through (plan_host_product):
+// t_end[i] = modelled seconds of schedule i + 1 in M4RI_HIP_HOST_PLAN's numbering (-1: not applicable to this shape); returns the
+// number of the schedule the host path takes (0: the product is not pipelined at all).  Plain row-major operands of the natural strides.
+extern "C" int gf2_host_plan_model(int m, int l, int n, int algo, int param, double t_end[6]) {
+  for (int i = 0; i < 6; ++i) t_end[i] = -1.0;
+  if (m < 16384 || m % 256 || (long long)l * n < (1ll << 28)) return 0;
+  auto stride = [](int c) { const size_t w = (size_t)(c + 63) / 64; return (w < 3 || (w & 1) == 0 ? w : w + 1) * sizeof(word); };
+  int chosen = 0;
+  (void)plan_host_product(m, l, n, algo, param, false, stride(l), stride(n), stride(n), t_end, &chosen);
+  return chosen;
+}
 
 // mzd_transpose(DST, A) from the side copy of A, if A is a fresh thin product that still has one: DST (allocated when NULL) or nullptr.
 mzd_t *gf2_transpose_from_side_copy(mzd_t *DST, mzd_t const *A) {

@@ -60,3 +60,36 @@ def test_model_time_tracks_measured_time(dev, m, l, n):
     t_auto = next(t for L, t, _ in report if L == auto) if any(L == auto for L, _, _ in report) else None
     if t_auto is not None:
         assert t_auto <= 1.05 * min(t for _, t, _ in report), (auto, [(L, round(t * 1e3, 3)) for L, t, _ in report])
+
+
+def test_host_schedule_model_tracks_measured_time(built, monkeypatch):
+    """The schedules of a large product on HOST matrices (row blocks; slabs of the inner dimension; two row groups through the slabs;
+    round 5) are chosen by playing them through with the planner's time model and an assumed PCIe rate (plan_host_product).  At
+    32768^3 every schedule's modelled end must be within 15 % of the clock, and the schedule the model picks must not lose more than
+    3 % to the best one measured.  Reference entry point: mzd_mul on host mzd_t (m4ri-sys/src/strassen.rs:18 <- binary_matrix.rs:459-472)."""
+    import ctypes
+    import m4ri_rust_amd as pkg
+    from m4ri_rust_amd import device
+    device.require_gpu()
+    L = pkg._lib.lib()
+    n = 32768
+    te = (ctypes.c_double * 6)()
+    monkeypatch.setenv("M4RI_HIP_HOST_PLAN", "0")
+    chosen = L.gf2_host_plan_model(n, n, n, 0, 0, te)
+    assert 1 <= chosen <= 6 and all(t > 0 for t in te)
+    A, B = pkg.BinMatrix.random(n, n), pkg.BinMatrix.random(n, n)
+    C = pkg.BinMatrix.zero(n, n)
+    measured = {}
+    for plan in (1, 2, 3, 4, 5, 6):
+        monkeypatch.setenv("M4RI_HIP_HOST_PLAN", str(plan))
+        L.mzd_mul(C.mzd, A.mzd, B.mzd, 0)
+        ts = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            assert L.mzd_mul(C.mzd, A.mzd, B.mzd, 0)
+            ts.append(time.perf_counter() - t0)
+        measured[plan] = min(ts)
+    report = [(p, round(measured[p] * 1e3, 2), round(te[p - 1] * 1e3, 2)) for p in measured]
+    bad = [r for r in report if not 0.85 * r[1] <= r[2] <= 1.15 * r[1]]
+    assert not bad, "schedules whose modelled end is more than 15 %% off the measured one (plan, measured ms, model ms): %s of %s" % (bad, report)
+    assert measured[chosen] <= 1.03 * min(measured.values()), (chosen, report)

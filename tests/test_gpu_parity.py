@@ -358,6 +358,32 @@ def test_packed_plain_product_2gib_operand(dev):
     assert np.array_equal(dev.mul(Aw, B, algo="m4rm").to_words(), C1.to_words()[r0:r0 + rows])
 
 
+@pytest.mark.parametrize("plan", [2, 3, 4, 5, 6, 0], ids=["four_equal_slabs", "growing_slabs", "two_slabs", "two_row_groups_x_four_slabs",
+                                                     "two_row_groups_x_two_slabs", "by_the_model"])
+@pytest.mark.parametrize("shape", [(16384, 16384, 16384 + 77), (16384 + 256, 32768, 8192 + 64)], ids=lambda s_: "x".join(map(str, s_)))
+def test_host_product_pipelined_over_slabs_of_the_inner_dimension(pkg, dev, shape, plan, monkeypatch):
+    """Round 5: large host products may run as C ^= A[:, K] B[K, :] over slabs K of the inner dimension (A's slab uploaded by a 2-D
+    copy, B's rows contiguous), the last slab in four row blocks whose rows of C are downloaded one by one.  Every schedule
+    (M4RI_HIP_HOST_PLAN, read per call) gives the bits of the device-resident product; B cached on the device is borrowed, not uploaded;
+    the default strategies of the friendly layer all reach it."""
+    m, l, n = shape
+    monkeypatch.setenv("M4RI_HIP_HOST_PLAN", str(plan))
+    A, B = pkg.BinMatrix.random(m, l), pkg.BinMatrix.random(l, n)
+    a, b = A.to_words(), B.to_words()
+    ref = dev.mul(dev.DMat.from_words(a, l), dev.DMat.from_words(b, n)).to_words()
+    Lc = pkg._lib.lib()
+    for _ in range(2):  # back to back: streams, events and pooled blocks are reused
+        assert np.array_equal((A * B).to_words(), ref)
+    assert np.array_equal(pkg.BinMatrix(Lc.mzd_mul_m4rm(None, A.mzd, B.mzd, 0)).to_words(), ref)
+    Cp = pkg.BinMatrix.random(m, n)  # a preallocated destination is overwritten, not accumulated into
+    assert Lc.mzd_mul(Cp.mzd, A.mzd, B.mzd, 0) and np.array_equal(Cp.to_words(), ref)
+    B.cache_on_device()
+    assert np.array_equal((A * B).to_words(), ref)
+    B.uncache()
+    rows = np.array([0, 4095, 4096, m // 2, m - 1])
+    assert np.array_equal(ref[rows], g.o_mul_m4rm(np.ascontiguousarray(a[rows]), b, len(rows), l, n))
+
+
 @pytest.mark.parametrize("l", [16384 + 192, 16384], ids=["whole_B", "B_in_two_halves"])
 def test_host_product_pipelined_over_row_blocks(pkg, dev, l):
     """Host products with >= 16384 rows are pipelined over four row blocks of A and C and, when the inner dimension allows,
