@@ -18,3 +18,4 @@ void gf2_pinned_free(void *p, size_t bytes);
 // mzd_transpose(DST, A) served from the packed side copy a fresh thin product carries (m4ri_hip_api.cpp, ResultSide): the
 // destination (allocated when DST is NULL), or nullptr when A has no side copy
 mzd_t *gf2_transpose_from_side_copy(mzd_t *DST, mzd_t const *A);
+bool gf2_mzd_block_is_pinned(mzd_t const *M);

@@ -94,6 +94,11 @@ hipError_t gf2k_widevec(const uint64_t *A, long long lda, const uint64_t *Bt, lo
                         int m, int l, int n, int accumulate, int jshift, hipStream_t stream);
 hipError_t gf2k_tallskinny(const uint64_t *A, long long lda, const uint64_t *B, long long ldb, uint64_t *C, long long ldc,
                            int m, int l, int n, int accumulate, hipStream_t stream);
+// the same for one to four vectors against rows of 65..256 bits, with the packed transposed product written beside C (word
+// side[j * side_ld + row / 64] = bit j of rows row .. row + 63); A, C and side may be pinned HOST memory (the kernel then streams
+// them over PCIe itself: no copies); hipErrorNotSupported for other shapes
+hipError_t gf2k_tallskinny_side(const uint64_t *A, long long lda, const uint64_t *B, long long ldb, uint64_t *C, long long ldc, int m,
+                                int l, int n, uint64_t *side, long long side_ld, hipStream_t stream);
 // n <= 64 vectors, any inner dimension: 4-bit tables per 512-bit slab, inner dimension divided among workgroups (atomic XOR into C)
 hipError_t gf2k_tallskinny_long(const uint64_t *A, long long lda, const uint64_t *B, long long ldb, uint64_t *C, long long ldc,
                                 int m, int l, int n, int accumulate, hipStream_t stream);

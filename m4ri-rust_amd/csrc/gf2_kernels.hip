@@ -3324,8 +3324,22 @@ extern "C" hipError_t gf2k_tallskinny_long(const u64 *A, long long lda, const u6
 //   256 < l, 64 < n          gf2_tallskinny3_kernel<NW>  row sets of 32 / NW tables, rows re-fetched per row set
 // (The caller keeps l <= 1024: beyond that the tile kernel with split-K is faster.)  M4RI_HIP_TS6 = mask of the entry widths
 // (1, 2, 4 words) the 4-bit kernel takes instead (default 1); M4RI_HIP_TALLSKINNY_OLD=1 sends l <= 256 to the round-1 kernels (A/B runs).
+// `side` (optional): the table-free kernel for one to four vectors also packs bit j of every 64 rows' results into word
+// side[j * side_ld + row / 64] -- the transposed form of the product, for free (a ballot per vector and 64 rows); other kernels cannot
+// (hipErrorNotSupported: the caller transposes C itself).  A, C and side may be PINNED HOST blocks (gf2k_tallskinny_side's caller).
+static hipError_t tallskinny_impl(const u64 *A, long long lda, const u64 *B, long long ldb, u64 *C, long long ldc, int m, int l, int n,
+                                  int accumulate, u64 *side, long long side_ld, hipStream_t stream);
 extern "C" hipError_t gf2k_tallskinny(const u64 *A, long long lda, const u64 *B, long long ldb, u64 *C, long long ldc, int m,
                                       int l, int n, int accumulate, hipStream_t stream) {
+  return tallskinny_impl(A, lda, B, ldb, C, ldc, m, l, n, accumulate, nullptr, 0, stream);
+}
+extern "C" hipError_t gf2k_tallskinny_side(const u64 *A, long long lda, const u64 *B, long long ldb, u64 *C, long long ldc, int m,
+                                           int l, int n, u64 *side, long long side_ld, hipStream_t stream) {
+  if (!side || n > 4 || l > 256 || l <= 64) return hipErrorNotSupported;
+  return tallskinny_impl(A, lda, B, ldb, C, ldc, m, l, n, 0, side, side_ld, stream);
+}
+static hipError_t tallskinny_impl(const u64 *A, long long lda, const u64 *B, long long ldb, u64 *C, long long ldc, int m, int l, int n,
+                                  int accumulate, u64 *side, long long side_ld, hipStream_t stream) {
   if (m <= 0 || n <= 0) return hipSuccess;
   if (n > 256 || l <= 0) return hipErrorInvalidValue;
   const int nw = (n + 63) / 64;
@@ -3360,7 +3374,8 @@ extern "C" hipError_t gf2k_tallskinny(const u64 *A, long long lda, const u64 *B,
       while (rpt > 1 && ((long long)m + 256LL * rpt - 1) / (256LL * rpt) < vwant) rpt >>= 1;
       const unsigned grid = (unsigned)(((long long)m + 256LL * rpt - 1) / (256LL * rpt));
 #define GF2_LPNVEC_GO(NVV, RPTV, MODEV)                                                                                \
-  hipLaunchKernelGGL((gf2_lpnvec_kernel<NVV, 256, RPTV, MODEV, GF2_LPNVEC_STRIDED>), dim3(grid), dim3(256), 0, stream, A, lda, B, ldb, C, ldc, m, l, n, accumulate)
+  hipLaunchKernelGGL((gf2_lpnvec_kernel<NVV, 256, RPTV, MODEV, GF2_LPNVEC_STRIDED>), dim3(grid), dim3(256), 0, stream, A, lda, B, ldb, C, ldc, m, l, n, accumulate, \
+                     side, side_ld)
 #define GF2_LPNVEC_RPT(NVV, MODEV)                                                                                     \
   do {                                                                                                                 \
     if (rpt >= 4) GF2_LPNVEC_GO(NVV, 4, MODEV);                                                                        \

@@ -2179,6 +2179,16 @@ int result_side_rows(ResultSide *side, const gf2_dmat &c, int r0, hipStream_t s)
   return e == hipSuccess ? 0 : fail(e, "gf2k_transpose");
 }
 
+// One to four vectors against many rows of 65..256 bits: the table-free kernel packs the side copy itself (a ballot per vector and 64
+// rows), so product and transposed form are ONE launch.  1 = done, 0 = not this shape (the caller multiplies and transposes), < 0 error.
+bool thin_vector_shape(int m, int l, int n) { return n >= 1 && n <= 4 && l > 64 && l <= 256 && m >= 262144; }
+int thin_product_with_side(ResultSide *side, u64 *c, long long ldc, const u64 *a, long long lda, const gf2_dmat &b, int m, int l, hipStream_t s) {
+  if (!side || !thin_vector_shape(m, l, b.ncols)) return 0;
+  const hipError_t e = gf2k_tallskinny_side(a, lda, b.data, b.ld, c, ldc, m, l, b.ncols, reinterpret_cast<u64 *>(side->buf), (long long)side->ld, s);
+  if (e == hipErrorNotSupported) return 0;
+  return e == hipSuccess ? 1 : fail(e, "gf2k_tallskinny_side");
+}
+
 int host_mul_range(mzd_t *C, const mzd_t *A, const mzd_t *B, int r0, int r1, int accumulate, int algo, int param, hipStream_t s,
                    ResultSide *side = nullptr) {
   const int rows = r1 - r0;
@@ -2200,6 +2210,21 @@ int host_mul_range(mzd_t *C, const mzd_t *A, const mzd_t *B, int r0, int r1, int
   // Thin products (the LPN shape, 2^20 x 256 times a few vectors) are pipelined too: their kernels stream A at HBM rate, so the call
   // IS the upload of A (32 MiB: 0.56 ms) -- with row blocks the kernel and the download of C (8 MiB in M4RI's layout) hide behind it
   // instead of following it.
+  // `&A * &v` with A on the host (round 5): the vector kernel reads A from, and writes C and the side copy into, the PINNED host blocks
+  // themselves -- the launch IS the transfer (32 MiB in at the rate a kernel pulls over PCIe, 8 MiB out beside it), with no copy queue
+  // between its pieces: 2^20 x 256 x 1 0.69 ms for the product against 0.77 through uploads, kernel and downloads in two row blocks
+  // (profiles/r05_zero_copy_probe.txt; the side copy is what made it worth having: it used to need C on the device)
+  static const int zero_copy = dev_env_int("M4RI_HIP_THIN_ZERO_COPY", 1);
+  if (zero_copy && side && whole && !accumulate && plain_layout && thin_vector_shape(rows, A->ncols, B->ncols) && !cache_lookup(A) &&
+      gf2_mzd_block_is_pinned(A) && gf2_mzd_block_is_pinned(C) && (size_t)rows * A->rowstride * sizeof(word) >= ((size_t)8 << 20)) {
+    DMatOwner dB;
+    rc = to_device(dB, B, s, true);
+    int done = 0;
+    if (!rc) done = thin_product_with_side(side, C->rows[0], C->rowstride, A->rows[0], A->rowstride, dB.d, rows, A->ncols, s);
+    if (done < 0) rc = done;
+    if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = fail(hipGetLastError(), "thin product: stream");
+    if (rc || done == 1) return rc;
+  }
   const bool thin = B->ncols <= 256 && A->ncols <= 1024 && (size_t)rows * A->rowstride * sizeof(word) >= ((size_t)8 << 20);
   const bool big_pipelined = pipe_blocks >= 2 && !accumulate && plain_layout && rows >= 16384 && rows % (pipe_blocks * 64) == 0 &&
                              (long long)A->ncols * B->ncols >= (1ll << 28) && !(whole && cache_lookup(A));
@@ -2362,8 +2387,15 @@ int host_mul_range(mzd_t *C, const mzd_t *A, const mzd_t *B, int r0, int r1, int
     if (!rc) rc = to_device(dB, B, s, true);
     if (!rc) rc = to_device_rows(dC, C, r0, r1, s, accumulate != 0);
     // (thin products: no wait between the kernel and the download -- the download's own launch latency would be exposed behind it)
-    if (!rc) rc = mul_dispatch(&dC.d, &dA.d, &dB.d, accumulate, algo, param, s, /*sync_free=*/!(side || B->ncols <= 64));
-    if (!rc && side) {
+    int fused = 0;  // product and side copy in one launch (one to four vectors)
+    if (!rc && side && !accumulate) {
+      fused = thin_product_with_side(side, dC.d.data, dC.d.ld, dA.d.data, dA.d.ld, dB.d, rows, A->ncols, s);
+      if (fused < 0) rc = fused;
+    }
+    if (!rc && fused != 1) rc = mul_dispatch(&dC.d, &dA.d, &dB.d, accumulate, algo, param, s, /*sync_free=*/!(side || B->ncols <= 64));
+    if (!rc && side && fused == 1) {
+      rc = download_rows(C, r0, &dC.d, s);  // (syncs: the side copy is complete with it)
+    } else if (!rc && side) {
       // C comes down on the download stream while the compute stream transposes it and brings the small form down
       SideStream *sd = nullptr;
       rc = side_stream(s, 1, &sd, /*want_s3=*/true);

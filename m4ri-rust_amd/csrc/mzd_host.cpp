@@ -149,6 +149,8 @@ void *gf2_pinned_alloc(size_t bytes) {
   }
   return p;
 }
+// is the block of M pinned host memory (device-visible: a kernel may read or write it directly)?
+bool gf2_mzd_block_is_pinned(mzd_t const *M) { return M && M->blocks && M->padding[0] == kAllocPinned; }
 void gf2_pinned_free(void *p, size_t bytes) {
   if (p && !pin_pool_give(p, bytes, nullptr, 0, 0)) (void)hipHostFree(p);
 }

@@ -1119,7 +1119,7 @@ def test_operand_cache(pkg):
         del T
 
 
-@pytest.mark.parametrize("m,n", [(1 << 20, 1), (1 << 18, 3), (300032, 1), (1 << 17, 8), (200001, 2)])
+@pytest.mark.parametrize("m,n", [(1 << 20, 1), (1 << 18, 3), (300032, 1), (1 << 17, 8), (200001, 2), (300001, 2), (1 << 19, 4), (1 << 19, 5)])
 def test_result_side_copy(pkg, m, n):
     """A thin product into a NULL destination comes back with its packed transposed form beside it (m4ri_hip_api.cpp, ResultSide):
     mzd_transpose of that product is served from it and must equal the transposition of the bits the product holds -- for the
