@@ -271,10 +271,13 @@ void gf2_prof_enable(int on);
 int gf2_prof_read(int *launches, double *ms, int reset);
 
 /* Schedules of a large product on HOST matrices (upload / multiply / download pipelines), as the library's time model plays them
- * through: t_end[i] = modelled seconds of schedule i + 1 in M4RI_HIP_HOST_PLAN's numbering (1 row blocks of A and C; 2 / 3 / 4 slabs of
- * the inner dimension: four equal, 1/8 1/8 1/4 1/2, two halves; 5 / 6 two row groups through four / two slabs), -1 where a schedule
- * does not apply; returns the number of the schedule mzd_mul takes for this shape (0: not pipelined). */
-int gf2_host_plan_model(int m, int l, int n, int algo, int param, double t_end[6]);
+ * through: t_end[i] = modelled seconds of schedule i + 1 in M4RI_HIP_HOST_PLAN's numbering, -1 where a schedule does not apply:
+ *   1 row blocks of A and C;  2 / 3 / 4 slabs of the inner dimension (four equal; 1/8 1/8 1/4 1/2; two halves), the last slab in row
+ *   blocks;  5 / 6 two row groups, each through four equal slabs / two halves;  7 / 8 / 12 the first row group through slabs that grow
+ *   from 1/16 (a short lead-in while B arrives), the second through two halves / four quarters / the whole inner dimension;  9 / 10 the
+ *   first group through 1/8 1/8 1/4 1/2 / four equal slabs, the second through two halves;  11 one group through the growing slabs.
+ * Returns the number of the schedule mzd_mul takes for this shape (0: not pipelined). */
+int gf2_host_plan_model(int m, int l, int n, int algo, int param, double t_end[12]);
 
 /* Launch census: "<count> <mangled kernel name>\n" for every kernel of the library this process has launched so far, written to buf
  * (at most cap - 1 bytes and a terminator); returns the length of the whole text.  With M4RI_HIP_KERNEL_CENSUS_FILE=<path> in the

@@ -2076,16 +2076,18 @@ double host_product_model(int m, int l, int n, int algo, int param) {
 // Which one ends first depends on how compute and PCIe compare, so each candidate is played through with the planner's own time
 // model and the copy rate of the link (profiles/r05_slab_prices.txt has the measured sub-products).
 struct HostPlan {
-  std::vector<int> slabs;  // sizes of the slabs of the inner dimension in bits; empty: the row-block plan
-  int row_groups = 1;      // slab plans: the rows of A and C in this many groups, one group after the other through all slabs (a
-                           // finished group's rows of C leave while the next group is multiplied; sub-products of rows / 2 x l / 4
-                           // are no less efficient than all rows x l / 4: 32768^3 16384 x 8192 x 32768 0.64 ms against 1.24 for twice the rows)
+  // slab plans: gslabs[g] = the sizes (bits) of the slabs of the inner dimension through which row group g of A and C runs, one group
+  // after the other (a finished group's rows of C leave while the next group is multiplied; half-height sub-products are no less
+  // efficient: 32768^3 16384 x 8192 x 32768 0.64 ms against 1.24 for twice the rows).  The FIRST group's slabs also bring B in, so
+  // they start small (a short lead-in) and grow; later groups find B resident and take few, large slabs.  Empty: the row-block plan.
+  std::vector<std::vector<int>> gslabs;
   double t_end = 0;
 };
+constexpr int kHostPlanCandidates = 12;
 HostPlan plan_host_product(int rows, int l, int n, int algo, int param, bool b_resident, size_t a_row_bytes, size_t b_row_bytes, size_t c_row_bytes,
                            double *all_t_end = nullptr, int *chosen = nullptr) {
   static const double rate = (double)dev_env_int("M4RI_HIP_PCIE_GBS", 55) * 1e9;
-  // read per call (tests and A/B runs): 1 row blocks, 2 four equal slabs, 3 growing slabs, 4 two slabs, 5 / 6 two row groups x four / two slabs; 0 = by the model
+  // read per call (tests and A/B runs): the number of a candidate below (1 row blocks ... 12); 0 = by the model
   const int forced = env_int("M4RI_HIP_HOST_PLAN", 0);
   auto T = [&](int m_, int l_) { return host_product_model(m_, l_, n, algo, param); };
   const int NB = 4;
@@ -2122,20 +2124,18 @@ HostPlan plan_host_product(int rows, int l, int n, int algo, int param, bool b_r
     }
     rb.t_end = td;
   }
-  auto slab_plan = [&](const std::vector<int> &ks, int NR) {
+  auto slab_plan = [&](const std::vector<std::vector<int>> &gs) {
     HostPlan hp;
-    hp.slabs = ks;
-    hp.row_groups = NR;
-    const int rg = rows / NR;
+    hp.gslabs = gs;
+    const int NR = (int)gs.size(), rg = rows / NR;
     double up = 0, tc = 0, td = 0;
-    for (int g = 0; g < NR; ++g)
+    for (int g = 0; g < NR; ++g) {
+      const std::vector<int> &ks = gs[g];
       for (size_t si = 0; si < ks.size(); ++si) {
         up += ((double)rg * ks[si] / 8.0 + ((b_resident || g > 0) ? 0.0 : (double)ks[si] * b_row_bytes)) / rate;
-        if (si + 1 < ks.size()) {
+        if (si + 1 < ks.size() || g + 1 < NR) {
           tc = std::max(tc, up) + T(rg, ks[si]);
-        } else if (g + 1 < NR) {
-          tc = std::max(tc, up) + T(rg, ks[si]);
-          td = std::max(td, tc) + (double)rg * c_row_bytes / rate;
+          if (si + 1 == ks.size()) td = std::max(td, tc) + (double)rg * c_row_bytes / rate;
         } else {
           for (int b = 0; b < NB; ++b) {
             tc = std::max(tc, up) + T(rg / NB, ks[si]);
@@ -2143,30 +2143,41 @@ HostPlan plan_host_product(int rows, int l, int n, int algo, int param, bool b_r
           }
         }
       }
+    }
     hp.t_end = td;
     return hp;
   };
-  std::vector<HostPlan> cands{rb};
+  // the candidates, in the numbering of M4RI_HIP_HOST_PLAN (a candidate that does not apply to the shape keeps its number, t_end < 0)
   const bool slabs_ok = l % (8 * 1024) == 0 && l >= 16384 && rows % (NB * 64) == 0;
-  if (slabs_ok) {
-    cands.push_back(slab_plan({l / 4, l / 4, l / 4, l / 4}, 1));
-    cands.push_back(slab_plan({l / 8, l / 8, l / 4, l / 2}, 1));
-    cands.push_back(slab_plan({l / 2, l / 2}, 1));
-    if (rows % (2 * NB * 64) == 0 && rows / 2 >= 8192) {
-      cands.push_back(slab_plan({l / 4, l / 4, l / 4, l / 4}, 2));
-      cands.push_back(slab_plan({l / 2, l / 2}, 2));
-    }
-  }
+  const bool two_ok = slabs_ok && rows % (2 * NB * 64) == 0 && rows / 2 >= 8192;
+  const bool fine_ok = l % (16 * 1024) == 0;  // sixteenths of the inner dimension stay multiples of 1024 bits
+  const std::vector<int> E4{l / 4, l / 4, l / 4, l / 4}, H2{l / 2, l / 2}, W1{l}, G8{l / 8, l / 8, l / 4, l / 2},
+      G16{l / 16, l / 16, l / 8, l / 4, l / 4, l / 4};
+  HostPlan none;
+  none.t_end = -1.0;
+  std::vector<HostPlan> cands{rb};
+  cands.push_back(slabs_ok ? slab_plan({E4}) : none);                       // 2
+  cands.push_back(slabs_ok ? slab_plan({G8}) : none);                       // 3
+  cands.push_back(slabs_ok ? slab_plan({H2}) : none);                       // 4
+  cands.push_back(two_ok ? slab_plan({E4, E4}) : none);                     // 5
+  cands.push_back(two_ok ? slab_plan({H2, H2}) : none);                     // 6
+  cands.push_back(two_ok && fine_ok ? slab_plan({G16, H2}) : none);         // 7
+  cands.push_back(two_ok && fine_ok ? slab_plan({G16, E4}) : none);         // 8
+  cands.push_back(two_ok ? slab_plan({G8, H2}) : none);                     // 9
+  cands.push_back(two_ok ? slab_plan({E4, H2}) : none);                     // 10
+  cands.push_back(slabs_ok && fine_ok ? slab_plan({G16}) : none);           // 11
+  cands.push_back(two_ok && fine_ok ? slab_plan({G16, W1}) : none);         // 12
+  static_assert(kHostPlanCandidates == 12, "candidate list");
   if (all_t_end)
-    for (size_t i = 0; i < 6; ++i) all_t_end[i] = i < cands.size() ? cands[i].t_end : -1.0;
+    for (size_t i = 0; i < (size_t)kHostPlanCandidates; ++i) all_t_end[i] = i < cands.size() ? cands[i].t_end : -1.0;
   // the fastest slab plan by the model -- within half a percent the LATER candidate wins: two row groups measured 0.2-0.3 ms ahead
   // of their one-group twins where the model has them level (32768^3 7.9 against 8.2 ms, 65536^3 41.0 against 41.4; profiles/
   // r05_host_plan_ab.txt) --, taken if it promises 3 % over the row blocks
   size_t best = 0, bs = 0;
   for (size_t i = 1; i < cands.size(); ++i)
-    if (!bs || cands[i].t_end <= 1.005 * cands[bs].t_end) bs = i;
+    if (cands[i].t_end > 0 && (!bs || cands[i].t_end <= 1.005 * cands[bs].t_end)) bs = i;
   if (bs && cands[bs].t_end < 0.97 * cands[0].t_end) best = bs;
-  if (forced >= 1 && forced <= (int)cands.size()) best = (size_t)forced - 1;
+  if (forced >= 1 && forced <= (int)cands.size() && cands[(size_t)forced - 1].t_end > 0) best = (size_t)forced - 1;
   if (chosen) *chosen = (int)best + 1;
   return cands[best];
 }
@@ -2232,12 +2243,14 @@ int host_mul_range(mzd_t *C, const mzd_t *A, const mzd_t *B, int r0, int r1, int
   if (big_pipelined && pipe_blocks == 4 && B->rowstride >= 1 && !(B->flags & mzd_flag_windowed_zerooffset))
     hplan = plan_host_product(rows, A->ncols, B->ncols, algo, param, (bool)cache_lookup(B), (size_t)A->rowstride * sizeof(word),
                               (size_t)B->rowstride * sizeof(word), (size_t)C->rowstride * sizeof(word));
-  if (!hplan.slabs.empty()) {
+  if (!hplan.gslabs.empty()) {
     // ---- slabs of the inner dimension: C (+)= A[G, K_s] B[K_s, :] for every row group G in turn; a finished group's rows of C leave
     // while the next group is multiplied, the LAST group's last slab runs in four row blocks whose rows leave one by one ----
-    const int S = (int)hplan.slabs.size(), NR = hplan.row_groups, NBL = 4, RGr = rows / NR;
+    const int NR = (int)hplan.gslabs.size(), NBL = 4, RGr = rows / NR;
+    int nslabs = 0;
+    for (const auto &g : hplan.gslabs) nslabs += (int)g.size();
     SideStream *sd = nullptr;
-    rc = side_stream(s, NR * S + NR + NBL, &sd, /*want_s3=*/true);
+    rc = side_stream(s, nslabs + NR + NBL, &sd, /*want_s3=*/true);
     DMatOwner dA, dB, dC;
     const bool bcached = (bool)cache_lookup(B);
     if (!rc) rc = to_device(dB, B, sd->s2, bcached);  // a cached B is borrowed (nothing is copied); otherwise allocated here, uploaded by slabs
@@ -2245,17 +2258,17 @@ int host_mul_range(mzd_t *C, const mzd_t *A, const mzd_t *B, int r0, int r1, int
     if (!rc) rc = to_device_rows(dC, C, r0, r1, s, false);
     if (!rc && (dA.d.ld != A->rowstride || dC.d.ld != C->rowstride || (!bcached && dB.d.ld != B->rowstride)))
       rc = fail_msg("host pipeline: unexpected device stride");
-    hipEvent_t *evU = sd ? sd->ev.data() : nullptr, *evC = evU + NR * S;
+    hipEvent_t *evU = sd ? sd->ev.data() : nullptr, *evC = evU + nslabs;
     auto rows_bytes = [](const mzd_t *M, int nr) { return ((size_t)(nr - 1) * M->rowstride + M->width) * sizeof(word); };
-    for (int g = 0; !rc && g < NR; ++g) {  // every upload is queued at once: the next piece travels while this one is multiplied
+    for (int g = 0, ev = 0; !rc && g < NR; ++g) {  // every upload is queued at once: the next piece travels while this one is multiplied
       int k0 = 0;
-      for (int si = 0; !rc && si < S; ++si) {
-        const int ks = hplan.slabs[si];
+      for (size_t si = 0; !rc && si < hplan.gslabs[g].size(); ++si, ++ev) {
+        const int ks = hplan.gslabs[g][si];
         if (hipMemcpy2DAsync(dA.d.data + (size_t)g * RGr * dA.d.ld + k0 / 64, (size_t)dA.d.ld * sizeof(u64), A->rows[r0 + g * RGr] + k0 / 64,
                              (size_t)A->rowstride * sizeof(word), (size_t)ks / 8, (size_t)RGr, hipMemcpyHostToDevice, sd->s2) != hipSuccess ||
             (!bcached && g == 0 &&
              hipMemcpyAsync(dB.d.data + (size_t)k0 * dB.d.ld, B->rows[k0], rows_bytes(B, ks), hipMemcpyHostToDevice, sd->s2) != hipSuccess) ||
-            hipEventRecord(evU[g * S + si], sd->s2) != hipSuccess)
+            hipEventRecord(evU[ev], sd->s2) != hipSuccess)
           rc = fail(hipGetLastError(), "host pipeline: upload of a slab");
         k0 += ks;
       }
@@ -2267,11 +2280,12 @@ int host_mul_range(mzd_t *C, const mzd_t *A, const mzd_t *B, int r0, int r1, int
         rc = fail(hipGetLastError(), "host pipeline: download");
       ++nev_c;
     };
-    for (int g = 0; !rc && g < NR; ++g) {
+    for (int g = 0, ev = 0; !rc && g < NR; ++g) {
       int k0 = 0;
-      for (int si = 0; !rc && si < S; ++si) {
-        const int ks = hplan.slabs[si];
-        if (hipStreamWaitEvent(s, evU[g * S + si], 0) != hipSuccess) rc = fail(hipGetLastError(), "host pipeline: wait");
+      const int S = (int)hplan.gslabs[g].size();
+      for (int si = 0; !rc && si < S; ++si, ++ev) {
+        const int ks = hplan.gslabs[g][si];
+        if (hipStreamWaitEvent(s, evU[ev], 0) != hipSuccess) rc = fail(hipGetLastError(), "host pipeline: wait");
         gf2_dmat a = dA.d, b = dB.d, c = dC.d;
         a.data += (size_t)g * RGr * a.ld + k0 / 64;
         a.nrows = RGr;
@@ -2659,8 +2673,8 @@ extern "C" void gf2_mzd_uncache(mzd_t const *M) { gf2_cache_forget(M); }
 // The schedules a large product on HOST matrices can take, as the library's time model plays them through (plan_host_product):
 // t_end[i] = modelled seconds of schedule i + 1 in M4RI_HIP_HOST_PLAN's numbering (-1: not applicable to this shape); returns the
 // number of the schedule the host path takes (0: the product is not pipelined at all).  Plain row-major operands of the natural strides.
-extern "C" int gf2_host_plan_model(int m, int l, int n, int algo, int param, double t_end[6]) {
-  for (int i = 0; i < 6; ++i) t_end[i] = -1.0;
+extern "C" int gf2_host_plan_model(int m, int l, int n, int algo, int param, double t_end[12]) {
+  for (int i = 0; i < kHostPlanCandidates; ++i) t_end[i] = -1.0;
   if (m < 16384 || m % 256 || (long long)l * n < (1ll << 28)) return 0;
   auto stride = [](int c) { const size_t w = (size_t)(c + 63) / 64; return (w < 3 || (w & 1) == 0 ? w : w + 1) * sizeof(word); };
   int chosen = 0;

@@ -358,8 +358,9 @@ def test_packed_plain_product_2gib_operand(dev):
     assert np.array_equal(dev.mul(Aw, B, algo="m4rm").to_words(), C1.to_words()[r0:r0 + rows])
 
 
-@pytest.mark.parametrize("plan", [2, 3, 4, 5, 6, 0], ids=["four_equal_slabs", "growing_slabs", "two_slabs", "two_row_groups_x_four_slabs",
-                                                     "two_row_groups_x_two_slabs", "by_the_model"])
+@pytest.mark.parametrize("plan", [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 0],
+                         ids=["four_equal_slabs", "growing_slabs", "two_slabs", "two_row_groups_x_four_slabs", "two_row_groups_x_two_slabs", "fine_then_halves",
+                              "fine_then_quarters", "growing_then_halves", "quarters_then_halves", "fine_slabs", "fine_then_whole", "by_the_model"])
 @pytest.mark.parametrize("shape", [(16384, 16384, 16384 + 77), (16384 + 256, 32768, 8192 + 64)], ids=lambda s_: "x".join(map(str, s_)))
 def test_host_product_pipelined_over_slabs_of_the_inner_dimension(pkg, dev, shape, plan, monkeypatch):
     """Round 5: large host products may run as C ^= A[:, K] B[K, :] over slabs K of the inner dimension (A's slab uploaded by a 2-D

@@ -7,13 +7,13 @@ import m4ri_rust_amd as pkg
 L = pkg._lib.lib()
 for n in [int(a) for a in sys.argv[1:]] or [32768, 65536]:
     import ctypes
-    te = (ctypes.c_double * 6)()
+    te = (ctypes.c_double * 12)()
     os.environ["M4RI_HIP_HOST_PLAN"] = "0"
     ch = L.gf2_host_plan_model(n, n, n, 0, 0, te)
-    print("n=%d model: %s ms -> schedule %d" % (n, ", ".join("%d: %.2f" % (i + 1, te[i] * 1e3) for i in range(6)), ch), flush=True)
+    print("n=%d model: %s ms -> schedule %d" % (n, ", ".join("%d: %.2f" % (i + 1, te[i] * 1e3) for i in range(12) if te[i] > 0), ch), flush=True)
     A, B = pkg.BinMatrix.random(n, n), pkg.BinMatrix.random(n, n)
     C = pkg.BinMatrix.zero(n, n)
-    for plan in (1, 2, 3, 4, 5, 6, 0, 1, 0):
+    for plan in (1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 0, 1, 0):
         os.environ["M4RI_HIP_HOST_PLAN"] = str(plan)
         L.mzd_mul(C.mzd, A.mzd, B.mzd, 0)
         ts = []

@@ -32,7 +32,7 @@ DESCRIPTIONS = {
     "M4RI_HIP_ELIM_SPECULATE": "0: the trailing product of an elimination block waits for the block's record instead of being enqueued ahead of it",
     "M4RI_HIP_KERNEL_CENSUS_FILE": "path: the launch counts of the process (gf2_kernel_census) are appended to this file when the library is unloaded; the GPU test suite sets it so that kernels launched by its child processes count (tests/test_zz_kernel_census.py)",
     "M4RI_HIP_ELIM_FAULT": "test hook: 1 = update workgroup 0 of every look-ahead launch never raises its counters, so that the look-ahead workgroup's bounded wait runs out and the elimination reports the failure (tests/test_gpu_elim.py::test_lookahead_failure_is_reported_not_hung)",
-    "M4RI_HIP_HOST_PLAN": "schedule of a large product on host matrices: 0 = the one the time model ends first (default), 1 = row blocks of A and C, 2 / 3 / 4 = slabs of the inner dimension (four equal / 1/8 1/8 1/4 1/2 / two halves), 5 / 6 = two row groups, each through four / two slabs; the last slab of the last group in four row blocks; read per call (parity tests run every schedule)",
+    "M4RI_HIP_HOST_PLAN": "schedule of a large product on host matrices: 0 = the one the time model ends first (default), 1 = row blocks of A and C, 2-12 = the slab schedules in the numbering of gf2_host_plan_model (include/m4ri_hip.h); read per call (parity tests run every schedule)",
     "M4RI_HIP_M4RM_CFG": "force one tile-kernel variant (7, 8, 9-12, 20, 81, 82) for A/B runs; anything else is ignored with a message",
 }
 
