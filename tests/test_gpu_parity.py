@@ -1257,3 +1257,28 @@ def test_mul_nt_every_row_width(dev, l, n):
     assert np.array_equal(dev.mul_nt(A, Bt).to_words(), ref)
     if l > 64:  # unaligned rows: odd stride
         assert np.array_equal(dev.mul_nt(_strided(dev, a, l, (l + 63) // 64 | 1, offset_words=1), Bt).to_words(), ref)
+
+
+def test_result_side_copy_can_be_switched_off(pkg):
+    """M4RI_HIP_RESULT_SIDE_COLS=0 (the escape hatch for bindings that let users store into any matrix through
+    rows[]): no product carries a side copy, so even a store through rows[] WITHOUT gf2_mzd_uncache is seen by the next
+    mzd_transpose -- and the operator still gives the right bits, A uploaded or cached.  In a child process: the variable is read once."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')\n"
+              "import numpy as np, gf2util as g, m4ri_rust_amd as pkg\n"
+              "L = pkg._lib.lib(); m, l = 1 << 19, 256\n"
+              "a, x = g.random_words(m, l, 3), g.random_words(l, 1, 4)\n"
+              "A, X = pkg.BinMatrix.from_words(a, l), pkg.BinMatrix.from_words(x, 1)\n"
+              "ref = g.o_mul_naive(a, x, m, l, 1)\n"
+              "for cached in (False, True):\n"
+              "    if cached: A.cache_on_device()\n"
+              "    R = pkg.BinMatrix(L.mzd_mul_naive(None, A.mzd, X.mzd))\n"
+              "    assert np.array_equal(R.to_words(), ref)\n"
+              "    R._words_view()[11, 0] ^= np.uint64(1)   # a plain store, no gf2_mzd_uncache\n"
+              "    st = ref.copy(); st[11, 0] ^= np.uint64(1)\n"
+              "    assert np.array_equal(R.transposed().to_words(), g.o_transpose(st, m, 1))\n"
+              "print('OK')\n") % (root, root)
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=dict(os.environ, M4RI_HIP_RESULT_SIDE_COLS="0"), timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
