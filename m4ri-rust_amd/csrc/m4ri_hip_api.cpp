@@ -2200,230 +2200,290 @@ int thin_product_with_side(ResultSide *side, u64 *c, long long ldc, const u64 *a
   return e == hipSuccess ? 1 : fail(e, "gf2k_tallskinny_side");
 }
 
+// One device's share of a host product: C[r0:r1, :] (+)= A[r0:r1, :] * B on the CURRENT device, stream s.  Four ways to run it,
+// each a function below; host_mul_range picks.
+struct HostMulArgs {
+  mzd_t *C;
+  const mzd_t *A, *B;
+  int r0, r1, accumulate, algo, param;
+  hipStream_t s;
+  ResultSide *side;  // not null: the product is fresh (library-allocated) and thin: leave its packed transposed form here
+};
+
+// (a) Slabs of the inner dimension: C (+)= A[G, K_s] B[K_s, :] for every row group G in turn (plan_host_product chose the slab lists); a
+// finished group's rows of C leave while the next group is multiplied, the LAST group's last slab runs in four row blocks whose rows
+// leave one by one.
+int host_mul_slabs(const HostMulArgs &h, const HostPlan &hplan) {
+  mzd_t *const C = h.C;
+  const mzd_t *const A = h.A, *const B = h.B;
+  const int r0 = h.r0, r1 = h.r1, rows = h.r1 - h.r0, accumulate = h.accumulate, algo = h.algo, param = h.param;
+  const hipStream_t s = h.s;
+  ResultSide *const side = h.side;
+  int rc = 0;
+  (void)r0, (void)r1, (void)side, (void)accumulate, (void)algo, (void)param;
+  // ---- slabs of the inner dimension: C (+)= A[G, K_s] B[K_s, :] for every row group G in turn; a finished group's rows of C leave
+  // while the next group is multiplied, the LAST group's last slab runs in four row blocks whose rows leave one by one ----
+  const int NR = (int)hplan.gslabs.size(), NBL = 4, RGr = rows / NR;
+  int nslabs = 0;
+  for (const auto &g : hplan.gslabs) nslabs += (int)g.size();
+  SideStream *sd = nullptr;
+  rc = side_stream(s, nslabs + NR + NBL, &sd, /*want_s3=*/true);
+  DMatOwner dA, dB, dC;
+  const bool bcached = (bool)cache_lookup(B);
+  if (!rc) rc = to_device(dB, B, sd->s2, bcached);  // a cached B is borrowed (nothing is copied); otherwise allocated here, uploaded by slabs
+  if (!rc) rc = to_device_rows(dA, A, r0, r1, s, false);
+  if (!rc) rc = to_device_rows(dC, C, r0, r1, s, false);
+  if (!rc && (dA.d.ld != A->rowstride || dC.d.ld != C->rowstride || (!bcached && dB.d.ld != B->rowstride)))
+    rc = fail_msg("host pipeline: unexpected device stride");
+  hipEvent_t *evU = sd ? sd->ev.data() : nullptr, *evC = evU + nslabs;
+  auto rows_bytes = [](const mzd_t *M, int nr) { return ((size_t)(nr - 1) * M->rowstride + M->width) * sizeof(word); };
+  for (int g = 0, ev = 0; !rc && g < NR; ++g) {  // every upload is queued at once: the next piece travels while this one is multiplied
+    int k0 = 0;
+    for (size_t si = 0; !rc && si < hplan.gslabs[g].size(); ++si, ++ev) {
+      const int ks = hplan.gslabs[g][si];
+      if (hipMemcpy2DAsync(dA.d.data + (size_t)g * RGr * dA.d.ld + k0 / 64, (size_t)dA.d.ld * sizeof(u64), A->rows[r0 + g * RGr] + k0 / 64,
+                           (size_t)A->rowstride * sizeof(word), (size_t)ks / 8, (size_t)RGr, hipMemcpyHostToDevice, sd->s2) != hipSuccess ||
+          (!bcached && g == 0 &&
+           hipMemcpyAsync(dB.d.data + (size_t)k0 * dB.d.ld, B->rows[k0], rows_bytes(B, ks), hipMemcpyHostToDevice, sd->s2) != hipSuccess) ||
+          hipEventRecord(evU[ev], sd->s2) != hipSuccess)
+        rc = fail(hipGetLastError(), "host pipeline: upload of a slab");
+      k0 += ks;
+    }
+  }
+  int nev_c = 0;
+  auto download = [&](int row0, int nr, const gf2_dmat &c) {
+    if (hipEventRecord(evC[nev_c], s) != hipSuccess || hipStreamWaitEvent(sd->s3, evC[nev_c], 0) != hipSuccess ||
+        hipMemcpyAsync(C->rows[r0 + row0], c.data, rows_bytes(C, nr), hipMemcpyDeviceToHost, sd->s3) != hipSuccess)
+      rc = fail(hipGetLastError(), "host pipeline: download");
+    ++nev_c;
+  };
+  for (int g = 0, ev = 0; !rc && g < NR; ++g) {
+    int k0 = 0;
+    const int S = (int)hplan.gslabs[g].size();
+    for (int si = 0; !rc && si < S; ++si, ++ev) {
+      const int ks = hplan.gslabs[g][si];
+      if (hipStreamWaitEvent(s, evU[ev], 0) != hipSuccess) rc = fail(hipGetLastError(), "host pipeline: wait");
+      gf2_dmat a = dA.d, b = dB.d, c = dC.d;
+      a.data += (size_t)g * RGr * a.ld + k0 / 64;
+      a.nrows = RGr;
+      a.ncols = ks;
+      b.data += (size_t)k0 * b.ld;
+      b.nrows = ks;
+      c.data += (size_t)g * RGr * c.ld;
+      c.nrows = RGr;
+      if (si + 1 < S || g + 1 < NR) {
+        if (!rc) rc = mul_dispatch(&c, &a, &b, si > 0, algo, param, s, /*sync_free=*/false);
+        if (!rc && si + 1 == S) download(g * RGr, RGr, c);
+      } else {
+        for (int bl = 0; !rc && bl < NBL; ++bl) {
+          const int R = RGr / NBL;
+          gf2_dmat ab = a, cb = c;
+          ab.data += (size_t)bl * R * ab.ld;
+          ab.nrows = R;
+          cb.data += (size_t)bl * R * cb.ld;
+          cb.nrows = R;
+          rc = mul_dispatch(&cb, &ab, &b, si > 0, algo, param, s, /*sync_free=*/false);
+          if (!rc) download(g * RGr + bl * R, R, cb);
+        }
+      }
+      k0 += ks;
+    }
+  }
+  if (sd && hipStreamSynchronize(sd->s2) != hipSuccess && !rc) rc = fail(hipGetLastError(), "host pipeline: upload stream");
+  if (sd && sd->s3 && hipStreamSynchronize(sd->s3) != hipSuccess && !rc) rc = fail(hipGetLastError(), "host pipeline: download stream");
+  if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = fail(hipGetLastError(), "host pipeline: compute stream");
+  return rc;
+}
+
+// (b) Row blocks of A and C (contiguous rows) x halves of the inner dimension for the first block (contiguous rows of B):
+//   C_i = A_i[:, 0:l/2] * B[0:l/2, :]  ^  A_i[:, l/2:l] * B[l/2:l, :]
+// so that the first product can start after ONE block of A and HALF of B have arrived (7.3 ms of PCIe at n = 65536 instead of 12.2
+// with all of B first) and every transfer is one linear copy.  Upload order: A_0, B top, B bottom, A_1, ...  `thin`: the LPN shapes,
+// whose kernels stream A at HBM rate (the call IS the upload of A): two blocks, the second short.
+int host_mul_row_blocks(const HostMulArgs &h, bool thin, int pipe_blocks) {
+  mzd_t *const C = h.C;
+  const mzd_t *const A = h.A, *const B = h.B;
+  const int r0 = h.r0, r1 = h.r1, rows = h.r1 - h.r0, accumulate = h.accumulate, algo = h.algo, param = h.param;
+  const hipStream_t s = h.s;
+  ResultSide *const side = h.side;
+  int rc = 0;
+  (void)r0, (void)r1, (void)side, (void)accumulate, (void)algo, (void)param;
+  // Units: row blocks of A and C (contiguous rows) x halves of the inner dimension (contiguous rows of B):
+  //   C_i = A_i[:, 0:l/2] * B[0:l/2, :]  ^  A_i[:, l/2:l] * B[l/2:l, :]
+  // so that the first product can start after ONE block of A and HALF of B have arrived (7.3 ms of PCIe at n = 65536
+  // instead of 12.2 with all of B first) and every transfer is one linear copy.  Upload order: A_0, B top, B bottom, A_1, ...
+  const int l = A->ncols;
+  const bool bcached = (bool)cache_lookup(B);
+  const int K = (!bcached && l >= 8192 && l % 256 == 0 && B->rowstride >= 1 && !(B->flags & mzd_flag_windowed_zerooffset)) ? 2 : 1;
+  SideStream *sd = nullptr;
+  rc = side_stream(s, 2 * pipe_blocks + 3, &sd, /*want_s3=*/true);
+  DMatOwner dA, dB, dC;
+  if (!rc) rc = to_device(dB, B, sd->s2, K == 1);  // K == 2: allocated here, uploaded in halves below
+  if (!rc) rc = to_device_rows(dA, A, r0, r1, s, false);
+  if (!rc) rc = to_device_rows(dC, C, r0, r1, s, false);
+  // block boundaries: four equal blocks, or -- when a quarter still has 16384 rows -- a quarter, a half and a quarter: the
+  // half-size block multiplies at the rate of the big tiles (32768 x 32768 x 65536: 8.2 ms against 2 x 4.5 ms for two quarters)
+  // while the first and the last block stay short (quick start, short tail of the download)
+  std::vector<int> bnd;
+  {
+    const int q = rows / pipe_blocks;
+    if (pipe_blocks == 4 && q >= 16384 && !thin) bnd = {0, q, 3 * q, rows};
+    // a thin product is nothing but its copies: every block boundary costs ~20 us between two uploads, and what follows the last
+    // upload (~100 us of fixed latencies: event -> kernel 26, kernel -> copy 35, the copies' own ~9 each) is exposed -- so two blocks,
+    // the second short: 3/16 of the rows put the end of the first block's download where the second block's kernel ends
+    // (2^20 x 256 x 1 under the profiler: 793 us with four equal blocks, 763 with these two; unpipelined 800; profiles/r05_av_timeline.txt)
+    else if (thin && pipe_blocks == 4) bnd = {0, (int)((long long)rows * 13 / 16) & ~63, rows};
+    else
+      for (int i = 0; i <= pipe_blocks; ++i) bnd.push_back(i * q);
+  }
+  const int NBLK = (int)bnd.size() - 1;
+  auto rows_bytes = [](const mzd_t *M, int nr) { return ((size_t)(nr - 1) * M->rowstride + M->width) * sizeof(word); };
+  if (!rc && (dA.d.ld != A->rowstride || dC.d.ld != C->rowstride || (K == 2 && dB.d.ld != B->rowstride)))
+    rc = fail_msg("host pipeline: unexpected device stride");
+  hipEvent_t *evA = sd ? sd->ev.data() : nullptr, *evC = evA + pipe_blocks, *evB = evC + pipe_blocks;
+  auto upload_a = [&](int i) {
+    if (hipMemcpyAsync(dA.d.data + (size_t)bnd[i] * dA.d.ld, A->rows[r0 + bnd[i]], rows_bytes(A, bnd[i + 1] - bnd[i]), hipMemcpyHostToDevice,
+                       sd->s2) != hipSuccess ||
+        hipEventRecord(evA[i], sd->s2) != hipSuccess)
+      rc = fail(hipGetLastError(), "host pipeline: upload of A");
+  };
+  if (!rc) upload_a(0);
+  for (int k = 0; !rc && k < K; ++k) {  // K == 1: B went up whole above (or lives in the operand cache)
+    if (K == 2 && hipMemcpyAsync(dB.d.data + (size_t)k * (l / 2) * dB.d.ld, B->rows[k * (l / 2)], rows_bytes(B, l / 2), hipMemcpyHostToDevice,
+                                 sd->s2) != hipSuccess)
+      rc = fail(hipGetLastError(), "host pipeline: upload of B");
+    if (!rc && hipEventRecord(evB[k], sd->s2) != hipSuccess) rc = fail(hipGetLastError(), "host pipeline: event");
+  }
+  for (int i = 1; !rc && i < NBLK; ++i) upload_a(i);
+  for (int i = 0; !rc && i < NBLK; ++i) {
+    const int R = bnd[i + 1] - bnd[i];
+    gf2_dmat c = dC.d;
+    c.data += (size_t)bnd[i] * c.ld;
+    c.nrows = R;
+    if (hipStreamWaitEvent(s, evA[i], 0) != hipSuccess) rc = fail(hipGetLastError(), "host pipeline: wait");
+    // only the FIRST block is multiplied in halves of the inner dimension (it starts while the bottom half of B is still on the
+    // wire); by the time a later block has arrived all of B is resident, and one product over the whole inner dimension is the
+    // more efficient launch (65536^3: 2 x 16384 x 32768 x 65536 take 9.2 ms, 16384 x 65536 x 65536 takes 8.2)
+    const int Ki = i == 0 ? K : 1;
+    for (int k = 0; !rc && k < Ki; ++k) {
+      gf2_dmat a = dA.d, b = dB.d;
+      a.data += (size_t)bnd[i] * a.ld + (size_t)k * (l / Ki) / 64;
+      a.nrows = R;
+      a.ncols = l / Ki;
+      b.data += (size_t)k * (l / Ki) * b.ld;
+      b.nrows = l / Ki;
+      for (int kk = (Ki == 1 ? 0 : k); !rc && kk < (Ki == 1 ? K : k + 1); ++kk)
+        if (hipStreamWaitEvent(s, evB[kk], 0) != hipSuccess) rc = fail(hipGetLastError(), "host pipeline: wait");
+      if (!rc) rc = mul_dispatch(&c, &a, &b, k > 0, algo, param, s, /*sync_free=*/false);
+    }
+    if (!rc && (hipEventRecord(evC[i], s) != hipSuccess || hipStreamWaitEvent(sd->s3, evC[i], 0) != hipSuccess ||
+                hipMemcpyAsync(C->rows[r0 + bnd[i]], c.data, rows_bytes(C, R), hipMemcpyDeviceToHost, sd->s3) != hipSuccess))
+      rc = fail(hipGetLastError(), "host pipeline: download");
+    if (!rc && side) rc = result_side_rows(side, c, bnd[i], s);  // beside the block's download
+  }
+  if (sd && hipStreamSynchronize(sd->s2) != hipSuccess && !rc) rc = fail(hipGetLastError(), "host pipeline: upload stream");
+  if (sd && sd->s3 && hipStreamSynchronize(sd->s3) != hipSuccess && !rc) rc = fail(hipGetLastError(), "host pipeline: download stream");
+  if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = fail(hipGetLastError(), "host pipeline: compute stream");
+  return rc;
+}
+
+// (c) Everything up, one product, everything down (small products, windows, accumulating calls, operands the pipelines do not take).
+int host_mul_plain(const HostMulArgs &h) {
+  mzd_t *const C = h.C;
+  const mzd_t *const A = h.A, *const B = h.B;
+  const int r0 = h.r0, r1 = h.r1, rows = h.r1 - h.r0, accumulate = h.accumulate, algo = h.algo, param = h.param;
+  const hipStream_t s = h.s;
+  ResultSide *const side = h.side;
+  int rc = 0;
+  (void)r0, (void)r1, (void)side, (void)accumulate, (void)algo, (void)param;
+  DMatOwner dA, dB, dC;
+  rc = to_device_rows(dA, A, r0, r1, s, true);
+  if (!rc) rc = to_device(dB, B, s, true);
+  if (!rc) rc = to_device_rows(dC, C, r0, r1, s, accumulate != 0);
+  // (thin products: no wait between the kernel and the download -- the download's own launch latency would be exposed behind it)
+  int fused = 0;  // product and side copy in one launch (one to four vectors)
+  if (!rc && side && !accumulate) {
+    fused = thin_product_with_side(side, dC.d.data, dC.d.ld, dA.d.data, dA.d.ld, dB.d, rows, A->ncols, s);
+    if (fused < 0) rc = fused;
+  }
+  if (!rc && fused != 1) rc = mul_dispatch(&dC.d, &dA.d, &dB.d, accumulate, algo, param, s, /*sync_free=*/!(side || B->ncols <= 64));
+  if (!rc && side && fused == 1) {
+    rc = download_rows(C, r0, &dC.d, s);  // (syncs: the side copy is complete with it)
+  } else if (!rc && side) {
+    // C comes down on the download stream while the compute stream transposes it and brings the small form down
+    SideStream *sd = nullptr;
+    rc = side_stream(s, 1, &sd, /*want_s3=*/true);
+    if (!rc && (hipEventRecord(sd->ev[0], s) != hipSuccess || hipStreamWaitEvent(sd->s3, sd->ev[0], 0) != hipSuccess ||
+                hipMemcpyAsync(C->rows[r0], dC.d.data, ((size_t)(rows - 1) * C->rowstride + C->width) * sizeof(word), hipMemcpyDeviceToHost,
+                               sd->s3) != hipSuccess))
+      rc = fail(hipGetLastError(), "thin product: download");
+    if (!rc) rc = result_side_rows(side, dC.d, 0, s);
+    if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = fail(hipGetLastError(), "thin product: compute stream");
+    if (sd && sd->s3 && hipStreamSynchronize(sd->s3) != hipSuccess && !rc) rc = fail(hipGetLastError(), "thin product: download stream");
+  } else if (!rc) rc = download_rows(C, r0, &dC.d, s);
+  if (rc) (void)hipStreamSynchronize(s);
+  return rc;
+}
+
+// (d) `&A * &v` with A on the host (round 5): the vector kernel reads A from, and writes C and the side copy into, the PINNED host
+// blocks themselves -- the launch IS the transfer (32 MiB in at the rate a kernel pulls over PCIe, 8 MiB out beside it), with no copy
+// queue between its pieces: 2^20 x 256 x 1 0.69 ms for the product against 0.77 through uploads, kernel and downloads in two row
+// blocks (profiles/r05_zero_copy_probe.txt; the side copy is what made it worth having: it used to need C on the device).
+// 1 = done, 0 = not this case, < 0 error.
+int host_mul_zero_copy(const HostMulArgs &h) {
+  mzd_t *const C = h.C;
+  const mzd_t *const A = h.A, *const B = h.B;
+  const int r0 = h.r0, r1 = h.r1, rows = h.r1 - h.r0, accumulate = h.accumulate, algo = h.algo, param = h.param;
+  const hipStream_t s = h.s;
+  ResultSide *const side = h.side;
+  int rc = 0;
+  (void)r0, (void)r1, (void)side, (void)accumulate, (void)algo, (void)param;
+  DMatOwner dB;
+  rc = to_device(dB, B, s, true);
+  int done = 0;
+  if (!rc) done = thin_product_with_side(side, C->rows[0], C->rowstride, A->rows[0], A->rowstride, dB.d, rows, A->ncols, s);
+  if (done < 0) rc = done;
+  if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = fail(hipGetLastError(), "thin product: stream");
+  return rc ? rc : done;
+}
+
+// Returns when rows [r0, r1) of C are complete in host memory.
 int host_mul_range(mzd_t *C, const mzd_t *A, const mzd_t *B, int r0, int r1, int accumulate, int algo, int param, hipStream_t s,
                    ResultSide *side = nullptr) {
   const int rows = r1 - r0;
   if (rows <= 0) return 0;
-  int rc = 0;
-  // Large products are pipelined over row blocks of A and C: C[R,:] = A[R,:] B.  An upload stream brings B and the blocks
-  // of A in, a download stream takes the blocks of C out (PCIe is full duplex: the two directions get a stream each), the
-  // compute stream multiplies block i as soon as it has arrived -- PCIe is most of a host call: 1.5 GiB at n = 65536.
+  const HostMulArgs h{C, A, B, r0, r1, accumulate, algo, param, s, side};
+  // Large products are pipelined: an upload stream brings the operands in, a download stream takes C out (PCIe is full duplex: the two
+  // directions get a stream each), the compute stream multiplies a piece as soon as it has arrived -- PCIe is most of a host call:
+  // 1.5 GiB at n = 65536.
   static const int pipe_blocks = env_int("M4RI_HIP_HOST_PIPELINE_BLOCKS", 4);  // (2 blocks at 32768 / 16384 rows measured slower: 9.7 / 2.1 against 9.0 / 1.9 ms)
   const bool plain_layout = !(A->flags & mzd_flag_windowed_zerooffset) && !(C->flags & mzd_flag_windowed_zerooffset) &&
                             A->rowstride >= 1 && C->rowstride >= 1;
   const bool whole = r0 == 0 && r1 == A->nrows;
   // (Round 4 measured a 2 x 2 plan for mid-sized products -- the four quadrants of C as units, A in two row blocks, B in two
-  // column panels by 2-D copies, upload order A_0, B_0, B_1, A_1 -- against the row blocks below at 32768^3: 8.6 against 8.8 ms.
+  // column panels by 2-D copies, upload order A_0, B_0, B_1, A_1 -- against the row blocks at 32768^3: 8.6 against 8.8 ms.
   // The 2-D copies run at the linear rate (hipMemcpy2DAsync, 2 KiB rows: 54 GB/s), but a 16384 x 32768 x 16384 quadrant takes
   // 1.33-1.40 ms -- 49 leaves = 392 tiles = 1.5 rounds, run as a whole round plus a tail launch -- where a quarter of the whole
   // product's time would be 1.1: four of them are 5.5 ms of device work behind the 2.4 ms the first two pieces take to arrive.
-  // Not kept: the floor of either decomposition is the rate of its sub-products, profiles/r04_host_path_timeline.txt.)
-  // Thin products (the LPN shape, 2^20 x 256 times a few vectors) are pipelined too: their kernels stream A at HBM rate, so the call
-  // IS the upload of A (32 MiB: 0.56 ms) -- with row blocks the kernel and the download of C (8 MiB in M4RI's layout) hide behind it
-  // instead of following it.
-  // `&A * &v` with A on the host (round 5): the vector kernel reads A from, and writes C and the side copy into, the PINNED host blocks
-  // themselves -- the launch IS the transfer (32 MiB in at the rate a kernel pulls over PCIe, 8 MiB out beside it), with no copy queue
-  // between its pieces: 2^20 x 256 x 1 0.69 ms for the product against 0.77 through uploads, kernel and downloads in two row blocks
-  // (profiles/r05_zero_copy_probe.txt; the side copy is what made it worth having: it used to need C on the device)
+  // Not kept: profiles/r04_host_path_timeline.txt.)
   static const int zero_copy = dev_env_int("M4RI_HIP_THIN_ZERO_COPY", 1);
   if (zero_copy && side && whole && !accumulate && plain_layout && thin_vector_shape(rows, A->ncols, B->ncols) && !cache_lookup(A) &&
       gf2_mzd_block_is_pinned(A) && gf2_mzd_block_is_pinned(C) && (size_t)rows * A->rowstride * sizeof(word) >= ((size_t)8 << 20)) {
-    DMatOwner dB;
-    rc = to_device(dB, B, s, true);
-    int done = 0;
-    if (!rc) done = thin_product_with_side(side, C->rows[0], C->rowstride, A->rows[0], A->rowstride, dB.d, rows, A->ncols, s);
-    if (done < 0) rc = done;
-    if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = fail(hipGetLastError(), "thin product: stream");
-    if (rc || done == 1) return rc;
+    const int done = host_mul_zero_copy(h);
+    if (done != 0) return done < 0 ? done : 0;
   }
+  // thin products (the LPN shape, 2^20 x 256 times a few vectors) are pipelined too
   const bool thin = B->ncols <= 256 && A->ncols <= 1024 && (size_t)rows * A->rowstride * sizeof(word) >= ((size_t)8 << 20);
-  const bool big_pipelined = pipe_blocks >= 2 && !accumulate && plain_layout && rows >= 16384 && rows % (pipe_blocks * 64) == 0 &&
-                             (long long)A->ncols * B->ncols >= (1ll << 28) && !(whole && cache_lookup(A));
-  HostPlan hplan;
-  if (big_pipelined && pipe_blocks == 4 && B->rowstride >= 1 && !(B->flags & mzd_flag_windowed_zerooffset))
-    hplan = plan_host_product(rows, A->ncols, B->ncols, algo, param, (bool)cache_lookup(B), (size_t)A->rowstride * sizeof(word),
-                              (size_t)B->rowstride * sizeof(word), (size_t)C->rowstride * sizeof(word));
-  if (!hplan.gslabs.empty()) {
-    // ---- slabs of the inner dimension: C (+)= A[G, K_s] B[K_s, :] for every row group G in turn; a finished group's rows of C leave
-    // while the next group is multiplied, the LAST group's last slab runs in four row blocks whose rows leave one by one ----
-    const int NR = (int)hplan.gslabs.size(), NBL = 4, RGr = rows / NR;
-    int nslabs = 0;
-    for (const auto &g : hplan.gslabs) nslabs += (int)g.size();
-    SideStream *sd = nullptr;
-    rc = side_stream(s, nslabs + NR + NBL, &sd, /*want_s3=*/true);
-    DMatOwner dA, dB, dC;
-    const bool bcached = (bool)cache_lookup(B);
-    if (!rc) rc = to_device(dB, B, sd->s2, bcached);  // a cached B is borrowed (nothing is copied); otherwise allocated here, uploaded by slabs
-    if (!rc) rc = to_device_rows(dA, A, r0, r1, s, false);
-    if (!rc) rc = to_device_rows(dC, C, r0, r1, s, false);
-    if (!rc && (dA.d.ld != A->rowstride || dC.d.ld != C->rowstride || (!bcached && dB.d.ld != B->rowstride)))
-      rc = fail_msg("host pipeline: unexpected device stride");
-    hipEvent_t *evU = sd ? sd->ev.data() : nullptr, *evC = evU + nslabs;
-    auto rows_bytes = [](const mzd_t *M, int nr) { return ((size_t)(nr - 1) * M->rowstride + M->width) * sizeof(word); };
-    for (int g = 0, ev = 0; !rc && g < NR; ++g) {  // every upload is queued at once: the next piece travels while this one is multiplied
-      int k0 = 0;
-      for (size_t si = 0; !rc && si < hplan.gslabs[g].size(); ++si, ++ev) {
-        const int ks = hplan.gslabs[g][si];
-        if (hipMemcpy2DAsync(dA.d.data + (size_t)g * RGr * dA.d.ld + k0 / 64, (size_t)dA.d.ld * sizeof(u64), A->rows[r0 + g * RGr] + k0 / 64,
-                             (size_t)A->rowstride * sizeof(word), (size_t)ks / 8, (size_t)RGr, hipMemcpyHostToDevice, sd->s2) != hipSuccess ||
-            (!bcached && g == 0 &&
-             hipMemcpyAsync(dB.d.data + (size_t)k0 * dB.d.ld, B->rows[k0], rows_bytes(B, ks), hipMemcpyHostToDevice, sd->s2) != hipSuccess) ||
-            hipEventRecord(evU[ev], sd->s2) != hipSuccess)
-          rc = fail(hipGetLastError(), "host pipeline: upload of a slab");
-        k0 += ks;
-      }
-    }
-    int nev_c = 0;
-    auto download = [&](int row0, int nr, const gf2_dmat &c) {
-      if (hipEventRecord(evC[nev_c], s) != hipSuccess || hipStreamWaitEvent(sd->s3, evC[nev_c], 0) != hipSuccess ||
-          hipMemcpyAsync(C->rows[r0 + row0], c.data, rows_bytes(C, nr), hipMemcpyDeviceToHost, sd->s3) != hipSuccess)
-        rc = fail(hipGetLastError(), "host pipeline: download");
-      ++nev_c;
-    };
-    for (int g = 0, ev = 0; !rc && g < NR; ++g) {
-      int k0 = 0;
-      const int S = (int)hplan.gslabs[g].size();
-      for (int si = 0; !rc && si < S; ++si, ++ev) {
-        const int ks = hplan.gslabs[g][si];
-        if (hipStreamWaitEvent(s, evU[ev], 0) != hipSuccess) rc = fail(hipGetLastError(), "host pipeline: wait");
-        gf2_dmat a = dA.d, b = dB.d, c = dC.d;
-        a.data += (size_t)g * RGr * a.ld + k0 / 64;
-        a.nrows = RGr;
-        a.ncols = ks;
-        b.data += (size_t)k0 * b.ld;
-        b.nrows = ks;
-        c.data += (size_t)g * RGr * c.ld;
-        c.nrows = RGr;
-        if (si + 1 < S || g + 1 < NR) {
-          if (!rc) rc = mul_dispatch(&c, &a, &b, si > 0, algo, param, s, /*sync_free=*/false);
-          if (!rc && si + 1 == S) download(g * RGr, RGr, c);
-        } else {
-          for (int bl = 0; !rc && bl < NBL; ++bl) {
-            const int R = RGr / NBL;
-            gf2_dmat ab = a, cb = c;
-            ab.data += (size_t)bl * R * ab.ld;
-            ab.nrows = R;
-            cb.data += (size_t)bl * R * cb.ld;
-            cb.nrows = R;
-            rc = mul_dispatch(&cb, &ab, &b, si > 0, algo, param, s, /*sync_free=*/false);
-            if (!rc) download(g * RGr + bl * R, R, cb);
-          }
-        }
-        k0 += ks;
-      }
-    }
-    if (sd && hipStreamSynchronize(sd->s2) != hipSuccess && !rc) rc = fail(hipGetLastError(), "host pipeline: upload stream");
-    if (sd && sd->s3 && hipStreamSynchronize(sd->s3) != hipSuccess && !rc) rc = fail(hipGetLastError(), "host pipeline: download stream");
-    if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = fail(hipGetLastError(), "host pipeline: compute stream");
-    return rc;
+  const bool pipelined = pipe_blocks >= 2 && !accumulate && plain_layout && rows >= 16384 && rows % (pipe_blocks * 64) == 0 &&
+                         !(whole && cache_lookup(A));
+  const bool big = (long long)A->ncols * B->ncols >= (1ll << 28);
+  if (pipelined && big && pipe_blocks == 4 && B->rowstride >= 1 && !(B->flags & mzd_flag_windowed_zerooffset)) {
+    const HostPlan hplan = plan_host_product(rows, A->ncols, B->ncols, algo, param, (bool)cache_lookup(B), (size_t)A->rowstride * sizeof(word),
+                                             (size_t)B->rowstride * sizeof(word), (size_t)C->rowstride * sizeof(word));
+    if (!hplan.gslabs.empty()) return host_mul_slabs(h, hplan);
   }
-  if (pipe_blocks >= 2 && !accumulate && plain_layout && rows >= 16384 && rows % (pipe_blocks * 64) == 0 &&
-      ((long long)A->ncols * B->ncols >= (1ll << 28) || thin) && !(whole && cache_lookup(A))) {
-    // Units: row blocks of A and C (contiguous rows) x halves of the inner dimension (contiguous rows of B):
-    //   C_i = A_i[:, 0:l/2] * B[0:l/2, :]  ^  A_i[:, l/2:l] * B[l/2:l, :]
-    // so that the first product can start after ONE block of A and HALF of B have arrived (7.3 ms of PCIe at n = 65536
-    // instead of 12.2 with all of B first) and every transfer is one linear copy.  Upload order: A_0, B top, B bottom, A_1, ...
-    const int l = A->ncols;
-    const bool bcached = (bool)cache_lookup(B);
-    const int K = (!bcached && l >= 8192 && l % 256 == 0 && B->rowstride >= 1 && !(B->flags & mzd_flag_windowed_zerooffset)) ? 2 : 1;
-    SideStream *sd = nullptr;
-    rc = side_stream(s, 2 * pipe_blocks + 3, &sd, /*want_s3=*/true);
-    DMatOwner dA, dB, dC;
-    if (!rc) rc = to_device(dB, B, sd->s2, K == 1);  // K == 2: allocated here, uploaded in halves below
-    if (!rc) rc = to_device_rows(dA, A, r0, r1, s, false);
-    if (!rc) rc = to_device_rows(dC, C, r0, r1, s, false);
-    // block boundaries: four equal blocks, or -- when a quarter still has 16384 rows -- a quarter, a half and a quarter: the
-    // half-size block multiplies at the rate of the big tiles (32768 x 32768 x 65536: 8.2 ms against 2 x 4.5 ms for two quarters)
-    // while the first and the last block stay short (quick start, short tail of the download)
-    std::vector<int> bnd;
-    {
-      const int q = rows / pipe_blocks;
-      if (pipe_blocks == 4 && q >= 16384 && !thin) bnd = {0, q, 3 * q, rows};
-      // a thin product is nothing but its copies: every block boundary costs ~20 us between two uploads, and what follows the last
-      // upload (~100 us of fixed latencies: event -> kernel 26, kernel -> copy 35, the copies' own ~9 each) is exposed -- so two blocks,
-      // the second short: 3/16 of the rows put the end of the first block's download where the second block's kernel ends
-      // (2^20 x 256 x 1 under the profiler: 793 us with four equal blocks, 763 with these two; unpipelined 800; profiles/r05_av_timeline.txt)
-      else if (thin && pipe_blocks == 4) bnd = {0, (int)((long long)rows * 13 / 16) & ~63, rows};
-      else
-        for (int i = 0; i <= pipe_blocks; ++i) bnd.push_back(i * q);
-    }
-    const int NBLK = (int)bnd.size() - 1;
-    auto rows_bytes = [](const mzd_t *M, int nr) { return ((size_t)(nr - 1) * M->rowstride + M->width) * sizeof(word); };
-    if (!rc && (dA.d.ld != A->rowstride || dC.d.ld != C->rowstride || (K == 2 && dB.d.ld != B->rowstride)))
-      rc = fail_msg("host pipeline: unexpected device stride");
-    hipEvent_t *evA = sd ? sd->ev.data() : nullptr, *evC = evA + pipe_blocks, *evB = evC + pipe_blocks;
-    auto upload_a = [&](int i) {
-      if (hipMemcpyAsync(dA.d.data + (size_t)bnd[i] * dA.d.ld, A->rows[r0 + bnd[i]], rows_bytes(A, bnd[i + 1] - bnd[i]), hipMemcpyHostToDevice,
-                         sd->s2) != hipSuccess ||
-          hipEventRecord(evA[i], sd->s2) != hipSuccess)
-        rc = fail(hipGetLastError(), "host pipeline: upload of A");
-    };
-    if (!rc) upload_a(0);
-    for (int k = 0; !rc && k < K; ++k) {  // K == 1: B went up whole above (or lives in the operand cache)
-      if (K == 2 && hipMemcpyAsync(dB.d.data + (size_t)k * (l / 2) * dB.d.ld, B->rows[k * (l / 2)], rows_bytes(B, l / 2), hipMemcpyHostToDevice,
-                                   sd->s2) != hipSuccess)
-        rc = fail(hipGetLastError(), "host pipeline: upload of B");
-      if (!rc && hipEventRecord(evB[k], sd->s2) != hipSuccess) rc = fail(hipGetLastError(), "host pipeline: event");
-    }
-    for (int i = 1; !rc && i < NBLK; ++i) upload_a(i);
-    for (int i = 0; !rc && i < NBLK; ++i) {
-      const int R = bnd[i + 1] - bnd[i];
-      gf2_dmat c = dC.d;
-      c.data += (size_t)bnd[i] * c.ld;
-      c.nrows = R;
-      if (hipStreamWaitEvent(s, evA[i], 0) != hipSuccess) rc = fail(hipGetLastError(), "host pipeline: wait");
-      // only the FIRST block is multiplied in halves of the inner dimension (it starts while the bottom half of B is still on the
-      // wire); by the time a later block has arrived all of B is resident, and one product over the whole inner dimension is the
-      // more efficient launch (65536^3: 2 x 16384 x 32768 x 65536 take 9.2 ms, 16384 x 65536 x 65536 takes 8.2)
-      const int Ki = i == 0 ? K : 1;
-      for (int k = 0; !rc && k < Ki; ++k) {
-        gf2_dmat a = dA.d, b = dB.d;
-        a.data += (size_t)bnd[i] * a.ld + (size_t)k * (l / Ki) / 64;
-        a.nrows = R;
-        a.ncols = l / Ki;
-        b.data += (size_t)k * (l / Ki) * b.ld;
-        b.nrows = l / Ki;
-        for (int kk = (Ki == 1 ? 0 : k); !rc && kk < (Ki == 1 ? K : k + 1); ++kk)
-          if (hipStreamWaitEvent(s, evB[kk], 0) != hipSuccess) rc = fail(hipGetLastError(), "host pipeline: wait");
-        if (!rc) rc = mul_dispatch(&c, &a, &b, k > 0, algo, param, s, /*sync_free=*/false);
-      }
-      if (!rc && (hipEventRecord(evC[i], s) != hipSuccess || hipStreamWaitEvent(sd->s3, evC[i], 0) != hipSuccess ||
-                  hipMemcpyAsync(C->rows[r0 + bnd[i]], c.data, rows_bytes(C, R), hipMemcpyDeviceToHost, sd->s3) != hipSuccess))
-        rc = fail(hipGetLastError(), "host pipeline: download");
-      if (!rc && side) rc = result_side_rows(side, c, bnd[i], s);  // beside the block's download
-    }
-    if (sd && hipStreamSynchronize(sd->s2) != hipSuccess && !rc) rc = fail(hipGetLastError(), "host pipeline: upload stream");
-    if (sd && sd->s3 && hipStreamSynchronize(sd->s3) != hipSuccess && !rc) rc = fail(hipGetLastError(), "host pipeline: download stream");
-    if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = fail(hipGetLastError(), "host pipeline: compute stream");
-  } else {
-    DMatOwner dA, dB, dC;
-    rc = to_device_rows(dA, A, r0, r1, s, true);
-    if (!rc) rc = to_device(dB, B, s, true);
-    if (!rc) rc = to_device_rows(dC, C, r0, r1, s, accumulate != 0);
-    // (thin products: no wait between the kernel and the download -- the download's own launch latency would be exposed behind it)
-    int fused = 0;  // product and side copy in one launch (one to four vectors)
-    if (!rc && side && !accumulate) {
-      fused = thin_product_with_side(side, dC.d.data, dC.d.ld, dA.d.data, dA.d.ld, dB.d, rows, A->ncols, s);
-      if (fused < 0) rc = fused;
-    }
-    if (!rc && fused != 1) rc = mul_dispatch(&dC.d, &dA.d, &dB.d, accumulate, algo, param, s, /*sync_free=*/!(side || B->ncols <= 64));
-    if (!rc && side && fused == 1) {
-      rc = download_rows(C, r0, &dC.d, s);  // (syncs: the side copy is complete with it)
-    } else if (!rc && side) {
-      // C comes down on the download stream while the compute stream transposes it and brings the small form down
-      SideStream *sd = nullptr;
-      rc = side_stream(s, 1, &sd, /*want_s3=*/true);
-      if (!rc && (hipEventRecord(sd->ev[0], s) != hipSuccess || hipStreamWaitEvent(sd->s3, sd->ev[0], 0) != hipSuccess ||
-                  hipMemcpyAsync(C->rows[r0], dC.d.data, ((size_t)(rows - 1) * C->rowstride + C->width) * sizeof(word), hipMemcpyDeviceToHost,
-                                 sd->s3) != hipSuccess))
-        rc = fail(hipGetLastError(), "thin product: download");
-      if (!rc) rc = result_side_rows(side, dC.d, 0, s);
-      if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = fail(hipGetLastError(), "thin product: compute stream");
-      if (sd && sd->s3 && hipStreamSynchronize(sd->s3) != hipSuccess && !rc) rc = fail(hipGetLastError(), "thin product: download stream");
-    } else if (!rc) rc = download_rows(C, r0, &dC.d, s);
-    if (rc) (void)hipStreamSynchronize(s);
-  }
-  return rc;
+  if (pipelined && (big || thin)) return host_mul_row_blocks(h, thin, pipe_blocks);
+  return host_mul_plain(h);
 }
 
 // Devices a host product of this shape is spread over.  M4RI_HIP_DEVICES: unset = the current device only (the fan-out is
