@@ -1282,3 +1282,35 @@ def test_result_side_copy_can_be_switched_off(pkg):
               "print('OK')\n") % (root, root)
     r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=dict(os.environ, M4RI_HIP_RESULT_SIDE_COLS="0"), timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_lpn_operator_from_several_host_threads(pkg):
+    """`BinMatrix: Send + Sync` (binary_matrix.rs:38-39): four host threads run the reference's LPN operator `&A * &v` at once -- one shared
+    A (uploaded per call: the zero-copy vector kernel; then cached on the device), every thread its own vectors --, so the side copies,
+    the pooled pinned blocks with their row-pointer arrays and the per-thread streams are exercised concurrently; every result is
+    checked against the oracle."""
+    import threading
+    m, l = 1 << 19, 256
+    a = g.random_words(m, l, 3)
+    A = pkg.BinMatrix.from_words(a, l)
+    nthreads, per = 4, 6
+    xs = [[g.random_words(1, l, 100 + 10 * t + i) for i in range(per)] for t in range(nthreads)]
+    want = [[g.o_transpose(g.o_mul_naive(a, g.o_transpose(x, 1, l), m, l, 1), m, 1)[0] for x in row] for row in xs]
+    for cached in (False, True):
+        if cached:
+            A.cache_on_device()
+        bad = []
+
+        def worker(t):
+            for i in range(per):
+                got = A * pkg.BinVector(xs[t][i][0], l)
+                if len(got) != m or not np.array_equal(np.asarray(got.get_storage(), dtype=np.uint64), want[t][i]):
+                    bad.append((t, i))
+
+        ts = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
+        for t_ in ts:
+            t_.start()
+        for t_ in ts:
+            t_.join()
+        assert not bad, (cached, bad)
+    A.uncache()
