@@ -28,6 +28,7 @@
 #include <atomic>
 
 typedef uint64_t u64;
+typedef uint32_t u32;
 
 __device__ __forceinline__ u64 shfl64(u64 v, int src) {
   const unsigned lo = (unsigned)__shfl((int)(unsigned)v, src), hi = (unsigned)__shfl((int)(unsigned)(v >> 32), src);
@@ -48,6 +49,41 @@ __device__ __forceinline__ u64 rdlane64(u64 v, int lane) {  // lane must be wave
 }
 __device__ __forceinline__ int rdlane32(int v, int lane) {
   return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(lane));
+}
+
+// Where does a fused step's time go?  (tools/elim_stamps.py, development builds only.)  When set, thread 0 of the look-ahead workgroup adds
+// the shader cycles of its stages to stamps[0..7] (launch start -> every update workgroup has rewritten the next column -> first
+// pass's candidates loaded -> basis complete -> every update workgroup done -> published) and counts the steps in stamps[8].
+#ifdef GF2K_DEV_VARIANTS
+__device__ unsigned long long *gf2k_elim_stamps;
+extern "C" hipError_t gf2k_dev_set_elim_stamps(unsigned long long *p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(gf2k_elim_stamps), &p, sizeof(p));
+}
+#define ELIM_STAMP(k)                                                                  \
+  do {                                                                                 \
+    if (COH && gf2k_elim_stamps && threadIdx.x == 0) {                                 \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime();                    \
+      gf2k_elim_stamps[k] += now_ - gf2k_elim_stamps[15];                              \
+      gf2k_elim_stamps[15] = now_;                                                     \
+    }                                                                                  \
+  } while (0)
+#else
+#define ELIM_STAMP(k) do { } while (0)
+#endif
+
+// Six registers' slot `lane_sel` := six scalar values (v_writelane_b32; this clang has no builtin for it).  VOP3 takes ONE scalar register
+// on gfx9, so the lane select goes through M0, saved and restored inside the statement (M0 is the compiler's).  The scalar operands come
+// from the scalar unit or from v_readlane many instructions earlier: no wait state is owed (the 4-state rule is about a lane select
+// written by the vector unit).
+__device__ __forceinline__ void elim_writelane6(u32 &v0, u32 &v1, u32 &v2, u32 &v3, int &v4, int &v5, u32 s0, u32 s1, u32 s2, u32 s3, int s4,
+                                                int s5, int lane_sel) {
+  unsigned keep;
+  asm("s_mov_b32 %6, m0\n\ts_mov_b32 m0, %13\n\t"
+      "v_writelane_b32 %0, %7, m0\n\tv_writelane_b32 %1, %8, m0\n\tv_writelane_b32 %2, %9, m0\n\t"
+      "v_writelane_b32 %3, %10, m0\n\tv_writelane_b32 %4, %11, m0\n\tv_writelane_b32 %5, %12, m0\n\t"
+      "s_mov_b32 m0, %6"
+      : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "=&s"(keep)
+      : "s"(s0), "s"(s1), "s"(s2), "s"(s3), "s"(s4), "s"(s5), "s"(lane_sel));
 }
 
 // shared state of the pivot search (one workgroup): a member of the calling kernel's LDS
@@ -93,6 +129,7 @@ __device__ __forceinline__ bool elim_pivot_step(ElimPivotShared &sm, const u64 *
   if (tid < 256) s_chosen[tid] = 0;
   unsigned char f0 = 1;                                // flag of row scan0 + tid before this step (first pass, tid < 256)
   __syncthreads();
+  ELIM_STAMP(1);  // (after the wait for the next column)
   // the first pass looks at 256 rows only (one wave per SIMD: nearly always enough for 64 pivots, and the waves that
   // re-reduce their candidates after the first wave's insertions do not compete for issue slots); then 1024 per pass
   int csz = 256;
@@ -105,26 +142,42 @@ __device__ __forceinline__ bool elim_pivot_step(ElimPivotShared &sm, const u64 *
     const u64 wraw = inr ? elim_ld<COH>(A + (long long)i * lda + wc) : 0;
     if (base == scan0) f0 = fl;
     u64 w = fl == 0 ? (wraw & colmask) : 0, t = 0;
+#ifdef GF2K_DEV_VARIANTS
+    if (base == scan0) {
+      asm volatile("" : "+v"(w));  // (the stamp stands behind the arrival of the candidates)
+      ELIM_STAMP(2);
+    }
+#endif
     int done = 0;  // basis vectors already applied to w
     for (;;) {
       const int nb = s_nb;
       if (nb == 64) break;  // uniform over the workgroup
-      if (done < nb && __ballot(w != 0)) {  // basis vector `lane` in registers, broadcast by v_readlane
-        const u64 mw = b_word[lane], mt = b_trk[lane];
-        const int mc = b_col[lane];
+      if (done < nb && __ballot(w != 0)) {
+        // The basis is FULLY reduced (every vector is clear on the pivot columns of all others), so adding vector k never changes a
+        // candidate's bit on another vector's pivot column: whether vector k is added is decided by the candidate's bits as they are
+        // NOW.  That takes the candidate out of the loop's dependency chain -- 63 turns of five broadcasts, a mask and four XORs that
+        // overlap freely instead of 63 turns that each wait for the one before (round 5: the search loop was 16 of a step's 28 us).
+        // The vectors come straight from LDS (one address for the wave: a broadcast read; no hop through scalar registers), four
+        // turns in flight.
+        const u64 w0 = w;
+        u32 wl = (u32)w, wh = (u32)(w >> 32), tl = (u32)t, th = (u32)(t >> 32);
+#pragma unroll 4
         for (int k = done; k < nb; ++k) {
-          const int c = rdlane32(mc, k);
-          const u64 pw = rdlane64(mw, k), pt = rdlane64(mt, k);
-          if ((w >> c) & 1) {
-            w ^= pw;
-            t ^= pt;
-          }
+          const u64 pw = b_word[k], pt = b_trk[k];
+          const u32 sel = (u32)__builtin_amdgcn_sbfe((int)(u32)(w0 >> b_col[k]), 0, 1);  // all ones where the candidate has vector k's column
+          wl = __builtin_amdgcn_bitop3_b32((u32)pw, sel, wl, 0x6a);
+          wh = __builtin_amdgcn_bitop3_b32((u32)(pw >> 32), sel, wh, 0x6a);
+          tl = __builtin_amdgcn_bitop3_b32((u32)pt, sel, tl, 0x6a);
+          th = __builtin_amdgcn_bitop3_b32((u32)(pt >> 32), sel, th, 0x6a);
         }
+        w = (u64)wl | ((u64)wh << 32), t = (u64)tl | ((u64)th << 32);
       }
+      ELIM_STAMP(7);  // (re-reduction of this wave's candidates; wave 0's view)
       done = nb;
       const u64 nzb = __ballot(w != 0);
       if (lane == 0) s_nz[wave] = nzb != 0;
       __syncthreads();
+      ELIM_STAMP(9);  // (waiting for the other waves' re-reductions)
       int fw = -1;
       for (int wv = 15; wv >= 0; --wv)
         if (s_nz[wv]) fw = wv;
@@ -133,31 +186,45 @@ __device__ __forceinline__ bool elim_pivot_step(ElimPivotShared &sm, const u64 *
         u64 mw = lane < nb ? b_word[lane] : 0, mt = lane < nb ? b_trk[lane] : 0;
         int mc = lane < nb ? b_col[lane] : 0, mrow = lane < nb ? b_row[lane] : 0;
         int nbl = nb;
-        u64 mask = nzb;
-        while (mask && nbl < 64) {
-          const int p = __builtin_ctzll(mask);  // lowest row first
-          const u64 pw = rdlane64(w, p);
-          const u64 pt = rdlane64(t, p) | (1ull << nbl);
-          const int c = __builtin_ctzll(pw);
-          if ((mw >> c) & 1) {  // keep the older vectors clear on the new pivot column
-            mw ^= pw;
-            mt ^= pt;
+        // One pivot per turn, up to 64 turns in ONE wave: the search's longest serial piece (in-kernel stamps, round 5: 22,000 of a
+        // step's 60,000 cycles -- 350 per turn -- in the form that took the lowest non-zero candidate by ballot / s_ff1 and tested the
+        // column through exec-masked branches).  Every hop between the vector and the scalar unit costs 15-25 cycles, so the loop-carried
+        // chain is kept to five: the candidates are visited in LANE order (a scalar counter: no ballot, no s_ff1 on it; a zero candidate
+        // is skipped by a scalar branch), v_readlane of the candidate's word -> s_ff1_i32_b64 for its lowest column -> one 64-bit shift
+        // of every lane's word by that column -> v_bfe_i32 (all ones / zero) -> v_bitop3_b32 ((pivot & mask) ^ word) -> the next
+        // v_readlane.  The tracking words and the older basis vectors are updated off the chain with the same masks.  The pivot's own
+        // lane needs no special case: its bit on the column is set, so it XORs itself to zero.
+        u32 wl = (u32)w, wh = (u32)(w >> 32), tl = (u32)t, th = (u32)(t >> 32);
+        u32 bl = (u32)mw, bh = (u32)(mw >> 32), btl = (u32)mt, bth = (u32)(mt >> 32);
+        (void)nzb;
+        // (ONE wave runs here while the others wait at the barrier, so nothing hides an instruction's four issue cycles: a turn costs
+        // its instruction count.  Hence v_writelane_b32 for the new vector's slot -- one instruction per register instead of a compare,
+        // a move and a select each --, the tracking bit set without branches, one backward branch.)
+        const int row0w = __builtin_amdgcn_readfirstlane(base + fw * 64);
+        int p = 0;
+        do {  // lowest row first
+          const u32 pwl = __builtin_amdgcn_readlane(wl, p), pwh = __builtin_amdgcn_readlane(wh, p);
+          if ((pwl | pwh) != 0) {  // (uniform; zero: no candidate in this lane, or a dependent one)
+            const int c = __builtin_ctzll(((u64)pwh << 32) | pwl);
+            const u64 nbit = 1ull << nbl;
+            const u32 ptl = __builtin_amdgcn_readlane(tl, p) | (u32)nbit, pth = __builtin_amdgcn_readlane(th, p) | (u32)(nbit >> 32);
+            const u32 wm = (u32)__builtin_amdgcn_sbfe((int)(u32)((((u64)wh << 32) | wl) >> c), 0, 1);  // all ones where the candidate has the column
+            const u32 bm = (u32)__builtin_amdgcn_sbfe((int)(u32)((((u64)bh << 32) | bl) >> c), 0, 1);  // ... where an older basis vector has it
+            wl = __builtin_amdgcn_bitop3_b32(pwl, wm, wl, 0x6a);
+            wh = __builtin_amdgcn_bitop3_b32(pwh, wm, wh, 0x6a);
+            tl = __builtin_amdgcn_bitop3_b32(ptl, wm, tl, 0x6a);
+            th = __builtin_amdgcn_bitop3_b32(pth, wm, th, 0x6a);
+            bl = __builtin_amdgcn_bitop3_b32(pwl, bm, bl, 0x6a);  // keep the older vectors clear on the new pivot column
+            bh = __builtin_amdgcn_bitop3_b32(pwh, bm, bh, 0x6a);
+            btl = __builtin_amdgcn_bitop3_b32(ptl, bm, btl, 0x6a);
+            bth = __builtin_amdgcn_bitop3_b32(pth, bm, bth, 0x6a);
+            // the new vector takes slot nbl (that lane's slot was zero: untouched above)
+            elim_writelane6(bl, bh, btl, bth, mc, mrow, pwl, pwh, ptl, pth, c, row0w + p, nbl);
+            ++nbl;
           }
-          if (lane == nbl) {
-            mw = pw;
-            mt = pt;
-            mc = c;
-            mrow = base + fw * 64 + p;
-          }
-          if (lane == p) {
-            w = 0;
-          } else if ((w >> c) & 1) {
-            w ^= pw;
-            t ^= pt;
-          }
-          ++nbl;
-          mask = __ballot(w != 0);
-        }
+        } while (++p < 64 && nbl < 64);
+        w = (u64)wl | ((u64)wh << 32), t = (u64)tl | ((u64)th << 32);
+        mw = (u64)bl | ((u64)bh << 32), mt = (u64)btl | ((u64)bth << 32);
         done = nbl;
         if (lane < nbl) {
           b_word[lane] = mw;
@@ -166,16 +233,36 @@ __device__ __forceinline__ bool elim_pivot_step(ElimPivotShared &sm, const u64 *
           b_row[lane] = mrow;
         }
         if (lane == 0) s_nb = nbl;
+        ELIM_STAMP(10);  // (insertions by wave 0)
       }
       __syncthreads();
+      ELIM_STAMP(11);  // (waiting for another wave's insertions)
     }
     __syncthreads();  // s_nz is rewritten by the next pass
     if (s_nb == 64) break;
   }
   __syncthreads();
   const int np = s_nb;
+  ELIM_STAMP(3);  // basis complete
+  // (the previous step's pivots: stable since that step was published -- fetched before the wait instead of behind it)
+  const int prev_row = tid < st->np ? st->cur_row[tid] : -1;
   if (!between()) return false;  // (contains workgroup barriers; everything below writes global memory.  false: the look-ahead wait ran out -- nothing is published)
-  if (tid < st->np) rowflag[st->cur_row[tid]] = 255;  // the previous step's pivots become "pivot of this block"
+  ELIM_STAMP(4);  // every update workgroup done
+  // The chosen rows AS THEY ARE NOW (every update of the previous step has landed): requested first, so that their memory latency runs
+  // beside the ordering of the pivots below instead of behind it; stored into ptab further down (the tracking part gets its unit bit there).
+  u64 praw[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int idx = tid + 1024 * q, k = idx >> 6, wd = idx & 63;
+    u64 v = 0;
+    if (k < np) {
+      const long long r = b_row[k];
+      if (wd < sw) v = elim_ld<COH>(A + r * lda + c0w + wd);
+      else if (wd < sw + uw) v = elim_ld<COH>(U + r * ldu + (wd - sw));
+    }
+    praw[q] = v;
+  }
+  if (prev_row >= 0) rowflag[prev_row] = 255;  // the previous step's pivots become "pivot of this block"
   __syncthreads();
 
   // order the pivots by column: vector k is pivot jbase + pos[k] of the block
@@ -228,17 +315,13 @@ __device__ __forceinline__ bool elim_pivot_step(ElimPivotShared &sm, const u64 *
   // (Round 4.  Until round 3 this kernel combined the 64 reduced rows itself -- 4-bit tables over the selector bits, ten
   // workgroup barriers, 11.5 of the step's ~47 us on ONE CU; the update kernel's tables are now built from the raw rows and
   // every row's selector goes through the 2-KiB map first: sixteen 8-byte lookups per eight rows and lane group.)
-  for (int idx = tid; idx < 64 * 64; idx += 1024) {
-    const int k = idx >> 6, wd = idx & 63;
-    u64 v = 0;
-    if (k < np) {
-      const long long r = b_row[k];
-      if (wd < sw) {
-        v = elim_ld<COH>(A + r * lda + c0w + wd);
-      } else if (wd < sw + uw) {
-        const int u = wd - sw, jj = jbase + f_pos[k];
-        v = elim_ld<COH>(U + r * ldu + u) ^ ((jj >> 6) == u ? 1ull << (jj & 63) : 0);
-      }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int idx = tid + 1024 * q, k = idx >> 6, wd = idx & 63;
+    u64 v = praw[q];
+    if (k < np && wd >= sw && wd < sw + uw) {
+      const int u = wd - sw, jj = jbase + f_pos[k];
+      v ^= (jj >> 6) == u ? 1ull << (jj & 63) : 0;
     }
     ptab[idx] = v;
   }
@@ -256,6 +339,11 @@ __device__ __forceinline__ bool elim_pivot_step(ElimPivotShared &sm, const u64 *
     }
     ptab[64 * 64 + tid] = x;
   }
+  __syncthreads();
+  ELIM_STAMP(5);  // published
+#ifdef GF2K_DEV_VARIANTS
+  if (COH && gf2k_elim_stamps && threadIdx.x == 0) gf2k_elim_stamps[8] += 1;
+#endif
   return true;
 }
 
@@ -328,6 +416,9 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
   const int fault = full_and_flags >> 8;  // (test hook, M4RI_HIP_ELIM_FAULT: 1 = update workgroup 0 never raises its counters)
   const int full = full_and_flags & 1;
   if (LOOK && (int)blockIdx.x == nupd) {
+#ifdef GF2K_DEV_VARIANTS
+    if (gf2k_elim_stamps && tid == 0) gf2k_elim_stamps[15] = __builtin_amdgcn_s_memtime();
+#endif
     if (!elim_wait_count(&st->cnt1, nupd, &st->err)) return;
     if (!elim_pivot_step<true>(sm, A, lda, m, c0w, sw, j + 1, colmask_next, U, ldu, uw, st, pivcols, ptab, rowflag, blkpiv,
                                [&] { return elim_wait_count(&st->cnt2, nupd, &st->err); }))
