@@ -78,7 +78,7 @@ extern "C" hipError_t gf2k_dev_set_elim_stamps(unsigned long long *p) {
 __device__ __forceinline__ void elim_writelane6(u32 &v0, u32 &v1, u32 &v2, u32 &v3, int &v4, int &v5, u32 s0, u32 s1, u32 s2, u32 s3, int s4,
                                                 int s5, int lane_sel) {
   unsigned keep;
-  asm("s_mov_b32 %6, m0\n\ts_mov_b32 m0, %13\n\t"
+  asm("s_mov_b32 %6, m0\n\ts_mov_b32 m0, %13\n\ts_nop 0\n\t"  // (one state between the scalar write of M0 and its first reader, as for the other M0 readers)
       "v_writelane_b32 %0, %7, m0\n\tv_writelane_b32 %1, %8, m0\n\tv_writelane_b32 %2, %9, m0\n\t"
       "v_writelane_b32 %3, %10, m0\n\tv_writelane_b32 %4, %11, m0\n\tv_writelane_b32 %5, %12, m0\n\t"
       "s_mov_b32 m0, %6"

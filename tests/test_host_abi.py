@@ -577,6 +577,8 @@ def test_hazard_checker_sees_known_bad_and_known_good_sequences():
     assert not findings(A + "\ts_mov_b32 m0, s4\n\ts_nop 0\n\tds_write_addtid_b32 v1 offset:256\n" + E)
     assert findings(A + "\ts_mov_b32 m0, s4\n\tglobal_load_lds_dwordx4 v[2:3], off\n" + E)
     assert findings("\ts_mov_b32 m0, s4\n" + A + "\tbuffer_load_dword v1, s[8:11], 0 offen lds\n" + E)
+    assert findings(A + "\ts_mov_b32 m0, s4\n\tv_writelane_b32 v1, s5, m0\n" + E) == ["SALU writes M0 -> v_readlane / v_writelane lane select in M0"]
+    assert not findings(A + "\ts_mov_b32 m0, s4\n\ts_nop 0\n\tv_writelane_b32 v1, s5, m0\n\tv_writelane_b32 v2, s6, m0\n" + E)
     # DPP
     assert findings(A + "\tv_xor_b32 v1, v2, v3\n\tv_mov_b32_dpp v4, v1 row_shr:1 row_mask:0xf bank_mask:0xf\n" + E) == ["VALU write -> DPP src0"]
     assert not findings(A + "\tv_xor_b32 v1, v2, v3\n\ts_nop 1\n\tv_mov_b32_dpp v4, v1 row_shr:1 row_mask:0xf bank_mask:0xf\n" + E)

@@ -20,6 +20,7 @@ gfx950).  A wait state = one issued instruction of the wave; `s_nop N` counts N 
                              s_movrel*                                      1
   VMEM / FLAT store of more than 64 bits -> VALU rewrites its data VGPRs   2
   VALU writes VCC         -> v_div_fmas                                     4
+  SALU writes M0          -> v_readlane / v_writelane with M0 as lane      1   (not in the ISA's table: kept as for the other readers of M0)
 
     python tools/asm_hazards.py            # prints the findings (function, line of the .s, pair, distance); exit 1 if any
 """
@@ -206,6 +207,8 @@ def check_function(name, ins, examined=None):
             checks.append(("VALU writes SGPR -> VMEM reads it", 5, lambda p, rd=rd: bool(p.valu_sgpr_writes() & rd)))
         if ("addtid" in c.mn) or (c.is_vmem() and re.search(r"\blds\b", c.text)) or c.mn.startswith(("global_load_lds", "s_sendmsg", "s_movrel")):
             checks.append(("SALU writes M0 -> add-TID LDS / LDS-DMA / s_sendmsg", 1, lambda p: "m0" in p.salu_writes()))
+        if c.mn.startswith(("v_readlane", "v_writelane")) and len(c.ops) > 2 and "m0" in regs_of(c.ops[2]):
+            checks.append(("SALU writes M0 -> v_readlane / v_writelane lane select in M0", 1, lambda p: "m0" in p.salu_writes()))
         if c.mn.startswith("v_div_fmas"):
             checks.append(("VALU writes VCC -> v_div_fmas", 4, lambda p: "vcc" in p.valu_sgpr_writes()))
         if c.is_valu():
