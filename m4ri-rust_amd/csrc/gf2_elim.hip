@@ -485,25 +485,35 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
     }
     raise(&st->cnt1);
   }
-  for (int it = tid; it < 16 * 5 * 64; it += 1024) {
-    const int wd = it & 63, e5 = (it >> 6) % 5, g = (it >> 6) / 5;
+  // The tables (round 5): thread (g = wave, wd = lane) owns word wd of group g -- it fetches the group's FOUR raw rows' words straight from
+  // ptab and writes all sixteen XOR combinations itself, walking them in Gray-code order (one XOR and one conflict-free 8-byte
+  // LDS write per entry), ONE barrier behind it.  (Until round 5: the single-bit entries through LDS first, then three levels of
+  // combinations, each behind a barrier and each done by the few waves whose entry index had the level's popcount -- 6, 4 and 1 of
+  // the 16 waves, sixteen turns each: ~3.5 us of a step, and at 65536 rows the update is what a step waits for.)
+  {
+    const int g = wave, wd = lane;
+    const u64 b0 = ptab[(g * 4 + 0) * 64 + wd], b1 = ptab[(g * 4 + 1) * 64 + wd], b2 = ptab[(g * 4 + 2) * 64 + wd],
+              b3 = ptab[(g * 4 + 3) * 64 + wd];
+    u64 *const tg = tab + (g * 16) * 64 + wd;
     u64 v = 0;
-    int e = 0;
-    if (e5) {
-      e = 1 << (e5 - 1);
-      v = ptab[(g * 4 + (e5 - 1)) * 64 + wd];
-    }
-    tab[(g * 16 + e) * 64 + wd] = v;
+    tg[0 * 64] = v;
+    v ^= b0, tg[1 * 64] = v;
+    v ^= b1, tg[3 * 64] = v;
+    v ^= b0, tg[2 * 64] = v;
+    v ^= b2, tg[6 * 64] = v;
+    v ^= b0, tg[7 * 64] = v;
+    v ^= b1, tg[5 * 64] = v;
+    v ^= b0, tg[4 * 64] = v;
+    v ^= b3, tg[12 * 64] = v;
+    v ^= b0, tg[13 * 64] = v;
+    v ^= b1, tg[15 * 64] = v;
+    v ^= b0, tg[14 * 64] = v;
+    v ^= b2, tg[10 * 64] = v;
+    v ^= b0, tg[11 * 64] = v;
+    v ^= b1, tg[9 * 64] = v;
+    v ^= b0, tg[8 * 64] = v;
   }
   __syncthreads();
-  // entries with 2, 3, 4 bits from the lower levels
-  for (int bits = 2; bits <= 4; ++bits) {
-    for (int it = tid; it < 16 * 16 * 64; it += 1024) {
-      const int wd = it & 63, e = (it >> 6) & 15, g = it >> 10;
-      if (__popc(e) == bits) tab[(g * 16 + e) * 64 + wd] = tab[(g * 16 + (e & (e - 1))) * 64 + wd] ^ tab[(g * 16 + (e & -e)) * 64 + wd];
-    }
-    __syncthreads();
-  }
   const int nS = sw - j;
   // tracking words past the one that holds this step's last pivot (index jbase + np - 1 of the block) are zero in every row and
   // in every table entry: those lanes neither load nor store (on average a third of the step's traffic)
