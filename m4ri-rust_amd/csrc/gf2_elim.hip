@@ -524,8 +524,13 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
   const long long ld = isS ? lda : ldu;
   const bool skip = LOOK && isS && lane == 1;  // word j + 1 is done
   constexpr int RG = 8;
-  for (long long r0 = row_b + wave * RG; r0 < row_e; r0 += 16 * RG) {
-    const long long m = row_e;  // (the bound of this workgroup's piece)
+  // every wave takes ONE contiguous run of the workgroup's rows, all runs the same length: 65536 rows over 255 workgroups are 264 rows
+  // each = 16.5 per wave -- dealt out in passes of 16 x 8 rows, one wave had a third pass of its own to make while fifteen waited
+  // (round 5: at 65536 rows the update is what a step waits for)
+  const long long wrun = (row_e - row_b + 15) / 16;
+  const long long wave_b = row_b + wave * wrun, wave_e = min(row_e, wave_b + wrun);
+  for (long long r0 = wave_b; r0 < wave_e; r0 += RG) {
+    const long long m = wave_e;  // (the bound of this wave's run)
     u64 old[RG];
     const long long rf = r0 + (lane & 7);
     const int flv = rf < m ? rowflag[rf] : 0;  // lanes 0..7: flags of the pass's rows
