@@ -67,7 +67,17 @@ extern "C" hipError_t gf2k_dev_set_elim_stamps(unsigned long long *p) {
       gf2k_elim_stamps[15] = now_;                                                     \
     }                                                                                  \
   } while (0)
+// the same for ONE update workgroup (the middle one of the launch): stamps[16 + k], its own running clock in stamps[31]
+#define UPD_STAMP(k)                                                                   \
+  do {                                                                                 \
+    if (LOOK && gf2k_elim_stamps && threadIdx.x == 0 && blockIdx.x == (unsigned)(nupd / 2)) { \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime();                    \
+      if (k) gf2k_elim_stamps[16 + k] += now_ - gf2k_elim_stamps[31];                  \
+      gf2k_elim_stamps[31] = now_;                                                     \
+    }                                                                                  \
+  } while (0)
 #else
+#define UPD_STAMP(k) do { } while (0)
 #define ELIM_STAMP(k) do { } while (0)
 #endif
 
@@ -98,7 +108,13 @@ struct ElimPivotShared {
   unsigned char s_chosen[256];  // rows scan0 .. scan0+255 picked by this step
   int s_lead[4];
   int s_col2k[64];
+  // the stash (see elim_pivot_step): the step's selector map and its slice of the tables for the next word column, the new scan start
+  u64 s_smap[256], s_nxt[256], s_pcmask;
+  int s_ns, s_far;
 };
+// The stash: u64 words [0, 256) = the next word column of rows scan .. scan + 255 as it will be once the step just published has been
+// applied, [256, 512) = those rows' flags; lives behind ptab's 64 x 64 + 256 words.
+constexpr int kElimStashOff = 64 * 64 + 256;
 
 // loads that see what other workgroups of the SAME launch stored with agent scope (the look-ahead search reads the word column the
 // update workgroups have just rewritten; L2 is not coherent across XCDs for plain accesses)
@@ -111,11 +127,20 @@ __device__ __forceinline__ T elim_ld(const T *p) {
 // The pivot step of word column j of the block: SEARCH (reads the column's word of the candidate rows and their flags, keeps the
 // basis in LDS, writes nothing to global memory), then `between()` (the look-ahead form waits there until every update workgroup
 // of the launch has finished), then PUBLISH (flags, state, pivot columns, the raw chosen rows and the selector map).
-template <bool COH, typename Between>
+// THE STASH (round 5).  The look-ahead search of the next step needs the next word column of its candidate rows AFTER the step
+// published here has been applied -- it used to wait for every update workgroup of its launch to rewrite that column first (5-9 us
+// of a step, the largest single stage once the search loops were rewritten).  But the publisher can work those 256 words out
+// itself, right here, while nothing else runs: the rows' selector words and the next column are final (every update of the previous
+// step has landed: that is what `between` waited for), the selector map and the column's slice of the tables are in its hands.  It
+// leaves them -- and the rows' flags -- behind ptab (`use_stash` of the NEXT search reads them instead of waiting); the update
+// workgroups rewrite the column for every row with the rest of the step, and a search that needs more than its first 256 rows waits
+// for them (`wait_column`).  `make_stash`: a next step exists in this block and its search will be a look-ahead one.
+template <bool COH, typename Between, typename WaitColumn>
 __device__ __forceinline__ bool elim_pivot_step(ElimPivotShared &sm, const u64 *A, long long lda, int m, long long c0w,
                                                 int sw, int j, u64 colmask, const u64 *U, long long ldu, int uw,
                                                 gf2k_elim_state *st, int *pivcols, u64 *__restrict__ ptab, unsigned char *rowflag,
-                                                int *__restrict__ blkpiv, Between between) {
+                                                int *__restrict__ blkpiv, Between between, WaitColumn wait_column, bool use_stash,
+                                                bool make_stash) {
   u64 (&b_word)[64] = sm.b_word, (&b_trk)[64] = sm.b_trk;
   int (&b_row)[64] = sm.b_row, (&b_col)[64] = sm.b_col, &s_nb = sm.s_nb, (&s_nz)[16] = sm.s_nz, (&f_pos)[64] = sm.f_pos;
   unsigned char (&s_chosen)[256] = sm.s_chosen;
@@ -138,8 +163,21 @@ __device__ __forceinline__ bool elim_pivot_step(ElimPivotShared &sm, const u64 *
     // w: candidate reduced against the basis; t: which chosen rows were added to it
     // flag and word are requested together (the word of a flagged row is simply discarded): one memory latency, not two
     const bool inr = tid < csz && i < m;
-    const unsigned char fl = inr ? elim_ld<COH>(rowflag + i) : 1;  // pivots of this block (and of the step being applied) are no candidates
-    const u64 wraw = inr ? elim_ld<COH>(A + (long long)i * lda + wc) : 0;
+    unsigned char fl = 1;  // pivots of this block (and of the step being applied) are no candidates
+    u64 wraw = 0;
+    if (use_stash && base == scan0) {  // (uniform) the previous publication left this pass's words and flags behind
+      if (inr) {
+        fl = (unsigned char)ptab[kElimStashOff + 256 + tid];
+        wraw = ptab[kElimStashOff + tid];
+      }
+    } else {
+      if (use_stash && base == scan0 + 256)  // (uniform) beyond the stash: the update workgroups' rewrite of the column
+        if (!wait_column()) return false;
+      if (inr) {
+        fl = elim_ld<COH>(rowflag + i);
+        wraw = elim_ld<COH>(A + (long long)i * lda + wc);
+      }
+    }
     if (base == scan0) f0 = fl;
     u64 w = fl == 0 ? (wraw & colmask) : 0, t = 0;
 #ifdef GF2K_DEV_VARIANTS
@@ -246,52 +284,35 @@ __device__ __forceinline__ bool elim_pivot_step(ElimPivotShared &sm, const u64 *
   ELIM_STAMP(3);  // basis complete
   // (the previous step's pivots: stable since that step was published -- fetched before the wait instead of behind it)
   const int prev_row = tid < st->np ? st->cur_row[tid] : -1;
-  if (!between()) return false;  // (contains workgroup barriers; everything below writes global memory.  false: the look-ahead wait ran out -- nothing is published)
-  ELIM_STAMP(4);  // every update workgroup done
-  // The chosen rows AS THEY ARE NOW (every update of the previous step has landed): requested first, so that their memory latency runs
-  // beside the ordering of the pivots below instead of behind it; stored into ptab further down (the tracking part gets its unit bit there).
-  u64 praw[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int idx = tid + 1024 * q, k = idx >> 6, wd = idx & 63;
-    u64 v = 0;
-    if (k < np) {
-      const long long r = b_row[k];
-      if (wd < sw) v = elim_ld<COH>(A + r * lda + c0w + wd);
-      else if (wd < sw + uw) v = elim_ld<COH>(U + r * ldu + (wd - sw));
-    }
-    praw[q] = v;
-  }
-  if (prev_row >= 0) rowflag[prev_row] = 255;  // the previous step's pivots become "pivot of this block"
-  __syncthreads();
 
+  // ---- PREPARE: everything of the publication that needs only the basis, into LDS and registers (nothing global is written yet:
+  // the update workgroups of this launch still read the previous step's state).  While they finish, this runs for free; until round 5
+  // all of it stood behind the wait, on the critical path of every step of a large matrix. ----
   // order the pivots by column: vector k is pivot jbase + pos[k] of the block
+  u64 o_pcmask = 0;
+  int o_c = 0, o_row = -1, o_pos = 0;  // (wave 0, lane < np)
   if (wave == 0) {
-    u64 pcmask = 0;
-    int c = 0, row = -1;
     if (lane < np) {
-      c = b_col[lane];
-      row = b_row[lane];
-      pcmask = 1ull << c;
+      o_c = b_col[lane];
+      o_row = b_row[lane];
+      o_pcmask = 1ull << o_c;
     }
-    for (int o = 32; o; o >>= 1) pcmask |= shfl64(pcmask, lane ^ o);
+    for (int o = 32; o; o >>= 1) o_pcmask |= shfl64(o_pcmask, lane ^ o);
+    const bool far = lane < np && o_row - scan0 >= 256;  // chosen by a later pass (rare)
+    const u64 anyfar = __ballot(far);
     if (lane < np) {
-      const int pos = __popcll(pcmask & ((1ull << c) - 1));
-      f_pos[lane] = pos;
-      pivcols[r_cur + pos] = (int)(wc * 64 + c);
-      blkpiv[jbase + pos] = row;
-      st->cur_row[pos] = row;
-      rowflag[row] = (unsigned char)(1 + c);
-      if (row - scan0 < 256) s_chosen[row - scan0] = 1;
+      o_pos = __popcll(o_pcmask & ((1ull << o_c) - 1));
+      f_pos[lane] = o_pos;
+      if (!far) s_chosen[o_row - scan0] = 1;
     }
     if (lane == 0) {
-      st->np = np;
-      st->pcmask = pcmask;
-      st->jbase = jbase;
-      st->r_cur = r_cur + np;
+      sm.s_pcmask = o_pcmask;
+      sm.s_far = anyfar != 0;
     }
   }
+  if (tid < 64) s_col2k[tid] = -1;
   __syncthreads();
+  if (tid < np) s_col2k[b_col[tid]] = tid;
   // the search of the next step starts behind the leading run of block pivots
   if (tid < 256) {
     const bool taken = f0 != 0 || s_chosen[tid];
@@ -306,15 +327,86 @@ __device__ __forceinline__ bool elim_pivot_step(ElimPivotShared &sm, const u64 *
       if (s_lead[w2] < 64) break;
     }
     const int ns = scan0 + adv;
-    st->scan = ns < m ? ns : m;
+    sm.s_ns = ns < m ? ns : m;
   }
-  // The chosen rows over the block's columns [c0w, c0w+sw) and the tracking words [0, uw), each with its own unit bit, AS READ
-  // (row k = insertion index k), and the 16 x 16 selector map that turns a row's bits on the pivot columns into the set of
-  // these raw rows to add: reduced pivot row k = XOR of the raw rows in b_trk[k], so a row whose word selects the pivot columns
-  // s must add the raw rows  XOR over c in s of b_trk[k(c)]  =  XOR over the nibbles of s of smap[nibble position][nibble].
+  // The 16 x 16 selector map that turns a row's bits on the pivot columns into the set of the raw chosen rows to add: reduced pivot
+  // row k = XOR of the raw rows in b_trk[k], so a row whose word selects the pivot columns s must add the raw rows
+  // XOR over c in s of b_trk[k(c)]  =  XOR over the nibbles of s of smap[nibble position][nibble].
   // (Round 4.  Until round 3 this kernel combined the 64 reduced rows itself -- 4-bit tables over the selector bits, ten
   // workgroup barriers, 11.5 of the step's ~47 us on ONE CU; the update kernel's tables are now built from the raw rows and
   // every row's selector goes through the 2-KiB map first: sixteen 8-byte lookups per eight rows and lane group.)
+  if (tid < 256) {
+    const int g = tid >> 4, v4 = tid & 15;
+    u64 x = 0;
+#pragma unroll
+    for (int b2 = 0; b2 < 4; ++b2) {
+      const int k = s_col2k[4 * g + b2];
+      if (((v4 >> b2) & 1) && k >= 0) x ^= b_trk[k];
+    }
+    sm.s_smap[tid] = x;
+  }
+  __syncthreads();
+  // the stash's candidates: rows s_ns .. s_ns + 255.  Their flags are stable (only publications write flags): read now; a row this
+  // step has chosen counts as flagged
+  const long long sr = (long long)sm.s_ns + tid;
+  const bool scand = make_stash && tid < 256 && sr < m;
+  bool sflag = true;
+  if (scand) {
+    sflag = elim_ld<COH>(rowflag + sr) != 0;
+    const long long si = sr - scan0;
+    if (si < 256) sflag |= s_chosen[si] != 0;
+    else if (sm.s_far)
+      for (int k = 0; k < np; ++k) sflag |= b_row[k] == sr;
+  }
+
+  if (!between()) return false;  // (contains workgroup barriers; everything below writes global memory.  false: the look-ahead wait ran out -- nothing is published)
+  ELIM_STAMP(4);  // every update workgroup done
+  // ---- PUBLISH.  Every global load first, in one memory latency: the chosen rows AS THEY ARE NOW (every update of the previous step
+  // has landed) over the block's columns [c0w, c0w+sw) and the tracking words [0, uw); for the stash, the candidates' selector word
+  // and next word, and the chosen rows' words on the next column (this thread's entry of that column's slice of the tables) ----
+  u64 praw[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int idx = tid + 1024 * q, k = idx >> 6, wd = idx & 63;
+    u64 v = 0;
+    if (k < np) {
+      const long long r = b_row[k];
+      if (wd < sw) v = elim_ld<COH>(A + r * lda + c0w + wd);
+      else if (wd < sw + uw) v = elim_ld<COH>(U + r * ldu + (wd - sw));
+    }
+    praw[q] = v;
+  }
+  u64 wsel = 0, wold = 0, nx = 0;
+  if (make_stash && tid < 256) {  // (make_stash is uniform)
+    if (scand && !sflag) {
+      wsel = elim_ld<COH>(A + sr * lda + wc);
+      wold = elim_ld<COH>(A + sr * lda + wc + 1);
+    }
+    const int g = tid >> 4, e = tid & 15;
+#pragma unroll
+    for (int b2 = 0; b2 < 4; ++b2) {
+      const int k = g * 4 + b2;
+      if (((e >> b2) & 1) && k < np) nx ^= elim_ld<COH>(A + (long long)b_row[k] * lda + wc + 1);
+    }
+  }
+  // ... then the stores: flags, state, pivot columns
+  if (prev_row >= 0) rowflag[prev_row] = 255;  // the previous step's pivots become "pivot of this block"
+  if (wave == 0) {
+    if (lane < np) {
+      pivcols[r_cur + o_pos] = (int)(wc * 64 + o_c);
+      blkpiv[jbase + o_pos] = o_row;
+      st->cur_row[o_pos] = o_row;
+      rowflag[o_row] = (unsigned char)(1 + o_c);
+    }
+    if (lane == 0) {
+      st->np = np;
+      st->pcmask = o_pcmask;
+      st->jbase = jbase;
+      st->r_cur = r_cur + np;
+      st->scan = sm.s_ns;
+    }
+  }
+  // the chosen rows, each with its own unit bit in the tracking part, AS READ (row k = insertion index k), and the selector map
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int idx = tid + 1024 * q, k = idx >> 6, wd = idx & 63;
@@ -325,22 +417,26 @@ __device__ __forceinline__ bool elim_pivot_step(ElimPivotShared &sm, const u64 *
     }
     ptab[idx] = v;
   }
-  if (tid < 64) s_col2k[tid] = -1;
-  __syncthreads();
-  if (tid < np) s_col2k[b_col[tid]] = tid;
-  __syncthreads();
-  if (tid < 256) {
-    const int g = tid >> 4, v4 = tid & 15;
-    u64 x = 0;
+  if (tid < 256) ptab[64 * 64 + tid] = sm.s_smap[tid];
+  if (make_stash) {  // (uniform) see THE STASH above
+    if (tid < 256) sm.s_nxt[tid] = nx;
+    __syncthreads();
+    if (tid < 256) {
+      u64 v = wold;
+      if (scand && !sflag) {
+        const u64 sq = wsel & sm.s_pcmask;
+        u64 x = 0, acc = 0;
 #pragma unroll
-    for (int b2 = 0; b2 < 4; ++b2) {
-      const int k = s_col2k[4 * g + b2];
-      if (((v4 >> b2) & 1) && k >= 0) x ^= b_trk[k];
+        for (int g = 0; g < 16; ++g) x ^= sm.s_smap[g * 16 + (int)((sq >> (4 * g)) & 15)];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc ^= sm.s_nxt[g * 16 + (int)((x >> (4 * g)) & 15)];
+        v = wold ^ acc;
+      }
+      ptab[kElimStashOff + tid] = v;
+      ptab[kElimStashOff + 256 + tid] = sflag ? 1 : 0;
     }
-    ptab[64 * 64 + tid] = x;
   }
-  __syncthreads();
-  ELIM_STAMP(5);  // published
+  ELIM_STAMP(5);  // published (and the stash left behind)
 #ifdef GF2K_DEV_VARIANTS
   if (COH && gf2k_elim_stamps && threadIdx.x == 0) gf2k_elim_stamps[8] += 1;
 #endif
@@ -351,17 +447,18 @@ __global__ __launch_bounds__(1024) void gf2_elim_pivot_kernel(const u64 *__restr
                                                               int sw, int j, u64 colmask, const u64 *__restrict__ U,
                                                               long long ldu, int uw, gf2k_elim_state *st, int *pivcols,
                                                               u64 *__restrict__ ptab, unsigned char *rowflag,
-                                                              int *__restrict__ blkpiv) {
+                                                              int *__restrict__ blkpiv, int make_stash) {
   __shared__ ElimPivotShared sm;
   if (__hip_atomic_load(&st->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // an earlier launch of the chain failed: touch nothing
-  (void)elim_pivot_step<false>(sm, A, lda, m, c0w, sw, j, colmask, U, ldu, uw, st, pivcols, ptab, rowflag, blkpiv, [] { return true; });
+  (void)elim_pivot_step<false>(sm, A, lda, m, c0w, sw, j, colmask, U, ldu, uw, st, pivcols, ptab, rowflag, blkpiv, [] { return true; },
+                               [] { return true; }, /*use_stash=*/false, make_stash != 0 && j + 1 < sw);
 }
 
 // every row adds the pivot rows selected by its bits on the pivot columns; the step's own pivot rows (row flag) are
 // overwritten with their reduced form, which is the single-bit table entry of their pivot column.  Four Russians with 4-bit groups: for each nibble of
 // the 64-bit selector word a 16-entry table of XOR combinations, 16 x 16 entries of 512 B (one LDS bank row each:
 // lane = word, conflict-free) = 128 KiB, built once per workgroup; a row then costs 16 lookups.
-constexpr int kUpdLds = 16 * 16 * 64 * 8 + 256 * 8 + 256 * 8;  // the tables, the selector map, the next word column's slice of the tables
+constexpr int kUpdLds = 16 * 16 * 64 * 8 + 256 * 8;  // the tables, the selector map
 
 // Bounded wait of the look-ahead workgroup for a counter the update workgroups of the same launch raise (every one of them raises
 // it, whatever it did, and none of them waits for anything: they are all dispatched before or alongside this workgroup because the
@@ -397,11 +494,14 @@ __device__ __forceinline__ bool elim_wait_count(int *cnt, int want, int *err) {
   return ok;
 }
 
-// LOOK (round 4): the launch has one workgroup more than it has update workgroups.  Every update workgroup first rewrites the NEXT
-// word column (j + 1) of its share of the rows -- one row per lane, a 2-KiB slice of the tables -- and raises st->cnt1; the extra
-// workgroup waits for all of them, runs the pivot SEARCH of step j + 1 on that column while the others update the remaining
-// words, waits for st->cnt2 (everything updated), and PUBLISHES step j + 1 (flags, state, raw pivot rows, selector map).  A step
-// is then one launch, and the one-CU search (~12 us) runs beside the update instead of behind it.
+// LOOK (round 4): the launch has one workgroup more than it has update workgroups.  The extra workgroup runs the pivot SEARCH of
+// step j + 1 while the others update, waits for st->cnt2 (everything updated), and PUBLISHES step j + 1 (flags, state, raw pivot
+// rows, selector map).  A step is then one launch, and the one-CU search runs beside the update instead of behind it.
+// What the search reads -- word column j + 1 of its candidate rows as step j leaves it -- comes from THE STASH of the previous
+// publication (elim_pivot_step), so it starts with the launch.  (Round 4 to mid round 5: every update workgroup rewrote that column
+// for its rows first and raised st->cnt1, and the search waited for all of them: 4-5 us at the head of every update workgroup --
+// three dependent memory latencies -- and 8.7 us before the search started at 65536 rows.)  A search that needs more than the
+// stash's 256 rows waits for the whole update (cnt2) and reads on from memory: rare, and no slower than the two-launch form.
 template <bool LOOK>
 __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__ A, long long lda, int m, int full_and_flags,
                                                                long long c0w, int sw, int j, u64 *__restrict__ U,
@@ -419,17 +519,17 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
 #ifdef GF2K_DEV_VARIANTS
     if (gf2k_elim_stamps && tid == 0) gf2k_elim_stamps[15] = __builtin_amdgcn_s_memtime();
 #endif
-    if (!elim_wait_count(&st->cnt1, nupd, &st->err)) return;
+    // (no wait for the next column: the previous publication left the first pass's words behind -- THE STASH)
     if (!elim_pivot_step<true>(sm, A, lda, m, c0w, sw, j + 1, colmask_next, U, ldu, uw, st, pivcols, ptab, rowflag, blkpiv,
-                               [&] { return elim_wait_count(&st->cnt2, nupd, &st->err); }))
+                               [&] { return elim_wait_count(&st->cnt2, nupd, &st->err); },
+                               [&] { return elim_wait_count(&st->cnt2, nupd, &st->err); }, /*use_stash=*/true, /*make_stash=*/j + 2 < sw))
       return;
     __syncthreads();
-    if (tid == 0) {  // every update workgroup is done: ready for the next launch
-      __hip_atomic_store(&st->cnt1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0)  // every update workgroup is done: ready for the next launch
       __hip_atomic_store(&st->cnt2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     return;
   }
+  UPD_STAMP(0);
   const int np = st->np, r0s = st->r0;
   const u64 pcmask = st->pcmask;
   // this workgroup's (write-through, agent-scope) stores so far have completed, then the count goes up.  NOT __threadfence():
@@ -440,12 +540,12 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
     if (tid == 0 && !(fault == 1 && blockIdx.x == 0)) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   if (np == 0) {
-    if (LOOK) raise(&st->cnt1), raise(&st->cnt2);
+    if (LOOK) raise(&st->cnt2);
     return;
   }
   // level 0/1: entry 0 and the single-bit entries: bit i = the step's i-th chosen row as the pivot kernel read it (raw; rows past
   // np are zero).  The selector map (see the pivot kernel) goes into LDS behind the tables.
-  u64 *smap = tab + 16 * 16 * 64, *nxt = smap + 256;
+  u64 *smap = tab + 16 * 16 * 64;
   if (tid < 256) smap[tid] = ptab[64 * 64 + tid];
   const int rows_lo = full ? 0 : r0s;
   const long long wc = c0w + j;
@@ -454,37 +554,6 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
   // three full passes)
   const long long per = ((((long long)m - rows_lo + nupd - 1) / nupd) + 7) & ~7ll;
   const long long row_b = rows_lo + (long long)blockIdx.x * per, row_e = min((long long)m, row_b + per);
-  if constexpr (LOOK) {
-    // ---- the next word column first (j + 1 < sw), before the tables: its 2-KiB slice of them straight from the raw rows, then
-    // one row per lane; the look-ahead workgroup starts its search ~5 us into the launch ----
-    if (tid < 256) {
-      const int g = tid >> 4, e = tid & 15;
-      u64 v = 0;
-#pragma unroll
-      for (int b2 = 0; b2 < 4; ++b2)
-        if ((e >> b2) & 1) v ^= ptab[(g * 4 + b2) * 64 + (j + 1)];
-      nxt[tid] = v;
-    }
-    __syncthreads();
-    u64 *const col = A + wc + 1;
-    // (the SAME rows as this workgroup's waves take below, because word j, the selector, is rewritten there)
-    for (long long r = row_b + tid; r < row_e; r += 1024) {
-      const int fl = rowflag[r];  // flag, selector word and old word in one memory latency
-      const u64 wsel = A[r * lda + wc], wold = col[r * lda];
-      const bool piv = fl >= 1 && fl <= 64;
-      const u64 sq = piv ? 1ull << (fl - 1) : wsel & pcmask;
-      if (!sq) continue;
-      u64 x = 0;
-#pragma unroll
-      for (int g = 0; g < 16; ++g) x ^= smap[g * 16 + (int)((sq >> (4 * g)) & 15)];
-      u64 acc = 0;
-#pragma unroll
-      for (int g = 0; g < 16; ++g) acc ^= nxt[g * 16 + (int)((x >> (4 * g)) & 15)];
-      const u64 v = piv ? acc : wold ^ acc;
-      __hip_atomic_store(col + r * lda, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (seen by the look-ahead workgroup's loads)
-    }
-    raise(&st->cnt1);
-  }
   // The tables (round 5): thread (g = wave, wd = lane) owns word wd of group g -- it fetches the group's FOUR raw rows' words straight from
   // ptab and writes all sixteen XOR combinations itself, walking them in Gray-code order (one XOR and one conflict-free 8-byte
   // LDS write per entry), ONE barrier behind it.  (Until round 5: the single-bit entries through LDS first, then three levels of
@@ -514,6 +583,7 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
     v ^= b0, tg[8 * 64] = v;
   }
   __syncthreads();
+  UPD_STAMP(3);  // tables built
   const int nS = sw - j;
   // tracking words past the one that holds this step's last pivot (index jbase + np - 1 of the block) are zero in every row and
   // in every table entry: those lanes neither load nor store (on average a third of the step's traffic)
@@ -522,7 +592,6 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
   const int tword = isS ? j + lane : (act ? sw + (lane - nS) : 0);
   u64 *const base = isS ? A + wc + lane : U + (lane - nS);
   const long long ld = isS ? lda : ldu;
-  const bool skip = LOOK && isS && lane == 1;  // word j + 1 is done
   constexpr int RG = 8;
   // every wave takes ONE contiguous run of the workgroup's rows, all runs the same length: 65536 rows over 255 workgroups are 264 rows
   // each = 16.5 per wave -- dealt out in passes of 16 x 8 rows, one wave had a third pass of its own to make while fifteen waited
@@ -570,14 +639,16 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
       }
       // a pivot of this step becomes its reduced form (the XOR of the raw rows in its b_trk); every other row adds what its word selects
       const bool piv = fl >= 1 && fl <= 64;
-      if (act && !skip && r0 + q < m) {
+      if (act && r0 + q < m) {
         const u64 v = piv ? acc : old[q] ^ acc;
         if constexpr (LOOK) __hip_atomic_store(base + (r0 + q) * ld, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (the look-ahead workgroup reads the rows it chose)
         else base[(r0 + q) * ld] = v;
       }
     }
   }
+  UPD_STAMP(4);  // wave 0's run of rows done (stores issued)
   if constexpr (LOOK) raise(&st->cnt2);
+  UPD_STAMP(5);  // every wave's run done and landed, count raised
 }
 
 // ---- end of a block: block pivot j (row blkpiv[j]) goes to row r0 + j; the non-pivot rows that sit inside
@@ -833,7 +904,7 @@ extern "C" hipError_t gf2k_elim_step(u64 *A, long long lda, int m, long long c0w
   if (grid < 1) grid = 1;
   if (!lookahead) {
     hipLaunchKernelGGL(gf2_elim_pivot_kernel, dim3(1), dim3(1024), 0, s, A, lda, m, c0w, sw, j, colmask, U, ldu, uw, st, pivcols, ptab,
-                       rowflag, blkpiv);
+                       rowflag, blkpiv, 0);
     hipLaunchKernelGGL(gf2_elim_update_kernel<false>, dim3(grid), dim3(1024), kUpdLds, s, A, lda, m, full, c0w, sw, j, U, ldu, uw, st,
                        ptab, rowflag, colmask_next, pivcols, blkpiv);
     return hipGetLastError();
@@ -841,7 +912,7 @@ extern "C" hipError_t gf2k_elim_step(u64 *A, long long lda, int m, long long c0w
   // look-ahead: the search of step j + 1 runs inside the update launch of step j; the block's first step is searched on its own
   if (j == 0)
     hipLaunchKernelGGL(gf2_elim_pivot_kernel, dim3(1), dim3(1024), 0, s, A, lda, m, c0w, sw, j, colmask, U, ldu, uw, st, pivcols, ptab,
-                       rowflag, blkpiv);
+                       rowflag, blkpiv, /*make_stash=*/1);
   if (j + 1 < sw)
     hipLaunchKernelGGL(gf2_elim_update_kernel<true>, dim3(grid + 1), dim3(1024), kUpdLds, s, A, lda, m, full, c0w, sw, j, U, ldu, uw, st,
                        ptab, rowflag, colmask_next, pivcols, blkpiv);

@@ -2962,7 +2962,8 @@ int echelonize_dev(gf2_dmat *A, int full, int col_limit, int *rank_out, int *piv
     return 0;
   }
   if (int rc = U.alloc((size_t)m * uw * sizeof(u64))) return rc;
-  if (int rc = ptab.alloc((64 * 64 + 256) * sizeof(u64))) return rc;  // the step's 64 pivot rows over the block + the 16 x 16 selector map
+  // the step's 64 pivot rows over the block + the 16 x 16 selector map + the stash of the next search (256 words, 256 flags: gf2_elim.hip)
+  if (int rc = ptab.alloc((64 * 64 + 256 + 512) * sizeof(u64))) return rc;
   if (int rc = tmp.alloc((size_t)2 * GF2K_ELIM_BLOCK_PIVOTS * tld * sizeof(u64))) return rc;
   if (int rc = P.alloc((size_t)prow_max * pld * sizeof(u64))) return rc;
   if (int rc = flags.alloc((size_t)m)) return rc;

@@ -19,7 +19,7 @@ names = ["", "launch start -> next column rewritten by all (cnt1)", "candidates 
 for n in [int(a) for a in sys.argv[1:]] or [4096, 65536]:
     M = device.DMat.random(n, n, 5)
     device.echelonize(M, full=True)
-    st = torch.zeros(16, dtype=torch.int64, device="cuda")
+    st = torch.zeros(32, dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()
     assert raw.gf2k_dev_set_elim_stamps(st.data_ptr()) == 0
     M = device.DMat.random(n, n, 5)
@@ -39,3 +39,10 @@ for n in [int(a) for a in sys.argv[1:]] or [4096, 65536]:
         print("    of the search loop: %-42s %8.0f" % (nm, h[k] / max(steps, 1)))
         tot += h[k]
     print("  %-62s %8.0f  (= %.1f us at 2.1 GHz; the launch itself adds its boundary)" % ("sum", tot / max(steps, 1), tot / max(steps, 1) / 2100.0))
+    print("  the middle UPDATE workgroup of the same launches (thread 0's view):")
+    tot = 0
+    for k, nm in ((1, "start -> next column rewritten (stores issued)"), (2, "... landed, cnt1 raised"), (3, "tables built"),
+                  (4, "wave 0's run of rows done (stores issued)"), (5, "every wave done, stores landed, cnt2 raised")):
+        print("    %-60s %8.0f" % (nm, h[16 + k] / max(steps, 1)))
+        tot += h[16 + k]
+    print("    %-60s %8.0f" % ("sum", tot / max(steps, 1)))
