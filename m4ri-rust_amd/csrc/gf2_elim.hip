@@ -598,13 +598,99 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
   // (round 5: at 65536 rows the update is what a step waits for)
   const long long wrun = (row_e - row_b + 15) / 16;
   const long long wave_b = row_b + wave * wrun, wave_e = min(row_e, wave_b + wrun);
+  // a lane group of 8 maps one row's selector: two nibbles per lane through the selector map, folded over the eight lanes by DPP
+  auto map_selector = [&](u64 sq) -> u64 {
+    const int h2 = (lane & 7) * 2;
+    const u64 x = smap[h2 * 16 + (int)((sq >> (4 * h2)) & 15)] ^ smap[(h2 + 1) * 16 + (int)((sq >> (4 * h2 + 4)) & 15)];
+    unsigned lo = (unsigned)x, hi = (unsigned)(x >> 32);
+    lo ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]: lane ^ 1
+    hi ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, 0xB1, 0xf, 0xf, true);
+    lo ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0x4E, 0xf, 0xf, true);  // quad_perm [2,3,0,1]: lane ^ 2
+    hi ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, 0x4E, 0xf, 0xf, true);
+    lo ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0x141, 0xf, 0xf, true);  // row_half_mirror: lane ^ 7 (the quads are uniform by now)
+    hi ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, 0x141, 0xf, 0xf, true);
+    return (u64)lo | ((u64)hi << 32);
+  };
+  auto put = [&](u64 *p, u64 v) {
+    if constexpr (LOOK) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (the look-ahead workgroup reads the rows it chose)
+    else *p = v;
+  };
+  if (np == 64 && nS - 1 + uw_live <= 32) {
+    // TWO ROWS PER LOOKUP (round 5).  The update is bound by its LDS reads -- sixteen 8-byte reads per row and wave, which cost the
+    // same 4+ clocks with 33 lanes active as with 64 (tools/lds_exec_bench) -- and on a step that found all 64 pivots of its word
+    // column a row has at most 32 live words besides that column: sw - j - 1 words right of it and uw_live <= j + 1 tracking words.
+    // The column itself needs no lookup then (every one of its 64 columns is a pivot column: a pivot row keeps its unit bit, every
+    // other row becomes zero on it).  So lanes 0..31 take one row and lanes 32..63 another, each half with its own table entries:
+    // half the LDS time per row.  Steps with fewer pivots (the matrix's last columns, rank-deficient input) take the loop below.
+    const int h = lane >> 5, l32 = lane & 31, nS1 = nS - 1;
+    const bool isS2 = l32 < nS1, act2 = l32 < nS1 + uw_live;
+    const int tword2 = isS2 ? j + 1 + l32 : (act2 ? sw + (l32 - nS1) : 0);
+    u64 *const base2 = isS2 ? A + wc + 1 + l32 : U + (l32 - nS1);
+    const long long ld2 = isS2 ? lda : ldu;
+    const u32 tw8 = (u32)tword2 * 8;
+    for (long long r0 = wave_b; r0 < wave_e; r0 += 16) {
+      const long long m = wave_e;  // (the bound of this wave's run)
+      const long long rf = r0 + (lane & 15);
+      const int flv = rf < m ? rowflag[rf] : 0;  // lanes 0..15: flags of the pass's rows
+      const bool pvl = flv >= 1 && flv <= 64;
+      // the selectors of rows r0 + q (lane group q, first round) and r0 + 8 + q (second round)
+      u64 xs[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const long long rq = r0 + 8 * t + (lane >> 3);
+        const int flq = rq < m ? rowflag[rq] : 0;
+        u64 sq = rq < m ? A[rq * lda + wc] : 0;
+        if (flq >= 1 && flq <= 64) sq = 1ull << (flq - 1);
+        xs[t] = map_selector(sq);
+      }
+      u64 old[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const long long r = r0 + q + 8 * h;
+        old[q] = (act2 && r < m) ? base2[r * ld2] : 0;
+      }
+      const unsigned pivm = (unsigned)__ballot(pvl && lane < 16) >> (8 * h);  // bit q: this half's row of pair q is a pivot of this step
+      // a pivot of this step becomes its reduced form (the XOR of the raw rows in its b_trk: what it held does not count); every other
+      // row adds what its word selects.  (Here and not at the store: the first unconditional use of the loaded words is where the
+      // compiler waits for them -- once; inside the skippable turns below it waited in every turn, with vmcnt(0), i.e. for the
+      // previous turn's STORE as well.)
+      u32 ol[8], oh[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        ol[q] = ((pivm >> q) & 1) ? 0 : (u32)old[q], oh[q] = ((pivm >> q) & 1) ? 0 : (u32)(old[q] >> 32);
+        asm volatile("" : "+v"(ol[q]), "+v"(oh[q]));  // (pins the wait and the select here)
+      }
+      if (lane < 16 && rf < m) put(A + rf * lda + wc, pvl ? 1ull << (flv - 1) : 0);  // the step's own word column
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const unsigned loa = __builtin_amdgcn_readlane((unsigned)xs[0], 8 * q), hia = __builtin_amdgcn_readlane((unsigned)(xs[0] >> 32), 8 * q);
+        const unsigned lob = __builtin_amdgcn_readlane((unsigned)xs[1], 8 * q), hib = __builtin_amdgcn_readlane((unsigned)(xs[1] >> 32), 8 * q);
+        if ((loa | hia | lob | hib) == 0) continue;
+        const unsigned lo = h ? lob : loa, hi = h ? hib : hia;
+        u32 al = ol[q], ah = oh[q];
+#pragma unroll
+        for (int g = 0; g < 16; g += 2) {
+          // per-lane entries: byte address = group * 8192 (an instruction offset) + nibble * 512 + word * 8 -- the nibble shifted into
+          // place and masked, OR-ed onto the word's offset (disjoint bits: one shift and one v_and_or_b32 per lookup)
+          const u32 sel = g < 8 ? lo : hi;
+          const int sh0 = 4 * (g & 7) - 9, sh1 = sh0 + 4;
+          const u32 a0 = ((sh0 < 0 ? sel << -sh0 : sel >> sh0) & 0x1e00u) | tw8, a1 = ((sh1 < 0 ? sel << -sh1 : sel >> sh1) & 0x1e00u) | tw8;
+          const u64 t0 = *(const u64 *)((const char *)tab + a0 + g * 8192), t1 = *(const u64 *)((const char *)tab + a1 + (g + 1) * 8192);
+          al = __builtin_amdgcn_bitop3_b32(al, (u32)t0, (u32)t1, 0x96);
+          ah = __builtin_amdgcn_bitop3_b32(ah, (u32)(t0 >> 32), (u32)(t1 >> 32), 0x96);
+        }
+        const long long r = r0 + q + 8 * h;
+        if (act2 && r < m) put(base2 + r * ld2, (u64)al | ((u64)ah << 32));
+      }
+    }
+  } else
   for (long long r0 = wave_b; r0 < wave_e; r0 += RG) {
     const long long m = wave_e;  // (the bound of this wave's run)
     u64 old[RG];
     const long long rf = r0 + (lane & 7);
     const int flv = rf < m ? rowflag[rf] : 0;  // lanes 0..7: flags of the pass's rows
     // lane group q = lane / 8 maps the selector of row r0 + q: its word's bits on the pivot columns (a pivot row of this step: the
-    // single bit of its pivot column, i.e. its reduced form), two nibbles per lane, folded over the eight lanes by DPP
+    // single bit of its pivot column, i.e. its reduced form)
     const long long rq = r0 + (lane >> 3);
     const int flq = rq < m ? rowflag[rq] : 0;
     u64 sq = rq < m ? A[rq * lda + wc] & pcmask : 0;
@@ -614,36 +700,24 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
       const long long r = r0 + q;
       old[q] = (act && r < m) ? base[r * ld] : 0;
     }
-    const int h2 = (lane & 7) * 2;
-    u64 x = smap[h2 * 16 + (int)((sq >> (4 * h2)) & 15)] ^ smap[(h2 + 1) * 16 + (int)((sq >> (4 * h2 + 4)) & 15)];
-    {
-      unsigned lo = (unsigned)x, hi = (unsigned)(x >> 32);
-      lo ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]: lane ^ 1
-      hi ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, 0xB1, 0xf, 0xf, true);
-      lo ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0x4E, 0xf, 0xf, true);  // quad_perm [2,3,0,1]: lane ^ 2
-      hi ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, 0x4E, 0xf, 0xf, true);
-      lo ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0x141, 0xf, 0xf, true);  // row_half_mirror: lane ^ 7 (the quads are uniform by now)
-      hi ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, 0x141, 0xf, 0xf, true);
-      x = (u64)lo | ((u64)hi << 32);
-    }
+    const u64 x = map_selector(sq);
 #pragma unroll
     for (int q = 0; q < RG; ++q) {
       const int fl = __builtin_amdgcn_readlane(flv, q);
       const unsigned lo = __builtin_amdgcn_readlane((unsigned)x, 8 * q), hi = __builtin_amdgcn_readlane((unsigned)(x >> 32), 8 * q);
       if ((lo | hi) == 0) continue;
-      u64 acc = 0;
+      u32 al = 0, ah = 0;
 #pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const unsigned idx = ((g < 8 ? lo : hi) >> (4 * (g & 7))) & 15u;
-        acc ^= tab[(g * 16 + idx) * 64 + tword];
+      for (int g = 0; g < 16; g += 2) {  // (three-input XORs: one VALU instruction per half and two lookups)
+        const unsigned i0 = ((g < 8 ? lo : hi) >> (4 * (g & 7))) & 15u, i1 = ((g < 8 ? lo : hi) >> (4 * (g & 7) + 4)) & 15u;
+        const u64 t0 = tab[(g * 16 + i0) * 64 + tword], t1 = tab[((g + 1) * 16 + i1) * 64 + tword];
+        al = __builtin_amdgcn_bitop3_b32(al, (u32)t0, (u32)t1, 0x96);
+        ah = __builtin_amdgcn_bitop3_b32(ah, (u32)(t0 >> 32), (u32)(t1 >> 32), 0x96);
       }
+      const u64 acc = (u64)al | ((u64)ah << 32);
       // a pivot of this step becomes its reduced form (the XOR of the raw rows in its b_trk); every other row adds what its word selects
       const bool piv = fl >= 1 && fl <= 64;
-      if (act && r0 + q < m) {
-        const u64 v = piv ? acc : old[q] ^ acc;
-        if constexpr (LOOK) __hip_atomic_store(base + (r0 + q) * ld, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (the look-ahead workgroup reads the rows it chose)
-        else base[(r0 + q) * ld] = v;
-      }
+      if (act && r0 + q < m) put(base + (r0 + q) * ld, piv ? acc : old[q] ^ acc);
     }
   }
   UPD_STAMP(4);  // wave 0's run of rows done (stores issued)
