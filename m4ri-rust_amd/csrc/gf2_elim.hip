@@ -220,7 +220,57 @@ __device__ __forceinline__ bool elim_pivot_step(ElimPivotShared &sm, const u64 *
       for (int wv = 15; wv >= 0; --wv)
         if (s_nz[wv]) fw = wv;
       if (fw < 0) break;
-      if (wave == fw) {  // this wave's candidates are reduced against the whole basis: insert the independent ones
+      if (wave == fw && nb == 0) {
+        // THE FIRST INSERTIONS (no older vectors; on full-rank input all 64 pivots of a step).  A chosen candidate STAYS IN ITS LANE as
+        // the basis vector: "reduce the later candidates by the new pivot" and "keep the older vectors clear on the new pivot column"
+        // are then ONE operation on one register pair -- 13 vector instructions per pivot instead of 24 (one shift + v_bfe_i32 instead
+        // of two, four v_bitop3_b32 instead of eight, a compare and two selects instead of six v_writelane_b32 through M0): the lone
+        // inserting wave pays four-plus cycles for every instruction it issues (in-kernel stamps: 296 cycles per pivot before).  The
+        // pivot's own lane is masked out of the XOR; its own tracking bit (toggled in), insertion index and LDS slot follow after the loop from the mask
+        // of chosen lanes.  Same visiting order, same pivots, same insertion indices as the general loop below.
+        u32 wl = (u32)w, wh = (u32)(w >> 32), tl = (u32)t, th = (u32)(t >> 32);
+        const int row0w = __builtin_amdgcn_readfirstlane(base + fw * 64);
+        int mc = 0, nbl = 0;
+        u64 chosen = 0;
+        // Sixty-four turns, no branch in them (a zero candidate's turn changes nothing: its word and its tracking word enter as zero):
+        // with the test-and-skip branch a turn cost 253 cycles for 30 instructions -- the wave waited on the chain v_readlane ->
+        // s_or / s_cmp / s_cbranch -> s_ff1 -> shift -> v_bfe -> select -> v_bitop3 -> the next v_readlane, not on issue slots.
+#pragma unroll 8
+        for (int p = 0; p < 64; ++p) {  // lowest row first
+          const u32 pwl = __builtin_amdgcn_readlane(wl, p), pwh = __builtin_amdgcn_readlane(wh, p);
+          // 1 / 0: a candidate / no candidate in this lane, or a dependent one.  (s_min_u32 by hand: written as a compare or as min() the
+          // flag becomes a lane mask, and the insertion count, the chosen mask and the tracking bit go through the vector unit with it)
+          u32 nz1;
+          asm("s_min_u32 %0, %1, 1" : "=s"(nz1) : "s"(pwl | pwh) : "scc");
+          const u32 nzm = 0u - nz1;
+          const int c = __builtin_ctzll(((u64)(pwh | 0x80000000u) << 32) | pwl);  // (63 for a zero word: any column will do)
+          const u64 nbit = 1ull << nbl;
+          const u32 ptl = (__builtin_amdgcn_readlane(tl, p) | (u32)nbit) & nzm, pth = (__builtin_amdgcn_readlane(th, p) | (u32)(nbit >> 32)) & nzm;
+          u32 wm = (u32)__builtin_amdgcn_sbfe((int)(u32)((((u64)wh << 32) | wl) >> c), 0, 1);  // all ones where a lane's word has the column
+          const bool self = lane == p;
+          wm = self ? 0u : wm;
+          mc = self ? c : mc;
+          wl = __builtin_amdgcn_bitop3_b32(pwl, wm, wl, 0x6a);
+          wh = __builtin_amdgcn_bitop3_b32(pwh, wm, wh, 0x6a);
+          tl = __builtin_amdgcn_bitop3_b32(ptl, wm, tl, 0x6a);
+          th = __builtin_amdgcn_bitop3_b32(pth, wm, th, 0x6a);
+          chosen |= (u64)nz1 << p;
+          nbl += (int)nz1;
+        }
+        const bool ch = (chosen >> lane) & 1;
+        const int kidx = __popcll(chosen & ((1ull << lane) - 1));  // insertion index: the chosen lanes in lane order
+        w = (u64)wl | ((u64)wh << 32), t = (u64)tl | ((u64)th << 32);
+        if (ch) {
+          b_word[kidx] = w;
+          b_trk[kidx] = t ^ (1ull << kidx);  // (XOR, not OR: a later pivot that contains this one toggles the bit when it is added)
+          b_col[kidx] = mc;
+          b_row[kidx] = row0w + lane;
+          w = 0;  // (consumed: no candidate any more)
+        }
+        done = nbl;
+        if (lane == 0) s_nb = nbl;
+        ELIM_STAMP(10);  // (insertions by wave 0)
+      } else if (wave == fw) {  // this wave's candidates are reduced against the whole basis: insert the independent ones
         u64 mw = lane < nb ? b_word[lane] : 0, mt = lane < nb ? b_trk[lane] : 0;
         int mc = lane < nb ? b_col[lane] : 0, mrow = lane < nb ? b_row[lane] : 0;
         int nbl = nb;

@@ -12,6 +12,7 @@ python3 tools/av_breakdown.py 2>/dev/null | grep -v amdgpu > $O/av_breakdown.txt
 python3 tools/host_plan_ab.py 32768 65536 16384 2>/dev/null | grep -v amdgpu > $O/host_plan_ab.txt
 tools/lpn_lab 64 128 256 > $O/lpn_lab_final.txt 2>&1
 python3 tools/elim_bench.py 2>/dev/null | grep "^n=" > $O/elim.txt
+AB_LIB=tools/libm4ri_hip_dev.so python3 tools/elim_stamps.py 4096 65536 2>/dev/null | grep -v amdgpu > $O/elim_stamps.txt
 echo "host path / lab / elimination done"
 # the per-rank shapes of the multi-GPU step on R x Q grids (DESIGN section 6's cap table): N = 8: 8x1, 4x2, 2x4, 1x8 and their halves
 # (two sub-panels); N = 4: 4x1, 2x2, 1x4; N = 2: 2x1, 1x2; the whole product
