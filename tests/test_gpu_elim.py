@@ -142,6 +142,57 @@ def test_rref_structured(pkg, block_words):
     assert rank == orank and np.array_equal(got, ref)
 
 
+def _structured_cases():
+    """Inputs for the blocked path (more than 1024 rows) that steer the 64-column step into its rarer branches (round 5): a search
+    that does not find its 64 pivots among the first 256 candidate rows (reads on behind the previous publication's stash, after
+    waiting for the whole update; chosen rows beyond the first 256), steps with fewer than 64 pivots (the one-row-per-lookup
+    update; the general insertion loop behind the in-lane one), leading runs of flagged rows, rows that cancel."""
+    rng = np.random.default_rng(77)
+    out = {}
+    base = g.words_to_bits(g.random_words(500, 2000, 41), 2000)
+    out["every-row-seven-times"] = np.repeat(base, 7, axis=0)[:3300]                      # 256 candidates hold ~37 independent rows
+    z = np.zeros((3000, 1500), dtype=np.uint8)
+    z[::3] = g.words_to_bits(g.random_words(1000, 1500, 42), 1500)
+    out["two-zero-rows-between"] = z                                                      # sparse candidates, many passes
+    d = g.words_to_bits(g.random_words(2600, 900, 43), 900)
+    out["column-pairs-equal"] = np.repeat(d, 2, axis=1)                                   # at most 32 pivots per word column
+    out["reversed-identity"] = np.eye(2100, dtype=np.uint8)[::-1].copy()                  # every pivot in the last active row
+    lo = g.words_to_bits(_low_rank(2500, 1900, 90, 44), 1900)
+    lo[rng.permutation(2500)[:700]] = 0
+    out["low-rank-with-zero-rows"] = lo
+    t = np.tril(np.ones((1800, 1800), dtype=np.uint8))
+    out["lower-triangular-ones"] = t                                                      # row i = row i-1 + unit: long dependency chains
+    w = g.words_to_bits(g.random_words(2048, 2048, 45), 2048)
+    w[:, 64:128] = 0
+    w[:, 700:1000] = 0
+    w[1000:1400] = w[200:600] ^ w[600:1000]
+    out["zero-column-bands-and-sums"] = w
+    return out
+
+
+_STRUCT = None
+
+
+@pytest.mark.parametrize("name", ["every-row-seven-times", "two-zero-rows-between", "column-pairs-equal", "reversed-identity",
+                                  "low-rank-with-zero-rows", "lower-triangular-ones", "zero-column-bands-and-sums"])
+@pytest.mark.parametrize("full", [True, False], ids=["rref", "upper"])
+def test_rref_structured_blocked(pkg, block_words, name, full):
+    global _STRUCT
+    if _STRUCT is None:
+        _STRUCT = _structured_cases()
+    bits = _STRUCT[name]
+    m, n = bits.shape
+    a = g.bits_to_words(bits)
+    got, rank = _host_rref(pkg, a, n, full=full)
+    ref, orank, _ = g.o_echelonize(a, m, n, full=True)
+    assert rank == orank
+    if full:
+        assert np.array_equal(got, ref)
+    else:  # same row space and pivots: reducing it fully gives the unique reduced form
+        again, rank2, _ = g.o_echelonize(got, m, n, full=True)
+        assert rank2 == rank and np.array_equal(again, ref)
+
+
 @pytest.mark.parametrize("m,n,r", [(100, 100, 100), (1200, 1500, 1500), (1500, 1200, 300), (3000, 2500, 2500)])
 def test_upper_echelon_form(pkg, block_words, m, n, r):
     """full = 0 (what BinMatrix::echelonize passes, binary_matrix.rs:259)."""
