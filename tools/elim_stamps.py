@@ -14,7 +14,7 @@ raw = ctypes.CDLL(_lib.LIB_PATH)
 if not hasattr(raw, "gf2k_dev_set_elim_stamps"):
     sys.exit("elim_stamps: needs the development library (AB_LIB=tools/libm4ri_hip_dev.so)")
 raw.gf2k_dev_set_elim_stamps.argtypes = [ctypes.c_void_p]
-names = ["", "launch start -> next column rewritten by all (cnt1)", "candidates of the first pass loaded", "basis complete (search loop)",
+names = ["", "launch start -> search starts (the stash: no wait any more)", "candidates of the first pass loaded", "basis complete (search loop)",
          "every update workgroup done (cnt2)", "published (flags, state, raw pivot rows, selector map)"]
 for n in [int(a) for a in sys.argv[1:]] or [4096, 65536]:
     M = device.DMat.random(n, n, 5)
@@ -41,8 +41,7 @@ for n in [int(a) for a in sys.argv[1:]] or [4096, 65536]:
     print("  %-62s %8.0f  (= %.1f us at 2.1 GHz; the launch itself adds its boundary)" % ("sum", tot / max(steps, 1), tot / max(steps, 1) / 2100.0))
     print("  the middle UPDATE workgroup of the same launches (thread 0's view):")
     tot = 0
-    for k, nm in ((1, "start -> next column rewritten (stores issued)"), (2, "... landed, cnt1 raised"), (3, "tables built"),
-                  (4, "wave 0's run of rows done (stores issued)"), (5, "every wave done, stores landed, cnt2 raised")):
+    for k, nm in ((3, "start -> tables built"), (4, "wave 0's run of rows done (stores issued)"), (5, "every wave done, stores landed, cnt2 raised")):
         print("    %-60s %8.0f" % (nm, h[16 + k] / max(steps, 1)))
         tot += h[16 + k]
     print("    %-60s %8.0f" % ("sum", tot / max(steps, 1)))
