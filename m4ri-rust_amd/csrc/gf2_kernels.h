@@ -56,6 +56,9 @@ enum { GF2K_ELIM_BLOCK_PIVOTS = 2048 };
 
 extern "C" {
 hipError_t gf2k_elim_begin_block(gf2k_elim_state *st, hipStream_t s);
+// one 64-column step.  ptab: 64 x 64 + 256 + 512 words (the step's raw pivot rows over the block, the selector map, the stash of the
+// next search: 256 words and 256 flags); the steps of a block must be enqueued in order j = 0 .. sw - 1 on one stream with the same
+// `lookahead` (the stash a step leaves behind is read by the next step's launch)
 hipError_t gf2k_elim_step(uint64_t *A, long long lda, int m, long long c0w, int sw, int j, uint64_t colmask, int full,
                           uint64_t *U, long long ldu, int uw, gf2k_elim_state *st, int *pivcols, uint64_t *ptab,
                           unsigned char *rowflag, int *blkpiv, uint64_t colmask_next, int lookahead, hipStream_t s);
