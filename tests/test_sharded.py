@@ -239,3 +239,20 @@ def test_bench_two_ranks_from_a_bare_shell(bcast, grid):
         assert out["config"]["grid"] == best["grid"]
     else:
         assert "panel_tuning" not in out
+
+
+@pytest.mark.gpu
+def test_rccl_one_rank_collectives():
+    """The collectives of the multi-GPU step through RCCL ITSELF (backend nccl), with the one rank a one-GPU box can hold (round 5;
+    until then no RCCL call had run for this repository): asynchronous broadcast, scatter + all-gather and gather on the compute
+    stream, the library's products between them on the same stream, source and destination buffers aliased as on rank 0 of a
+    real run; C must equal the product of the whole operands for 1, 2 and 4 sub-panels and both ways B travels
+    (tools/rccl_one_rank.py; reference caller binary_matrix.rs:459-472 -> strassen.rs:18)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MASTER_PORT"] = str(_free_port())
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_one_rank.py")], env=env, cwd=ROOT, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "rccl_one_rank: ok" in r.stdout and "MISMATCH" not in r.stdout
+    assert r.stdout.count("C matches") == 12 and "via nccl" in r.stdout
