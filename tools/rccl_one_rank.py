@@ -61,7 +61,9 @@ t = torch.tensor([1.5], dtype=torch.float64, device="cuda")
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
 dist.barrier()
 torch.cuda.synchronize()
-print("all_reduce(MAX) / barrier:", float(t[0]))
+info = [None]
+dist.all_gather_object(info, {"rank": 0, "device": torch.cuda.current_device()})  # (the per-rank records of the N > 1 bench line)
+print("all_reduce(MAX) / barrier / all_gather_object:", float(t[0]), info)
 dist.destroy_process_group()
 print("rccl_one_rank:", "ok" if ok else "FAILED")
 sys.exit(0 if ok else 1)
