@@ -385,6 +385,10 @@ def main():
     ap.add_argument("--no-elim", action="store_true", help="skip the elimination leg (reduced echelon forms, device resident)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--check", action="store_true", help="spot-check rows of C against the oracle after timing")
+    ap.add_argument("--rehearse-one-rank", action="store_true",
+                    help="rehearsal on a one-GPU box: run the N > 1 code path (process group, grid, panel tuning, RCCL collectives, gathers, "
+                         "self-check, per-rank records) with ONE rank -- the only way the nccl backend can run here, two ranks on one GPU "
+                         "are refused by RCCL; the line it prints is not a measurement")
     ap.add_argument("--no-configs", action="store_true",
                     help="N = 1: skip the other single-GPU BASELINE configurations (2, 3, 5) that are timed after the headline loop")
     ap.add_argument("--no-parity", action="store_true", help="skip the sha256 / sampled-row self-checks of the timed products")
@@ -407,17 +411,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         args.gpus = world
+    multi = (int(world) >= 2) or args.rehearse_one_rank  # the distributed code path (one rank: rehearsal only)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the multiply path has no CPU fallback")
     # rehearsal mode: more ranks than GPUs (e.g. 2 ranks on a 1-GPU box with --backend gloo) share device 0
     torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
-    if world > 1:
+    if multi:
+        if args.rehearse_one_rank:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
         dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     import __graft_entry__ as ge
     if rank == 0:
         ge.build()
-    if world > 1:
+    if multi:
         dist.barrier()
     import m4ri_rust_amd  # noqa: F401
     from m4ri_rust_amd import device
@@ -431,7 +439,7 @@ def main():
         r_, q_ = (int(x) for x in text.lower().split("x"))
         assert r_ >= 1 and q_ >= 1 and r_ * q_ == world, "--grid %s does not cover %d ranks" % (text, world)
         return r_, q_
-    R, Q = parse_grid(args.grid) if (args.grid and world > 1) else (world, 1)
+    R, Q = parse_grid(args.grid) if (args.grid and multi) else (world, 1)
     rows = n // R
     # all work (kernels and RCCL collectives) is issued under one explicit torch stream: torch orders its
     # collectives against the current stream, and the library launches on the very same hipStream_t
@@ -482,7 +490,7 @@ def main():
     A_t, A = make_a(R, Q)
 
     panel_tuning = None
-    if world > 1 and (args.panels <= 0 or args.grid is None) and args.bcast is None:
+    if multi and (args.panels <= 0 or args.grid is None) and args.bcast is None:
         # No multi-GPU run of this repository exists yet, so the first one tunes itself: three untimed steps of every candidate
         # (grid of ranks x sub-panels per column panel x how a panel travels), barrier + synchronize around them, the slowest rank's
         # time decides on every rank alike.  Priors from one-GPU timings of the per-rank shapes: DESIGN.md section 6.
@@ -524,13 +532,13 @@ def main():
             A_t, A = make_a(R, Q)
     if args.bcast is None:
         args.bcast = "broadcast"
-    P = (args.panels if args.panels > 0 else (2 if world == 2 else 4)) if world > 1 else 1
-    while world > 1 and P > 1 and not panel_ok(Q, P):
+    P = (args.panels if args.panels > 0 else (2 if world == 2 else 4)) if multi else 1
+    while multi and P > 1 and not panel_ok(Q, P):
         P //= 2
     assert ldw % (2 * Q * P) == 0
     wp, ncp = ldw // (Q * P), n // (Q * P)  # words / columns of one sub-panel
-    grid = grid_of(R, Q) if world > 1 else None
-    if world == 1:
+    grid = grid_of(R, Q) if multi else None
+    if not multi:
         B_t = torch.empty((n, ldw), dtype=torch.int64, device="cuda")
         C_t = torch.empty((rows, ldw), dtype=torch.int64, device="cuda")
         B = device.DMat.from_torch(B_t, n)
@@ -556,7 +564,7 @@ def main():
     step_events = []  # filled during the timed steps only
 
     def step(record=False):
-        if world > 1:
+        if multi:
             ev = [] if record else None
             sharded.step_grid(grid, A, b_src_t, Bp_t, Cp_t, Cfull_t, Bp, Cp, algo=args.algo, levels=args.levels, stream=stream,
                               bcast=args.bcast, events=ev)
@@ -568,7 +576,7 @@ def main():
     # the CPU baseline leg first (N = 1 only): the timed GPU loop then ends the run, so a driver-side utilisation sample
     # taken near the end sees the GPU busy
     cpu_baseline, cpu_sample = (None, None)
-    if world == 1 and not args.no_cpu:
+    if not multi and not args.no_cpu:
         cpu_baseline, cpu_sample = _cpu_baseline(args)
         if not args.check:
             cpu_sample = None
@@ -576,7 +584,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     device.prof_enable(True)
     device.prof_read(reset=True)
@@ -585,7 +593,7 @@ def main():
     for _ in range(args.steps):
         step(record=True)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -593,20 +601,20 @@ def main():
     launches, kernel_ms = device.prof_read(reset=True)
 
     dt_local = dt
-    if world > 1:
+    if multi:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
     rank_info = None
-    if world > 1:
+    if multi:
         mine = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(),
                 "name": torch.cuda.get_device_name(torch.cuda.current_device()), "timed_region_ms": dt_local * 1e3,
                 "step_breakdown": sharded.breakdown(step_events)}
         rank_info = [None] * world
         dist.all_gather_object(rank_info, mine)
     if rank != 0:
-        if world > 1:
+        if multi:
             dist.destroy_process_group()
         return
 
@@ -614,7 +622,7 @@ def main():
     ms_per_step = dt * 1e3 / args.steps
 
     sharded_ok = None
-    if args.check and world > 1:
+    if args.check and multi:
         # rank 0 recomputes every C panel from the full seeded A on its own GPU and compares with what was gathered
         A_full = device.DMat.random(n, n, 1, stream)
         sharded_ok = True
@@ -625,11 +633,11 @@ def main():
         del A_full
 
     self_check = None
-    if world > 1 and not args.no_parity:
+    if multi and not args.no_parity:
         self_check = _sharded_self_check(device, sharded, torch, [device.DMat.from_torch(b_src_t[j_][p_], ncp) for j_ in range(Q) for p_ in range(P)],
                                          [Cfull_t[j_][p_] for j_ in range(Q) for p_ in range(P)], n, R, stream)
     parity = None
-    if world == 1 and not args.no_parity and args.density == "half":
+    if not multi and not args.no_parity and args.density == "half":
         want = _golden_digests().get("sq_%d" % n, {}).get("sha256_c")
         if want:
             parity = _sha256_of(C, stream) == want  # the product of the LAST timed step
@@ -692,14 +700,14 @@ def main():
                 n, n, n, "Strassen(%d levels)-over-M4RM" % levels if levels else "M4RM only",
                 "; per step on a %d x %d grid of ranks: B (resident on rank 0) travels in %d column panels of %d sub-panels, rank (i, j) "
                 "multiplies its %d-row block i of A by the sub-panels of column panel j, the %d x %d blocks of C are gathered on rank 0"
-                % (R, Q, Q, P, rows, rows, ncp) if world > 1 else ""),
+                % (R, Q, Q, P, rows, rows, ncp) if multi else ""),
             "n": n, "algo": args.algo, "strassen_levels": levels,
             "parallelism": "row-block shard of A over %d GPU(s)%s" % (
                 world, " as a %d x %d grid (%d row blocks of A x %d column panels of B; the inner dimension is never split), %d sub-panels "
                        "per column panel: RCCL %s(sub-panel p+1) / gather(C sub-panel p-1) overlap the product of sub-panel p" % (
                     R, Q, R, Q, P, "broadcast" if args.bcast == "broadcast" else "scatter+all_gather")
-                if world > 1 else ""),
-            "grid": "%dx%d" % (R, Q) if world > 1 else None,
+                if multi else ""),
+            "grid": "%dx%d" % (R, Q) if multi else None,
         },
         "roofline": {
             "bound": "hbm",
@@ -732,7 +740,7 @@ def main():
     if parity is not None:
         out["parity_sha256_ok"] = bool(parity)
         out["parity_note"] = "sha256 of the last timed %d^3 product == tests/golden/digests_large.json[sq_%d]" % (n, n)
-    if world > 1:
+    if multi:
         out["ranks_seen"] = dist.get_world_size()
         out["backend"] = dist.get_backend()
         out["ranks"] = rank_info
@@ -753,7 +761,7 @@ def main():
         if self_check is not None:
             out["self_check"] = self_check
             out["parity_rows_ok"] = self_check["ok"]
-    if world == 1 and levels > 0 and launches:
+    if not multi and levels > 0 and launches:
         # the rest of a step is the Strassen split / merge passes (same stream, serial): HBM-streaming kernels whose
         # bytes are known exactly (every pass reads its sources once and writes its destinations once; the library's own count)
         pass_bytes = float(device._lib.lib().gf2_strassen_pass_bytes(n, n, n, levels))
@@ -773,11 +781,11 @@ def main():
             Ad, Bd = device.DMat.random(cn, cn, 1), device.DMat.random(cn, cn, 2)
             out["cpu_baseline"]["gpu_matches_cpu_sample"] = bool(
                 np.array_equal(device.mul(Ad, Bd, algo=args.algo, param=args.levels).to_words(), cpu_sample))
-    if world == 1 and not args.no_configs and args.density == "half":
+    if not multi and not args.no_configs and args.density == "half":
         out["configs"] = _extra_configs(device, torch, stream)
-    if world == 1 and not args.no_elim and args.density == "half":
+    if not multi and not args.no_elim and args.density == "half":
         out["elimination"] = _elimination(device, torch)
-    if world == 1 and not args.no_host_path and args.density == "half":
+    if not multi and not args.no_host_path and args.density == "half":
         del A, B, C, A_t, B_t, C_t  # the resident operands and (gf2_trim) the 15 GiB arena go back first
         torch.cuda.empty_cache()
         device._lib.lib().gf2_trim()
@@ -787,7 +795,7 @@ def main():
         time.sleep(1.0)
         out["host_path"] = _host_path(torch)
     print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

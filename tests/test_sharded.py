@@ -256,3 +256,26 @@ def test_rccl_one_rank_collectives():
     assert r.returncode == 0, r.stdout[-3000:]
     assert "rccl_one_rank: ok" in r.stdout and "MISMATCH" not in r.stdout
     assert r.stdout.count("C matches") == 12 and "via nccl" in r.stdout
+
+
+@pytest.mark.gpu
+def test_bench_distributed_path_on_rccl_with_one_rank():
+    """`bench.py --rehearse-one-rank`: the WHOLE N > 1 code path of the bench -- process group on the nccl backend (RCCL), grid, the
+    self-tuning over sub-panels and transports, the timed sharded steps, the MAX reduction of the timed region, per-rank records by
+    all_gather_object, sampled-row self-check, comparison with the single-GPU product -- with the one rank a one-GPU box can give RCCL
+    (two ranks on one GPU are refused: 'Duplicate GPU detected').  The two-rank rehearsals above run the same code over gloo."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MASTER_PORT"] = str(_free_port())
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--rehearse-one-rank", "--check", "--dim", "8192", "--no-cpu", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["backend"] == "nccl" and out["ranks_seen"] == 1 and out["config"]["grid"] == "1x1"
+    assert out["sharded_result_matches_single_gpu"] is True and out["self_check"]["ok"] is True and out["parity_rows_ok"] is True
+    tune = out["panel_tuning"]
+    assert {(c["panels"], c["bcast"]) for c in tune["candidates"]} == {(p, b) for p in (1, 2, 4) for b in ("broadcast", "allgather")}
+    assert out["step_breakdown"]["step_ms"] > 0 and len(out["ranks"]) == 1
