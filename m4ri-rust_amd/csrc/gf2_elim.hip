@@ -26,6 +26,7 @@
 #include "gf2_kernels.h"
 
 #include <atomic>
+#include <type_traits>
 
 typedef uint64_t u64;
 typedef uint32_t u32;
@@ -158,7 +159,9 @@ __device__ __forceinline__ bool elim_pivot_step(ElimPivotShared &sm, const u64 *
   // the first pass looks at 256 rows only (one wave per SIMD: nearly always enough for 64 pivots, and the waves that
   // re-reduce their candidates after the first wave's insertions do not compete for issue slots); then 1024 per pass
   int csz = 256;
+  bool beyond = false;  // (uniform) the search went past its first 256 rows
   for (int base = scan0; base < m; base += csz, csz = 1024) {
+    if (base != scan0) beyond = true;
     const int i = base + tid;
     // w: candidate reduced against the basis; t: which chosen rows were added to it
     // flag and word are requested together (the word of a flagged row is simply discarded): one memory latency, not two
@@ -409,7 +412,7 @@ __device__ __forceinline__ bool elim_pivot_step(ElimPivotShared &sm, const u64 *
       for (int k = 0; k < np; ++k) sflag |= b_row[k] == sr;
   }
 
-  if (!between()) return false;  // (contains workgroup barriers; everything below writes global memory.  false: the look-ahead wait ran out -- nothing is published)
+  if (!between(beyond || sm.s_far != 0)) return false;  // (`true`: rows beyond the priority range were read or chosen -- wait for the whole update; contains workgroup barriers; everything below writes global memory.  false: the look-ahead wait ran out -- nothing is published)
   ELIM_STAMP(4);  // every update workgroup done
   // ---- PUBLISH.  Every global load first, in one memory latency: the chosen rows AS THEY ARE NOW (every update of the previous step
   // has landed) over the block's columns [c0w, c0w+sw) and the tracking words [0, uw); for the stash, the candidates' selector word
@@ -500,7 +503,7 @@ __global__ __launch_bounds__(1024) void gf2_elim_pivot_kernel(const u64 *__restr
                                                               int *__restrict__ blkpiv, int make_stash) {
   __shared__ ElimPivotShared sm;
   if (__hip_atomic_load(&st->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // an earlier launch of the chain failed: touch nothing
-  (void)elim_pivot_step<false>(sm, A, lda, m, c0w, sw, j, colmask, U, ldu, uw, st, pivcols, ptab, rowflag, blkpiv, [] { return true; },
+  (void)elim_pivot_step<false>(sm, A, lda, m, c0w, sw, j, colmask, U, ldu, uw, st, pivcols, ptab, rowflag, blkpiv, [](bool) { return true; },
                                [] { return true; }, /*use_stash=*/false, make_stash != 0 && j + 1 < sw);
 }
 
@@ -508,7 +511,8 @@ __global__ __launch_bounds__(1024) void gf2_elim_pivot_kernel(const u64 *__restr
 // overwritten with their reduced form, which is the single-bit table entry of their pivot column.  Four Russians with 4-bit groups: for each nibble of
 // the 64-bit selector word a 16-entry table of XOR combinations, 16 x 16 entries of 512 B (one LDS bank row each:
 // lane = word, conflict-free) = 128 KiB, built once per workgroup; a row then costs 16 lookups.
-constexpr int kUpdLds = 16 * 16 * 64 * 8 + 256 * 8;  // the tables, the selector map
+constexpr int kEarlyMinRows = 192;  // rows per update workgroup from which the publication goes ahead of the update's end (see EARLY PUBLICATION)
+constexpr int kUpdLds = 16 * 16 * 64 * 8 + 256 * 8 + 2048;  // the tables, the selector map, the flags of the workgroup's rows
 
 // Bounded wait of the look-ahead workgroup for a counter the update workgroups of the same launch raise (every one of them raises
 // it, whatever it did, and none of them waits for anything: they are all dispatched before or alongside this workgroup because the
@@ -570,13 +574,15 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
     if (gf2k_elim_stamps && tid == 0) gf2k_elim_stamps[15] = __builtin_amdgcn_s_memtime();
 #endif
     // (no wait for the next column: the previous publication left the first pass's words behind -- THE STASH)
-    if (!elim_pivot_step<true>(sm, A, lda, m, c0w, sw, j + 1, colmask_next, U, ldu, uw, st, pivcols, ptab, rowflag, blkpiv,
-                               [&] { return elim_wait_count(&st->cnt2, nupd, &st->err); },
-                               [&] { return elim_wait_count(&st->cnt2, nupd, &st->err); }, /*use_stash=*/true, /*make_stash=*/j + 2 < sw))
-      return;
-    __syncthreads();
-    if (tid == 0)  // every update workgroup is done: ready for the next launch
-      __hip_atomic_store(&st->cnt2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the counters run on through the block (gf2k_elim_begin_block zeroes them): launch j is waiting for (j + 1) x nupd.  The
+    // publication waits for the PRIORITY rows only (cntP; see the update workgroups below) unless the search left them
+    const int want = (j + 1) * nupd;
+    const long long rows_lo_l = full ? 0 : st->r0;
+    const long long per_l = ((((long long)m - rows_lo_l + nupd - 1) / nupd) + 7) & ~7ll;
+    const bool early = per_l >= kEarlyMinRows && per_l <= 2048;
+    (void)elim_pivot_step<true>(sm, A, lda, m, c0w, sw, j + 1, colmask_next, U, ldu, uw, st, pivcols, ptab, rowflag, blkpiv,
+                                [&](bool need_all) { return elim_wait_count(need_all || !early ? &st->cnt2 : &st->cntP, want, &st->err); },
+                                [&] { return elim_wait_count(&st->cnt2, want, &st->err); }, /*use_stash=*/true, /*make_stash=*/j + 2 < sw);
     return;
   }
   UPD_STAMP(0);
@@ -590,7 +596,10 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
     if (tid == 0 && !(fault == 1 && blockIdx.x == 0)) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   if (np == 0) {
-    if (LOOK) raise(&st->cnt2);
+    if (LOOK) {
+      raise(&st->cnt2);
+      if (tid == 0 && !(fault == 1 && blockIdx.x == 0)) __hip_atomic_fetch_add(&st->cntP, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     return;
   }
   // level 0/1: entry 0 and the single-bit entries: bit i = the step's i-th chosen row as the pivot kernel read it (raw; rows past
@@ -604,6 +613,28 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
   // three full passes)
   const long long per = ((((long long)m - rows_lo + nupd - 1) / nupd) + 7) & ~7ll;
   const long long row_b = rows_lo + (long long)blockIdx.x * per, row_e = min((long long)m, row_b + per);
+  // EARLY PUBLICATION (round 5, last change).  The look-ahead workgroup needs, of all rows, only the ones its search chose and the next
+  // search's candidates: rows [scan, scan + 512) as long as the search stays inside its first pass.  It used to wait until EVERY update
+  // workgroup had finished and its stores had landed (~5 us between a workgroup's last store and the counter being seen) and published
+  // behind that: at 65536 rows, where the update is the longer side, 8 of a step's 22 us.  Now (a) every update workgroup copies what it
+  // will ever read of the shared state -- the step's record, the raw pivot rows, the selector map, THE FLAGS OF ITS ROWS -- into LDS and
+  // registers up front; (b) those 512 priority rows are dealt out over all workgroups, a few each, and ONE wave of every workgroup
+  // updates its few first and raises st->cntP when they have landed; (c) the publication waits for cntP only and then overwrites record,
+  // rows and flags while the update of all other rows is still running.  Workgroups with more than 2048 rows (> 522,000 rows on 255
+  // workgroups) keep the old hand-off: their flags do not fit the 2 KiB set aside here; so do workgroups with fewer than 192 rows (below
+  // ~49,000 rows the search is the longer side of a step and the extra pass only costs: 4096^2 1.14 -> 1.18 ms with it).
+  const bool pre = LOOK && per >= kEarlyMinRows && per <= 2048;
+  unsigned char *const sfl = reinterpret_cast<unsigned char *>(smap + 256);
+  long long P0 = 0, P1 = 0;
+  if (pre) {
+    P0 = st->scan;
+    P1 = min((long long)m, P0 + 512);
+    for (long long i = tid; i < row_e - row_b; i += 1024) sfl[i] = rowflag[row_b + i];
+  }
+  const int nS = sw - j;
+  // tracking words past the one that holds this step's last pivot (index jbase + np - 1 of the block) are zero in every row and
+  // in every table entry: those lanes neither load nor store (on average a third of the step's traffic)
+  const int uw_live = min(uw, ((st->jbase + np - 1) >> 6) + 1);
   // The tables (round 5): thread (g = wave, wd = lane) owns word wd of group g -- it fetches the group's FOUR raw rows' words straight from
   // ptab and writes all sixteen XOR combinations itself, walking them in Gray-code order (one XOR and one conflict-free 8-byte
   // LDS write per entry), ONE barrier behind it.  (Until round 5: the single-bit entries through LDS first, then three levels of
@@ -634,10 +665,6 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
   }
   __syncthreads();
   UPD_STAMP(3);  // tables built
-  const int nS = sw - j;
-  // tracking words past the one that holds this step's last pivot (index jbase + np - 1 of the block) are zero in every row and
-  // in every table entry: those lanes neither load nor store (on average a third of the step's traffic)
-  const int uw_live = min(uw, ((st->jbase + np - 1) >> 6) + 1);
   const bool isS = lane < nS, act = lane < nS + uw_live;
   const int tword = isS ? j + lane : (act ? sw + (lane - nS) : 0);
   u64 *const base = isS ? A + wc + lane : U + (lane - nS);
@@ -665,6 +692,11 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
     if constexpr (LOOK) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (the look-ahead workgroup reads the rows it chose)
     else *p = v;
   };
+  // rows [rb, re); SKIP (a compile-time switch: the plain form must not pay for it): without [s0, s1), flags from this workgroup's LDS copy
+  auto run = [&](auto skip_c, const long long rb, const long long re, const long long s0, const long long s1) {
+  constexpr bool SKIP = decltype(skip_c)::value;
+  auto valid = [&](long long r) { return SKIP ? (r < re && !(r >= s0 && r < s1)) : r < re; };
+  auto flag_of = [&](long long r) -> int { return SKIP ? (int)sfl[r - row_b] : (int)rowflag[r]; };
   if (np == 64 && nS - 1 + uw_live <= 32) {
     // TWO ROWS PER LOOKUP (round 5).  The update is bound by its LDS reads -- sixteen 8-byte reads per row and wave, which cost the
     // same 4+ clocks with 33 lanes active as with 64 (tools/lds_exec_bench) -- and on a step that found all 64 pivots of its word
@@ -678,18 +710,17 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
     u64 *const base2 = isS2 ? A + wc + 1 + l32 : U + (l32 - nS1);
     const long long ld2 = isS2 ? lda : ldu;
     const u32 tw8 = (u32)tword2 * 8;
-    for (long long r0 = wave_b; r0 < wave_e; r0 += 16) {
-      const long long m = wave_e;  // (the bound of this wave's run)
+    for (long long r0 = rb; r0 < re; r0 += 16) {
       const long long rf = r0 + (lane & 15);
-      const int flv = rf < m ? rowflag[rf] : 0;  // lanes 0..15: flags of the pass's rows
+      const int flv = valid(rf) ? flag_of(rf) : 0;  // lanes 0..15: flags of the pass's rows
       const bool pvl = flv >= 1 && flv <= 64;
       // the selectors of rows r0 + q (lane group q, first round) and r0 + 8 + q (second round)
       u64 xs[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const long long rq = r0 + 8 * t + (lane >> 3);
-        const int flq = rq < m ? rowflag[rq] : 0;
-        u64 sq = rq < m ? A[rq * lda + wc] : 0;
+        const int flq = valid(rq) ? flag_of(rq) : 0;
+        u64 sq = valid(rq) ? A[rq * lda + wc] : 0;
         if (flq >= 1 && flq <= 64) sq = 1ull << (flq - 1);
         xs[t] = map_selector(sq);
       }
@@ -697,7 +728,7 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const long long r = r0 + q + 8 * h;
-        old[q] = (act2 && r < m) ? base2[r * ld2] : 0;
+        old[q] = (act2 && valid(r)) ? base2[r * ld2] : 0;
       }
       const unsigned pivm = (unsigned)__ballot(pvl && lane < 16) >> (8 * h);  // bit q: this half's row of pair q is a pivot of this step
       // a pivot of this step becomes its reduced form (the XOR of the raw rows in its b_trk: what it held does not count); every other
@@ -710,7 +741,7 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
         ol[q] = ((pivm >> q) & 1) ? 0 : (u32)old[q], oh[q] = ((pivm >> q) & 1) ? 0 : (u32)(old[q] >> 32);
         asm volatile("" : "+v"(ol[q]), "+v"(oh[q]));  // (pins the wait and the select here)
       }
-      if (lane < 16 && rf < m) put(A + rf * lda + wc, pvl ? 1ull << (flv - 1) : 0);  // the step's own word column
+      if (lane < 16 && valid(rf)) put(A + rf * lda + wc, pvl ? 1ull << (flv - 1) : 0);  // the step's own word column
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const unsigned loa = __builtin_amdgcn_readlane((unsigned)xs[0], 8 * q), hia = __builtin_amdgcn_readlane((unsigned)(xs[0] >> 32), 8 * q);
@@ -730,25 +761,24 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
           ah = __builtin_amdgcn_bitop3_b32(ah, (u32)(t0 >> 32), (u32)(t1 >> 32), 0x96);
         }
         const long long r = r0 + q + 8 * h;
-        if (act2 && r < m) put(base2 + r * ld2, (u64)al | ((u64)ah << 32));
+        if (act2 && valid(r)) put(base2 + r * ld2, (u64)al | ((u64)ah << 32));
       }
     }
   } else
-  for (long long r0 = wave_b; r0 < wave_e; r0 += RG) {
-    const long long m = wave_e;  // (the bound of this wave's run)
+  for (long long r0 = rb; r0 < re; r0 += RG) {
     u64 old[RG];
     const long long rf = r0 + (lane & 7);
-    const int flv = rf < m ? rowflag[rf] : 0;  // lanes 0..7: flags of the pass's rows
+    const int flv = valid(rf) ? flag_of(rf) : 0;  // lanes 0..7: flags of the pass's rows
     // lane group q = lane / 8 maps the selector of row r0 + q: its word's bits on the pivot columns (a pivot row of this step: the
     // single bit of its pivot column, i.e. its reduced form)
     const long long rq = r0 + (lane >> 3);
-    const int flq = rq < m ? rowflag[rq] : 0;
-    u64 sq = rq < m ? A[rq * lda + wc] & pcmask : 0;
+    const int flq = valid(rq) ? flag_of(rq) : 0;
+    u64 sq = valid(rq) ? A[rq * lda + wc] & pcmask : 0;
     if (flq >= 1 && flq <= 64) sq = 1ull << (flq - 1);
 #pragma unroll
     for (int q = 0; q < RG; ++q) {
       const long long r = r0 + q;
-      old[q] = (act && r < m) ? base[r * ld] : 0;
+      old[q] = (act && valid(r)) ? base[r * ld] : 0;
     }
     const u64 x = map_selector(sq);
 #pragma unroll
@@ -767,9 +797,19 @@ __global__ __launch_bounds__(1024) void gf2_elim_update_kernel(u64 *__restrict__
       const u64 acc = (u64)al | ((u64)ah << 32);
       // a pivot of this step becomes its reduced form (the XOR of the raw rows in its b_trk); every other row adds what its word selects
       const bool piv = fl >= 1 && fl <= 64;
-      if (act && r0 + q < m) put(base + (r0 + q) * ld, piv ? acc : old[q] ^ acc);
+      if (act && valid(r0 + q)) put(base + (r0 + q) * ld, piv ? acc : old[q] ^ acc);
     }
   }
+  };
+  if (pre && wave == 15) {  // this workgroup's few of the priority rows first, by one wave; the other fifteen are on their runs already
+    const long long pr = (P1 - P0 + nupd - 1) / nupd;
+    const long long pb = P0 + (long long)blockIdx.x * pr, pe = min(P1, pb + pr);
+    run(std::false_type{}, pb, pe, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (they have landed)
+    if (lane == 0 && !(fault == 1 && blockIdx.x == 0)) __hip_atomic_fetch_add(&st->cntP, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (pre) run(std::true_type{}, wave_b, wave_e, P0, P1);
+  else run(std::false_type{}, wave_b, wave_e, 0, 0);
   UPD_STAMP(4);  // wave 0's run of rows done (stores issued)
   if constexpr (LOOK) raise(&st->cnt2);
   UPD_STAMP(5);  // every wave's run done and landed, count raised
@@ -873,6 +913,8 @@ __global__ void gf2_elim_begin_block_kernel(gf2k_elim_state *st) {
     st->scan = st->r_cur;
     st->np = 0;
     st->lastword = -1;
+    st->cntP = 0;
+    st->cnt2 = 0;
   }
 }
 

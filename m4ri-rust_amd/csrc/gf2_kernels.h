@@ -46,7 +46,7 @@ struct gf2k_elim_state {
   int lastword;  // after gf2k_elim_end_block: last word index (absolute) in which a pivot row of the block is non-zero
   unsigned long long pcmask;  // pivot columns of the current word
   int cur_row[64];            // rows chosen by the current step (their flag says "pivot of this step" until the next one)
-  int cnt1, cnt2;             // look-ahead launches: cnt2 = update workgroups that have finished (cnt1: unused since round 5)
+  int cntP, cnt2;             // look-ahead launches, counted up through a block: update workgroups whose PRIORITY rows have landed / that have finished
   int err;                    // set when the look-ahead workgroup's bounded wait ran out (never expected)
 };
 // Row flags (one byte per row) during a block: 0 = ordinary row, 1 + c = pivot of the CURRENT step with pivot column c of
