@@ -167,6 +167,13 @@ def _structured_cases():
     w[:, 700:1000] = 0
     w[1000:1400] = w[200:600] ^ w[600:1000]
     out["zero-column-bands-and-sums"] = w
+    # tall enough (>= 192 rows per update workgroup) for the publication to go ahead of the update's end: priority rows, flags
+    # copied into LDS up front, and -- with repeated rows -- the fall-back to the whole update when the search leaves its first pass
+    tb = g.words_to_bits(g.random_words(9000, 190, 46), 190)
+    out["tall-every-row-seven-times"] = np.repeat(tb, 7, axis=0)[:60000]
+    tc = g.words_to_bits(g.random_words(52000, 128, 47), 128)
+    tc[rng.random(52000) < 0.5] = 0
+    out["tall-column-pairs-zero-rows"] = np.repeat(tc, 2, axis=1)
     return out
 
 
@@ -174,7 +181,8 @@ _STRUCT = None
 
 
 @pytest.mark.parametrize("name", ["every-row-seven-times", "two-zero-rows-between", "column-pairs-equal", "reversed-identity",
-                                  "low-rank-with-zero-rows", "lower-triangular-ones", "zero-column-bands-and-sums"])
+                                  "low-rank-with-zero-rows", "lower-triangular-ones", "zero-column-bands-and-sums",
+                                  "tall-every-row-seven-times", "tall-column-pairs-zero-rows"])
 @pytest.mark.parametrize("full", [True, False], ids=["rref", "upper"])
 def test_rref_structured_blocked(pkg, block_words, name, full):
     global _STRUCT

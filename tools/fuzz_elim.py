@@ -1,6 +1,7 @@
 """Randomised structure fuzz of the BLOCKED elimination path (more than 1024 rows, or too large for the one-workgroup kernel) against
 the oracle (development tool; round 5: the stash, the two-row update, the in-lane insertion loop and their fallbacks all sit in this path).
-    python tools/fuzz_elim.py [count] [seed]
+    python tools/fuzz_elim.py [count] [seed] [tall]
+("tall": 49,000-140,000 rows x 65-320 columns -- from 192 rows per update workgroup on the publication goes ahead of the update's end.)
 Every case draws a shape, a column-block width and a recipe of planted structure: low rank, zero rows, rows repeated k times in a run,
 equal column pairs, zero column bands, rows that are sums of others, a shuffled row order; reduced and upper form are both checked."""
 import os, sys
@@ -12,11 +13,12 @@ import m4ri_rust_amd as pkg
 
 count = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+TALL = len(sys.argv) > 3 and sys.argv[3] == "tall"
 
 
 def make(it):
-    m = int(rng.integers(1025, 5200))
-    n = int(np.exp(rng.uniform(np.log(65), np.log(5000))))
+    m = int(rng.integers(49000, 140000)) if TALL else int(rng.integers(1025, 5200))
+    n = int(np.exp(rng.uniform(np.log(65), np.log(320 if TALL else 5000))))
     recipe = []
     if rng.random() < 0.5:
         r = int(np.exp(rng.uniform(0, np.log(min(m, n)))))
