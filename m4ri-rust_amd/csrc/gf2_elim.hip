@@ -60,9 +60,20 @@ __device__ unsigned long long *gf2k_elim_stamps;
 extern "C" hipError_t gf2k_dev_set_elim_stamps(unsigned long long *p) {
   return hipMemcpyToSymbol(HIP_SYMBOL(gf2k_elim_stamps), &p, sizeof(p));
 }
+// (-DELIM_STAMP_TOTAL_ONLY: only the last stamp of either workgroup fires, i.e. stamps[5] and stamps[21] hold the whole chain from the
+// workgroup's start without the stamps' own cost in between.  A stamp is a global read-modify-write by one thread, ~500 cycles on its own --
+// but one that FOLLOWS another closely reads the running clock the other has just stored and waits for that store: the intervals "barrier
+// behind the re-reductions" and "barrier behind another wave's insertions" (5,000 and 2,500 cycles in the stamped runs) are mostly that;
+// every wave has arrived at the first of those barriers 1,700-2,800 cycles after the loop's entry (measured with per-wave stamps).  The
+// whole look-ahead chain of a 4096-row step: 33,500 cycles unstamped against 38,000 as the sum of the stamped stages.)
+#ifdef ELIM_STAMP_TOTAL_ONLY
+#define ELIM_STAMP_ON(k) ((k) == 5)
+#else
+#define ELIM_STAMP_ON(k) true
+#endif
 #define ELIM_STAMP(k)                                                                  \
   do {                                                                                 \
-    if (COH && gf2k_elim_stamps && threadIdx.x == 0) {                                 \
+    if (ELIM_STAMP_ON(k) && COH && gf2k_elim_stamps && threadIdx.x == 0) {             \
       const unsigned long long now_ = __builtin_amdgcn_s_memtime();                    \
       gf2k_elim_stamps[k] += now_ - gf2k_elim_stamps[15];                              \
       gf2k_elim_stamps[15] = now_;                                                     \
@@ -71,7 +82,7 @@ extern "C" hipError_t gf2k_dev_set_elim_stamps(unsigned long long *p) {
 // the same for ONE update workgroup (the middle one of the launch): stamps[16 + k], its own running clock in stamps[31]
 #define UPD_STAMP(k)                                                                   \
   do {                                                                                 \
-    if (LOOK && gf2k_elim_stamps && threadIdx.x == 0 && blockIdx.x == (unsigned)(nupd / 2)) { \
+    if ((ELIM_STAMP_ON(k) || (k) == 0) && LOOK && gf2k_elim_stamps && threadIdx.x == 0 && blockIdx.x == (unsigned)(nupd / 2)) { \
       const unsigned long long now_ = __builtin_amdgcn_s_memtime();                    \
       if (k) gf2k_elim_stamps[16 + k] += now_ - gf2k_elim_stamps[31];                  \
       gf2k_elim_stamps[31] = now_;                                                     \
