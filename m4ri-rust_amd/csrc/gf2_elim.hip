@@ -53,8 +53,8 @@ __device__ __forceinline__ int rdlane32(int v, int lane) {
 }
 
 // Where does a fused step's time go?  (tools/elim_stamps.py, development builds only.)  When set, thread 0 of the look-ahead workgroup adds
-// the shader cycles of its stages to stamps[0..7] (launch start -> every update workgroup has rewritten the next column -> first
-// pass's candidates loaded -> basis complete -> every update workgroup done -> published) and counts the steps in stamps[8].
+// the shader cycles of its stages to stamps[0..11] (launch start -> search starts -> first pass's candidates loaded -> basis complete ->
+// the update workgroups' counter reached -> published; 7 / 9 / 10 / 11: inside the search loop) and counts the steps in stamps[8].
 #ifdef GF2K_DEV_VARIANTS
 __device__ unsigned long long *gf2k_elim_stamps;
 extern "C" hipError_t gf2k_dev_set_elim_stamps(unsigned long long *p) {
@@ -166,7 +166,7 @@ __device__ __forceinline__ bool elim_pivot_step(ElimPivotShared &sm, const u64 *
   if (tid < 256) s_chosen[tid] = 0;
   unsigned char f0 = 1;                                // flag of row scan0 + tid before this step (first pass, tid < 256)
   __syncthreads();
-  ELIM_STAMP(1);  // (after the wait for the next column)
+  ELIM_STAMP(1);  // (the search starts: until the stash there was a wait for the next column in front of this)
   // the first pass looks at 256 rows only (one wave per SIMD: nearly always enough for 64 pivots, and the waves that
   // re-reduce their candidates after the first wave's insertions do not compete for issue slots); then 1024 per pass
   int csz = 256;
