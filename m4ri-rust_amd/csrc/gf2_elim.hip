@@ -128,8 +128,8 @@ struct ElimPivotShared {
 // applied, [256, 512) = those rows' flags; lives behind ptab's 64 x 64 + 256 words.
 constexpr int kElimStashOff = 64 * 64 + 256;
 
-// loads that see what other workgroups of the SAME launch stored with agent scope (the look-ahead search reads the word column the
-// update workgroups have just rewritten; L2 is not coherent across XCDs for plain accesses)
+// loads that see what other workgroups of the SAME launch stored with agent scope (the look-ahead workgroup reads rows the update
+// workgroups have just rewritten; L2 is not coherent across XCDs for plain accesses)
 template <bool COH, typename T>
 __device__ __forceinline__ T elim_ld(const T *p) {
   if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -137,8 +137,9 @@ __device__ __forceinline__ T elim_ld(const T *p) {
 }
 
 // The pivot step of word column j of the block: SEARCH (reads the column's word of the candidate rows and their flags, keeps the
-// basis in LDS, writes nothing to global memory), then `between()` (the look-ahead form waits there until every update workgroup
-// of the launch has finished), then PUBLISH (flags, state, pivot columns, the raw chosen rows and the selector map).
+// basis in LDS, writes nothing to global memory), then `between(need_all)` (the look-ahead form waits there until the rows it is
+// going to read have landed: the PRIORITY rows, or -- need_all -- every update workgroup's; see EARLY PUBLICATION in the update
+// kernel), then PUBLISH (flags, state, pivot columns, the raw chosen rows and the selector map).
 // THE STASH (round 5).  The look-ahead search of the next step needs the next word column of its candidate rows AFTER the step
 // published here has been applied -- it used to wait for every update workgroup of its launch to rewrite that column first (5-9 us
 // of a step, the largest single stage once the search loops were rewritten).  But the publisher can work those 256 words out
@@ -560,8 +561,8 @@ __device__ __forceinline__ bool elim_wait_count(int *cnt, int want, int *err) {
 }
 
 // LOOK (round 4): the launch has one workgroup more than it has update workgroups.  The extra workgroup runs the pivot SEARCH of
-// step j + 1 while the others update, waits for st->cnt2 (everything updated), and PUBLISHES step j + 1 (flags, state, raw pivot
-// rows, selector map).  A step is then one launch, and the one-CU search runs beside the update instead of behind it.
+// step j + 1 while the others update, waits for st->cnt2 (everything updated; on large matrices for st->cntP only: the priority rows),
+// and PUBLISHES step j + 1 (flags, state, raw pivot rows, selector map).  A step is then one launch, and the one-CU search runs beside the update instead of behind it.
 // What the search reads -- word column j + 1 of its candidate rows as step j leaves it -- comes from THE STASH of the previous
 // publication (elim_pivot_step), so it starts with the launch.  (Round 4 to mid round 5: every update workgroup rewrote that column
 // for its rows first and raised st->cnt1, and the search waited for all of them: 4-5 us at the head of every update workgroup --
